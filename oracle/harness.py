@@ -1,0 +1,185 @@
+"""TEST INFRASTRUCTURE — ctypes view of oracle/driver.c.
+
+One `Driver` wraps one `tOptSet` inside a shared library that exports the
+drv_* entry points.  The same class drives the reference build
+(oracle/_ref/libref_*.so), the CPU restatement (oracle/liboracle_*.so) and the
+HIP product's drop-in symbols (libilqg_*_hip.so), so parity tests read the
+same on all three.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# CarParking demo parameters, reference examples/CarParking/testCar.m:2-11
+CAR_PARAMS = dict(
+    d=[2.0], h=[0.03],
+    pf=[0.01, 0.01, 0.01, 1.0], cf=[0.1, 0.1, 1.0, 0.3],
+    cu=[1e-2, 1e-4], cx=[1e-3, 1e-3], px=[0.1, 0.1],
+    limW=[-0.5, 0.5], limA=[-2.0, 2.0],
+)
+CAR_X0 = [1.0, 1.0, 1.5 * np.pi, 0.0]  # testCar.m:16
+CAR_N = 500                              # testCar.m:14
+
+
+def lib_path(kind, problem="carparking", full_ddp=0):
+    """kind: 'ref' (reference sources) or 'oracle' (CPU restatement)"""
+    if kind == "ref":
+        return os.path.join(HERE, "_ref", "libref_%s_fd%d.so" % (problem, full_ddp))
+    if kind == "oracle":
+        return os.path.join(HERE, "liboracle_%s_fd%d.so" % (problem, full_ddp))
+    raise ValueError(kind)
+
+
+def _bind(lib):
+    lib.drv_dims.argtypes = [_ip]
+    lib.drv_param_name.restype = C.c_char_p
+    lib.drv_param_name.argtypes = [C.c_int]
+    lib.drv_param_size.argtypes = [C.c_int]
+    lib.drv_create.restype = C.c_void_p
+    lib.drv_create.argtypes = [C.c_int]
+    lib.drv_destroy.argtypes = [C.c_void_p]
+    lib.drv_set_param.argtypes = [C.c_void_p, C.c_char_p, _dp, C.c_int]
+    lib.drv_set_opt.restype = C.c_char_p
+    lib.drv_set_opt.argtypes = [C.c_void_p, C.c_char_p, _dp, C.c_int]
+    lib.drv_init.argtypes = [C.c_void_p, _dp, _dp]
+    for f in ("drv_calc_derivs", "drv_back_pass", "drv_solve"):
+        getattr(lib, f).argtypes = [C.c_void_p]
+    lib.drv_line_search.argtypes = [C.c_void_p, C.c_int]
+    lib.drv_accept.argtypes = [C.c_void_p]
+    lib.drv_forward_pass.argtypes = [C.c_void_p, C.c_double, _dp]
+    lib.drv_set_lambda.argtypes = [C.c_void_p, C.c_double]
+    lib.drv_get_traj.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+    lib.drv_get_gains.argtypes = [C.c_void_p, _dp, _dp]
+    lib.drv_set_gains.argtypes = [C.c_void_p, _dp, _dp]
+    lib.drv_record_size.restype = C.c_int
+    lib.drv_get_derivs.argtypes = [C.c_void_p, _dp, _dp]
+    lib.drv_set_derivs.argtypes = [C.c_void_p, _dp, _dp]
+    lib.drv_get_scalars.argtypes = [C.c_void_p, _dp]
+    lib.drv_get_log_linesearch.argtypes = [C.c_void_p, C.c_int]
+    lib.drv_get_trace.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
+    return lib
+
+
+class Driver:
+    SCALARS = ("cost", "new_cost", "dcost", "expected", "lambda", "g_norm", "dV0", "dV1", "iterations")
+
+    def __init__(self, path, n_hor, params=None, opts=None):
+        self.lib = _bind(C.CDLL(path))
+        dims = np.zeros(6, dtype=np.int32)
+        self.lib.drv_dims(dims)
+        self.nx, self.nu, self.full_ddp, self.sizeof_el, self.n_params, self.has_hx = [int(v) for v in dims]
+        self.sxx = self.nx * (self.nx + 1) // 2
+        self.suu = self.nu * (self.nu + 1) // 2
+        self.N = n_hor
+        self.h = self.lib.drv_create(n_hor)
+        self.rec = self.lib.drv_record_size()
+        for k, v in (params or {}).items():
+            self.set_param(k, v)
+        for k, v in (opts or {}).items():
+            err = self.set_opt(k, v)
+            if err:
+                raise ValueError("option %s: %s" % (k, err))
+
+    def close(self):
+        if self.h:
+            self.lib.drv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def param_desc(self):
+        return [(self.lib.drv_param_name(i).decode(), self.lib.drv_param_size(i)) for i in range(self.n_params)]
+
+    def set_param(self, name, v):
+        v = np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64)
+        rc = self.lib.drv_set_param(self.h, name.encode(), v, v.size)
+        if rc:
+            raise ValueError("parameter %s: rc %d" % (name, rc))
+
+    def set_opt(self, name, v):
+        v = np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64)
+        r = self.lib.drv_set_opt(self.h, name.encode(), v, v.size)
+        return r.decode() if r else None
+
+    def init(self, x0, u0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        u0 = np.ascontiguousarray(u0, dtype=np.float64).reshape(self.N, self.nu)
+        return self.lib.drv_init(self.h, x0, u0)
+
+    def calc_derivs(self):
+        return self.lib.drv_calc_derivs(self.h)
+
+    def back_pass(self):
+        return self.lib.drv_back_pass(self.h)
+
+    def line_search(self, it=0):
+        return self.lib.drv_line_search(self.h, it)
+
+    def accept(self):
+        self.lib.drv_accept(self.h)
+
+    def forward_pass(self, alpha):
+        c = np.zeros(1)
+        ok = self.lib.drv_forward_pass(self.h, float(alpha), c)
+        return ok, float(c[0])
+
+    def set_lambda(self, lam):
+        self.lib.drv_set_lambda(self.h, float(lam))
+
+    def solve(self):
+        return self.lib.drv_solve(self.h)
+
+    def traj(self, which=0):
+        x = np.zeros((self.N + 1, self.nx))
+        u = np.zeros((self.N, self.nu))
+        self.lib.drv_get_traj(self.h, which, x, u)
+        return x, u
+
+    def gains(self):
+        l = np.zeros((self.N, self.nu))
+        L = np.zeros((self.N, self.nu * self.nx))
+        self.lib.drv_get_gains(self.h, l, L)
+        return l, L
+
+    def set_gains(self, l, L):
+        self.lib.drv_set_gains(self.h, np.ascontiguousarray(l, dtype=np.float64), np.ascontiguousarray(L, dtype=np.float64))
+
+    def derivs(self):
+        rec = np.zeros((self.N, self.rec))
+        fin = np.zeros(self.nx + self.sxx)
+        self.lib.drv_get_derivs(self.h, rec, fin)
+        return rec, fin
+
+    def set_derivs(self, rec, fin):
+        self.lib.drv_set_derivs(self.h, np.ascontiguousarray(rec, dtype=np.float64), np.ascontiguousarray(fin, dtype=np.float64))
+
+    def scalars(self):
+        out = np.zeros(9)
+        self.lib.drv_get_scalars(self.h, out)
+        return dict(zip(self.SCALARS, out.tolist()))
+
+    def log_linesearch(self, it=0):
+        return self.lib.drv_get_log_linesearch(self.h, it)
+
+    def trace(self, cap=4096):
+        arrs = [np.zeros(cap) for _ in range(6)]
+        ai = np.zeros(cap, dtype=np.int32)
+        bp = np.zeros(cap, dtype=np.int32)
+        n = self.lib.drv_get_trace(self.h, cap, *arrs, ai, bp)
+        n = min(n, cap)
+        names = ("lambda", "g_norm", "dV0", "dV1", "cost", "new_cost")
+        out = {k: a[:n].copy() for k, a in zip(names, arrs)}
+        out["alpha_idx"] = ai[:n].copy()
+        out["bp_calls"] = bp[:n].copy()
+        return out

@@ -1,0 +1,814 @@
+#!/usr/bin/env python3
+"""Emit iLQG_problem.h / iLQG_func.c for a symbolic optimal-control problem.
+
+The reference generates these two files with Maxima + gentran from the
+templates iLQG_problem.tem / iLQG_func.tem (driver make_iLQG.mac:7-8,
+printers genenerator_main.mac:204-447).  Maxima is not available in this
+environment and the reference does not commit generated files
+(.gitignore:36-37), so this tool produces conforming files with sympy.  It is
+a build-time tool only; nothing on the solver path imports it.
+
+What "conforming" means (layout contract, all from the reference):
+  * iLQG_problem.h: N_X, N_U, sizeofQxx/Quu/Qxu, trajEl_t / trajFin_t member
+    order, traj_t, multiplier structs           (iLQG_problem.tem:16-89)
+  * array layouts: fx[r+c*n], packed upper-tri hessians, fxx[r*sxx+UTRI(c,d)],
+    fxu[r*n*m + d*n + c]                        (genenerator_main.mac:204-281)
+  * function names, signatures and the order of operations inside
+    forward_pass / calc_derivs / limitsU / clampU / init_opt
+                                                (iLQG_func.tem:40-521)
+  * every non-constant assignment is followed by a NaN/Inf guard that prints
+    and returns 0                               (genenerator_main.mac:189-199)
+  * constant derivative entries are written once by init_opt, time-varying
+    ones by calc_derivs                         (iLQG_func.tem:262-347)
+  * auxiliary variables and their derivatives are struct members evaluated
+    once per step and reused                    (gen_dep_graph.mac:187-229)
+
+Augmented-Lagrangian constraints (hfe/hfi/hle/hli) are not supported yet; the
+multiplier structs are emitted empty and update_multipliers is a no-op.
+
+Usage:  python tools/gen_problem.py problems/defs/carparking.py problems/carparking
+"""
+import importlib.util
+import itertools
+import os
+import sys
+
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+
+
+# --------------------------------------------------------------------------
+# problem description
+# --------------------------------------------------------------------------
+class Problem:
+    """Symbolic problem: states, inputs, parameters, auxiliaries, f, L, F, h."""
+
+    def __init__(self, name):
+        self.name = name
+        self.x = []
+        self.u = []
+        self.params = {}  # name -> size (1 scalar, >1 vector, -1 per time step)
+        self.aux = []     # list of (symbol, definition)
+        self.f = None
+        self.L = None
+        self.F = None
+        self.h = []       # input constraints h_i < 0
+
+    def states(self, names):
+        self.x = list(sp.symbols(names, real=True))
+        return self.x
+
+    def inputs(self, names):
+        self.u = list(sp.symbols(names, real=True))
+        return self.u
+
+    def scalar(self, name):
+        self.params[name] = 1
+        return sp.Symbol(name, real=True)
+
+    def vector(self, name, size):
+        self.params[name] = size
+        return [sp.Symbol("%s[%d]" % (name, i), real=True) for i in range(size)]
+
+    def per_step(self, name):
+        """parameter with one value per time step, referenced as name[k]"""
+        self.params[name] = -1
+        return sp.Symbol("%s[k]" % name, real=True)
+
+    def auxiliary(self, name, definition):
+        s = sp.Symbol(name, real=True)
+        self.aux.append((s, sp.sympify(definition)))
+        return s
+
+
+# --------------------------------------------------------------------------
+# C printing
+# --------------------------------------------------------------------------
+class _Printer(C99CodePrinter):
+    """Prints small rational powers as products / sqrt so host libm and the
+    device math library see the same cheap operations."""
+
+    def _print_Pow(self, expr):
+        b, e = expr.base, expr.exp
+        if e.is_Rational:
+            num, den = abs(e.p), e.q
+            if den in (1, 2) and num <= 8:
+                bs = self._print(b)
+                if not (b.is_Symbol or b.is_Function):
+                    bs = "(" + bs + ")"
+                factors = []
+                if den == 2:
+                    whole, half = divmod(num, 2)
+                    factors += [bs] * whole
+                    if half:
+                        factors.append("sqrt(%s)" % self._print(b))
+                else:
+                    factors += [bs] * num
+                body = "*".join(factors)
+                if len(factors) > 1:
+                    body = "(" + body + ")"
+                return body if e.p > 0 else "1.0/" + body
+        return super()._print_Pow(expr)
+
+    def _print_Integer(self, expr):
+        return "%d.0" % int(expr)
+
+    def _print_Rational(self, expr):
+        return "%d.0/%d.0" % (expr.p, expr.q)
+
+
+_printer = _Printer({"precision": 17})
+
+
+def cexpr(e):
+    return _printer.doprint(e)
+
+
+def utri(r, c):
+    return c * (c + 1) // 2 + r
+
+
+# --------------------------------------------------------------------------
+# derivative engine with auxiliary variables (chain rule through symbols)
+# --------------------------------------------------------------------------
+class Deriver:
+    """Total derivatives of expressions that contain auxiliary symbols.
+
+    Each auxiliary A has a definition def(A) in terms of states, inputs,
+    parameters and earlier auxiliaries.  d A / d z is represented by a new
+    symbol A_z whose definition is the total derivative of def(A); second
+    derivatives likewise.  This mirrors the reference's gradef-based
+    auxiliary derivatives (gen_dep_graph.mac:187-229).
+    """
+
+    def __init__(self, prob):
+        self.prob = prob
+        self.base = list(prob.x) + list(prob.u)
+        self.base_name = {}
+        for i, s in enumerate(prob.x):
+            self.base_name[s] = "x%d" % i
+        for i, s in enumerate(prob.u):
+            self.base_name[s] = "u%d" % i
+        self.defs = {}       # dependent symbol -> definition
+        self.order = []      # evaluation order of dependent symbols
+        self.kind = {}       # symbol -> 'aux' | 'd1' | 'd2'
+        self.dcache = {}     # (symbol, z) -> derivative symbol or 0
+        self._tags = {}      # derivative symbol -> (aux name, sorted variable tags)
+        for s, d in prob.aux:
+            self.defs[s] = d
+            self.order.append(s)
+            self.kind[s] = "aux"
+
+    def total_diff(self, e, z):
+        r = sp.diff(e, z)
+        for s in [s for s in e.free_symbols if s in self.defs]:
+            pd = sp.diff(e, s)
+            if pd != 0:
+                ds = self.dsym(s, z)
+                if ds != 0:
+                    r += pd * ds
+        return r
+
+    def dsym(self, s, z):
+        key = (s, z)
+        if key in self.dcache:
+            return self.dcache[key]
+        # canonical name: aux name + sorted variable tags
+        d = sp.simplify(self.total_diff(self.defs[s], z))
+        if d == 0:
+            self.dcache[key] = sp.Integer(0)
+            return self.dcache[key]
+        root, tags = self._root_tags(s)
+        tags = sorted(tags + [self.base_name[z]])
+        name = "d%s_%s" % (root, "".join(tags))
+        existing = [q for q in self.defs if q.name == name]
+        if existing:  # symmetric second derivative already created
+            self.dcache[key] = existing[0]
+            return existing[0]
+        ns = sp.Symbol(name, real=True)
+        self.defs[ns] = d
+        self.order.append(ns)
+        self.kind[ns] = "d1" if self.kind[s] == "aux" else "d2"
+        self._tags[ns] = (root, tags)
+        self.dcache[key] = ns
+        return ns
+
+    def _root_tags(self, s):
+        if s in self._tags:
+            r, t = self._tags[s]
+            return r, list(t)
+        return s.name, []
+
+    def depends_on(self, e, syms):
+        """does e depend (transitively through auxiliaries) on any of syms"""
+        todo = list(e.free_symbols)
+        seen = set()
+        while todo:
+            q = todo.pop()
+            if q in seen:
+                continue
+            seen.add(q)
+            if q in syms:
+                return True
+            if q in self.defs:
+                todo += list(self.defs[q].free_symbols)
+        return False
+
+    def closure(self, exprs):
+        """all dependent symbols needed to evaluate exprs, in evaluation order"""
+        need = set()
+        todo = []
+        for e in exprs:
+            todo += [s for s in e.free_symbols if s in self.defs]
+        while todo:
+            q = todo.pop()
+            if q in need:
+                continue
+            need.add(q)
+            todo += [s for s in self.defs[q].free_symbols if s in self.defs]
+        return need
+
+
+# --------------------------------------------------------------------------
+# emitter
+# --------------------------------------------------------------------------
+class Emitter:
+    def __init__(self, prob):
+        self.p = prob
+        self.n = len(prob.x)
+        self.m = len(prob.u)
+        self.D = Deriver(prob)
+        self.param_names = sorted(prob.params)  # internal consistency is all that matters
+        self.time_syms = set(prob.x) | set(prob.u)
+        for nm in self.param_names:
+            if prob.params[nm] == -1:
+                self.time_syms.add(sp.Symbol("%s[k]" % nm, real=True))
+        self._derive()
+
+    # ---- symbolic work -------------------------------------------------
+    def _derive(self):
+        p, D, n, m = self.p, self.D, self.n, self.m
+        td = D.total_diff
+        x, u = p.x, p.u
+        self.fx = [[td(p.f[r], x[c]) for c in range(n)] for r in range(n)]
+        self.fu = [[td(p.f[r], u[c]) for c in range(m)] for r in range(n)]
+        self.fxx = [[[td(self.fx[r][c], x[d]) for d in range(n)] for c in range(n)] for r in range(n)]
+        self.fuu = [[[td(self.fu[r][c], u[d]) for d in range(m)] for c in range(m)] for r in range(n)]
+        self.fxu = [[[td(self.fx[r][c], u[d]) for d in range(m)] for c in range(n)] for r in range(n)]
+        self.Lx = [td(p.L, x[r]) for r in range(n)]
+        self.Lu = [td(p.L, u[r]) for r in range(m)]
+        self.Lxx = [[td(self.Lx[r], x[c]) for c in range(n)] for r in range(n)]
+        self.Luu = [[td(self.Lu[r], u[c]) for c in range(m)] for r in range(m)]
+        self.Lxu = [[td(self.Lx[r], u[c]) for c in range(m)] for r in range(n)]
+        if D.depends_on(p.F, set(u)):
+            raise ValueError("F may not depend on u")  # genenerator_main.mac:127-128
+        self.Fx = [td(p.F, x[r]) for r in range(n)]
+        self.Fxx = [[td(self.Fx[r], x[c]) for c in range(n)] for r in range(n)]
+        simp = lambda e: sp.simplify(e) if e != 0 else e
+        for name in ("fx", "fu", "Lxx", "Luu", "Lxu", "Fxx"):
+            setattr(self, name, [[simp(e) for e in row] for row in getattr(self, name)])
+        for name in ("fxx", "fuu", "fxu"):
+            setattr(self, name, [[[simp(e) for e in row] for row in mat] for mat in getattr(self, name)])
+        for name in ("Lx", "Lu", "Fx"):
+            setattr(self, name, [simp(e) for e in getattr(self, name)])
+
+        # input constraints: each depends on exactly one input with coefficient +-1
+        self.cons = []
+        for i, h in enumerate(p.h):
+            hu = [sp.simplify(sp.diff(h, uu)) for uu in u]
+            nz = [j for j, c in enumerate(hu) if c != 0]
+            if len(nz) != 1 or abs(hu[nz[0]]) != 1:
+                raise ValueError("constraint %d must depend on one input with coefficient +-1" % (i + 1))
+            j = nz[0]
+            sign = int(hu[j])
+            lim = sp.simplify(h - sign * u[j])
+            if sign > 0:
+                lim = -lim
+            hx = [td(h, xx) for xx in x]
+            self.cons.append(dict(index=i, input=j, sign=sign, limit=lim, hx=hx, expr=h))
+        self.has_hx = any(e != 0 for c in self.cons for e in c["hx"])
+
+        # which dependent symbols are needed where
+        first_order = list(itertools.chain(
+            p.f, [p.L], *self.fx, *self.fu, self.Lx, self.Lu, *self.Lxx, *self.Luu, *self.Lxu,
+            [c["limit"] for c in self.cons], *[c["hx"] for c in self.cons]))
+        second_order = list(itertools.chain(
+            *[itertools.chain(*mm) for mm in self.fxx],
+            *[itertools.chain(*mm) for mm in self.fuu],
+            *[itertools.chain(*mm) for mm in self.fxu]))
+        self.run_need = D.closure(first_order)
+        self.run_need_full = D.closure(second_order) - self.run_need
+        self.fin_need = D.closure(list(itertools.chain([p.F], self.Fx, *self.Fxx)))
+        for s in self.fin_need:
+            if D.depends_on(D.defs[s], set(u)):
+                raise ValueError("final-cost auxiliary %s depends on an input" % s)
+
+    # ---- symbol -> C name ------------------------------------------------
+    def csub(self, e, where):
+        """substitute C spellings; where in {'run','fin'} selects struct prefix for aux"""
+        e = sp.sympify(e)
+        rep = {}
+        for i, s in enumerate(self.p.x):
+            rep[s] = sp.Symbol("x[%d]" % i)
+        for i, s in enumerate(self.p.u):
+            rep[s] = sp.Symbol("u[%d]" % i)
+        for pi, nm in enumerate(self.param_names):
+            sz = self.p.params[nm]
+            if sz == 1:
+                rep[sp.Symbol(nm, real=True)] = sp.Symbol("p[%d][0]" % pi)
+            elif sz == -1:
+                rep[sp.Symbol("%s[k]" % nm, real=True)] = sp.Symbol("p[%d][k]" % pi)
+            else:
+                for j in range(sz):
+                    rep[sp.Symbol("%s[%d]" % (nm, j), real=True)] = sp.Symbol("p[%d][%d]" % (pi, j))
+        for s in self.D.defs:
+            rep[s] = sp.Symbol(self.macro_name(s))
+        return e.xreplace(rep)
+
+    def macro_name(self, s):
+        return ("aux_" if self.D.kind[s] == "aux" else "daux_") + s.name
+
+    def is_time_var(self, e):
+        return self.D.depends_on(sp.sympify(e), self.time_syms)
+
+    def is_const_number(self, e):
+        return len(sp.sympify(e).free_symbols) == 0
+
+    # ---- statement printers ---------------------------------------------
+    def assign(self, lhs, e, ind=4, ret="0", guard=True):
+        pad = " " * ind
+        e = sp.sympify(e)
+        rhs = cexpr(self.csub(e, None))
+        out = "%s%s= %s;\n" % (pad, lhs, rhs)
+        if guard and not self.is_const_number(e):
+            out += ('%sif(isNANorINF(%s)) { PRNT("    @k %%d: %s in line %%d is nan or inf: %%g\\n", k, __LINE__-1, %s); return %s; }\n'
+                    % (pad, lhs, lhs.replace('"', ""), lhs, ret))
+        return out
+
+    def block(self, items, want_time_var, ind=4):
+        """items: list of (lhs, expr). emit those whose time-variance matches."""
+        out = ""
+        for lhs, e in items:
+            if want_time_var is None or self.is_time_var(e) == want_time_var:
+                out += self.assign(lhs, e, ind)
+        return out
+
+    def jaco_items(self, name, mat):
+        nr, nc = len(mat), len(mat[0])
+        return [("t->%s[%d]" % (name, r + c * nr), mat[r][c]) for c in range(nc) for r in range(nr)]
+
+    def grad_items(self, name, v):
+        return [("t->%s[%d]" % (name, r), v[r]) for r in range(len(v))]
+
+    def hess_items(self, name, mat):
+        nr, nc = len(mat), len(mat[0])
+        items, idx = [], 0
+        for c in range(nc):
+            rows = range(c + 1) if nr == nc else range(nr)
+            for r in rows:
+                items.append(("t->%s[%d]" % (name, idx), mat[r][c]))
+                idx += 1
+        return items
+
+    def jaco2_items(self, name, ten):
+        n1, n2, n3 = len(ten), len(ten[0]), len(ten[0][0])
+        items, idx = [], 0
+        for r in range(n1):
+            for d in range(n3):
+                cols = range(d + 1) if n2 == n3 else range(n2)
+                for c in cols:
+                    items.append(("t->%s[%d]" % (name, idx), ten[r][c][d]))
+                    idx += 1
+        return items
+
+    def all_zero(self, ten):
+        return all(e == 0 for mat in ten for row in mat for e in row)
+
+    # ---- aux ordering ----------------------------------------------------
+    def aux_syms(self, need, kinds):
+        return [s for s in self.D.order if s in need and self.D.kind[s] in kinds]
+
+    def aux_block(self, need, kinds, want_time_var, u_dep=None, ind=4):
+        out = ""
+        for s in self.aux_syms(need, kinds):
+            d = self.D.defs[s]
+            tv = self.is_time_var(d)
+            if want_time_var is not None and tv != want_time_var:
+                continue
+            if u_dep is not None and self.D.depends_on(d, set(self.p.u)) != u_dep:
+                continue
+            out += self.assign(self.macro_name(s), d, ind)
+        return out
+
+    # ---- files -------------------------------------------------------------
+    def problem_h(self):
+        n, m = self.n, self.m
+        run_members = "".join("    double %s;\n" % s.name for s in self.aux_syms(self.run_need, ("aux", "d1", "d2")))
+        run_members_full = "".join("    double %s;\n" % s.name for s in self.aux_syms(self.run_need_full, ("aux", "d1", "d2")))
+        fin_members = "".join("    double %s;\n" % s.name for s in self.aux_syms(self.fin_need, ("aux", "d1", "d2")))
+        return f"""/* Problem header for '{self.p.name}' emitted by tools/gen_problem.py. Do not edit.
+ * Layout contract: reference iLQG_problem.tem:16-89. */
+#ifndef ILQG_PROBLEM_H
+#define ILQG_PROBLEM_H
+
+#include <math.h>
+#include "mex.h"
+#ifndef  HAVE_OCTAVE
+#include "matrix.h"
+#endif
+
+#define isNANorINF(v) (mxIsNaN(v) || mxIsInf(v))
+#define INF mxGetInf()
+
+#define N_X {n}
+#define N_U {m}
+
+#define sizeofQxx {n * (n + 1) // 2}
+#define sizeofQuu {m * (m + 1) // 2}
+#define sizeofQxu {n * m}
+
+/* additive hints for the batched backend (absent in Maxima-generated headers,
+ * which are then treated as the general case) */
+#define ILQG_PROBLEM_NAME "{self.p.name}"
+#define ILQG_STATE_DEPENDENT_LIMITS {1 if self.has_hx else 0}
+
+typedef struct {{
+    double x[N_X];
+    double u[N_U];
+    double lower[N_U];
+    double upper[N_U];
+    double lower_sign[N_U];
+    double upper_sign[N_U];
+    double lower_hx[N_X*N_U];
+    double upper_hx[N_X*N_U];
+
+    double l[N_U];
+    double L[N_U*N_X];
+    double c;
+    double cx[N_X];
+    double cxx[sizeofQxx];
+    double cu[N_U];
+    double cuu[sizeofQuu];
+    double cxu[sizeofQxu];
+    double fx[N_X*N_X];
+    double fu[N_X*N_U];
+#if FULL_DDP
+    double fxx[N_X*sizeofQxx];
+    double fuu[N_X*sizeofQuu];
+    double fxu[N_X*sizeofQxu];
+#endif
+{run_members}#if FULL_DDP
+{run_members_full}#endif
+}} trajEl_t;
+
+typedef struct {{
+    double x[N_X];
+
+    double c;
+    double cx[N_X];
+    double cxx[sizeofQxx];
+{fin_members}}} trajFin_t;
+
+typedef struct {{
+    trajEl_t* t;
+    trajFin_t f;
+}} traj_t;
+
+typedef struct {{
+}} multipliersEl_t;
+
+typedef struct {{
+}} multipliersFin_t;
+
+typedef struct {{
+    multipliersEl_t* t;
+    multipliersFin_t f;
+}} multipliers_t;
+
+#endif // ILQG_PROBLEM_H
+"""
+
+    def func_c(self):
+        p, n, m = self.p, self.n, self.m
+        o = []
+        w = o.append
+        w(f"/* Problem functions for '{p.name}' emitted by tools/gen_problem.py. Do not edit.\n"
+          " * Function set, signatures and evaluation order: reference iLQG_func.tem:40-521. */\n")
+        w('#include "iLQG.h"\n#include "matMult.h"\n\n')
+        w("#define mcond(cond, a, dummy, b) ((cond)? a: b)\n#define sec(x) (1.0/cos(x))\n#define csc(x) (1.0/sin(x))\n\n")
+        w("int n_params= %d;\n\n" % len(self.param_names))
+        for i, nm in enumerate(self.param_names):
+            w('tParamDesc p_name%d= {"%s", %d, 0};\n' % (i + 1, nm, p.params[nm]))
+        w("int n_vars= 0;\n\n")
+        w("tParamDesc *paramdesc[]= {%s};\n\n" % ", ".join("&p_name%d" % (i + 1) for i in range(len(self.param_names))))
+        for s in self.D.order:
+            if s in self.run_need or s in self.run_need_full or s in self.fin_need:
+                w("#define %s t->%s\n" % (self.macro_name(s), s.name))
+        w("\n")
+        w("static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o);\n"
+          "static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o);\n"
+          "static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o);\n"
+          "static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o);\n"
+          "static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o);\n"
+          "static int bp_derivsL(trajEl_t *t, int k, double **p);\n"
+          "static int bp_derivsF(trajFin_t *t, int k, double **p);\n\n")
+
+        # --- cost and dynamics ---
+        w("static int ddpL(trajEl_t *t, int k, tOptSet *o) {\n    const double *x= t->x;\n    const double *u= t->u;\n    double **p= o->p;\n\n")
+        w(self.assign("t->c", p.L))
+        w("\n    return 1;\n}\n\n")
+        w("static int ddpF(trajFin_t *t, tOptSet *o) {\n    const double *x= t->x;\n    const int k= o->n_hor;\n    double **p= o->p;\n\n")
+        w(self.assign("t->c", p.F))
+        w("\n    return 1;\n}\n\n")
+        w("static int ddpf(double x_next[], trajEl_t *t, int k, double **p, int N) {\n    const double *x= t->x;\n    const double *u= t->u;\n\n")
+        for r in range(n):
+            w(self.assign("x_next[%d]" % r, p.f[r]))
+        w("    return 1;\n}\n\n")
+
+        # --- input constraints ---
+        w("void clampU(double *u, trajEl_t *t, int k, double **p, int N) {\n    double limit;\n    const double *x= t->x;\n\n")
+        for c in self.cons:
+            w("    // constraint h[%d]= %s\n" % (c["index"] + 1, sp.sstr(c["expr"])))
+            w(self.assign("limit", c["limit"], guard=False))
+            j = c["input"]
+            if c["sign"] > 0:
+                w("    if(u[%d]>limit) u[%d]= limit;\n\n" % (j, j))
+            else:
+                w("    if(u[%d]<limit) u[%d]= limit;\n\n" % (j, j))
+        w("}\n\n")
+
+        w("static void limitsU(trajEl_t *t, int k, double **p, int N) {\n"
+          "    int i, j;\n    int lower_idx[N_U], upper_idx[N_U], *idx_;\n    double limit;\n"
+          "    const double *x= t->x;\n    double *hx_, *h_sign;\n\n"
+          "    for(i= 0; i<N_U; i++) {\n        lower_idx[i]= -1;\n        upper_idx[i]= -1;\n"
+          "        t->lower[i]= -INF;\n        t->upper[i]= INF;\n    }\n\n")
+        for c in self.cons:
+            j = c["input"]
+            w("    // constraint h[%d]= %s\n" % (c["index"] + 1, sp.sstr(c["expr"])))
+            w(self.assign("limit", c["limit"], guard=False))
+            if c["sign"] > 0:
+                w("    if(t->upper[%d]>limit) { t->upper[%d]= limit; upper_idx[%d]= %d; }\n\n" % (j, j, j, c["index"]))
+            else:
+                w("    if(t->lower[%d]<limit) { t->lower[%d]= limit; lower_idx[%d]= %d; }\n\n" % (j, j, j, c["index"]))
+        w("    for(i= 0; i<N_U; i++) {\n        t->lower[i]-= t->u[i];\n        t->upper[i]-= t->u[i];\n    }\n\n"
+          "    for(j= 0; j<2; j++) {\n        if(j==0) {\n            idx_= lower_idx;\n            hx_= t->lower_hx;\n            h_sign= t->lower_sign;\n"
+          "        } else {\n            idx_= upper_idx;\n            hx_= t->upper_hx;\n            h_sign= t->upper_sign;\n        }\n"
+          "        for(i= 0; i<N_U; i++, hx_+= N_X, h_sign++) {\n            switch(idx_[i]) {\n"
+          "                case -1:\n                    h_sign[0]= 0.0;\n                    break;\n")
+        for c in self.cons:
+            w("                case %d:\n" % c["index"])
+            for jx in range(n):
+                w(self.assign("hx_[%d]" % jx, c["hx"][jx], ind=20, guard=False))
+            w("                    h_sign[0]= %d.0;\n                    break;\n" % c["sign"])
+        w("            }\n        }\n    }\n}\n\n")
+
+        # --- forward pass ---
+        w("""int forward_pass(traj_t *c, tOptSet *o, double alpha, double *csum, int cost_only) {
+    int i, k, j;
+    double dx;
+    double *x0= o->x0;
+    int N= o->n_hor;
+    double **params= o->p;
+
+    trajEl_t *t= o->nominal->t;
+    trajEl_t *ct= c->t;
+    trajFin_t *cf= &c->f;
+
+    multipliersEl_t *m= o->multipliers.t;
+    multipliersFin_t *mf= &o->multipliers.f;
+
+    double *x_next;
+
+    csum[0]= 0.0;
+
+    if(!cost_only)
+        for(i= 0; i<N_X; i++) ct->x[i]= x0[i];
+
+    for(k= 0; k<N; k++, t++, ct++, m++) {
+        if(!cost_only) {
+            if(alpha) {
+                /* u = u_nom + alpha*l + L*(x - x_nom), accumulated state by state */
+                for(j= 0; j<N_U; j++)
+                    ct->u[j]= t->u[j] + t->l[j]*alpha;
+                for(i= 0; i<N_X; i++) {
+                    dx= ct->x[i] - t->x[i];
+                    for(j= 0; j<N_U; j++)
+                        ct->u[j]+= t->L[MAT_IDX(j, i, N_U)]*dx;
+                }
+            } else {
+                for(j= 0; j<N_U; j++)
+                    ct->u[j]= t->u[j];
+            }
+        }
+        if(!calcXVariableAux(ct, m, k, o)) return 0;
+
+        if(!cost_only)
+            clampU(ct->u, ct, k, params, N);
+        if(!calcXUVariableAux(ct, m, k, o)) return 0;
+
+        if(!cost_only) {
+            x_next= (k>=N-1)? cf->x: (ct+1)->x;
+            if(!ddpf(x_next, ct, k, params, N)) return 0;
+        }
+
+        if(!ddpL(ct, k, o)) return 0;
+        csum[0]+= ct->c;
+    }
+
+    if(!calcFVariableAux(cf, mf, o)) return 0;
+    if(!ddpF(cf, o)) return 0;
+    csum[0]+= cf->c;
+
+    return 1;
+}
+
+int calc_derivs(tOptSet *o) {
+    int k;
+    int N= o->n_hor;
+
+    trajEl_t *t= o->nominal->t + N - 1;
+    trajFin_t *f= &o->nominal->f;
+
+    multipliersEl_t *m= o->multipliers.t + N - 1;
+    multipliersFin_t *mf= &o->multipliers.f;
+
+    if(!calcFAuxDeriv(f, mf, o)) return 0;
+    if(!bp_derivsF(f, N, o->p)) return 0;
+
+    for(k= N-1; k>=0; k--, t--, m--) {
+        if(!calcLAuxDeriv(t, m, k, o)) return 0;
+        if(!bp_derivsL(t, k, o->p)) return 0;
+
+        limitsU(t, k, o->p, N);
+    }
+    return 1;
+}
+
+""")
+        # --- aux evaluation ---
+        w("static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {\n    const double *x= t->x;\n    double **p= o->p;\n    const double w_pen= o->w_pen_l;\n\n")
+        w(self.aux_block(self.run_need | self.run_need_full, ("aux",), True, u_dep=False))
+        w("    return 1;\n}\n\n")
+        w("static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {\n    const double *x= t->x;\n    const double *u= t->u;\n    double **p= o->p;\n    const double w_pen= o->w_pen_l;\n\n")
+        w(self.aux_block(self.run_need | self.run_need_full, ("aux",), True, u_dep=True))
+        w("    return 1;\n}\n\n")
+        w("static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {\n    const double *x= t->x;\n    double **p= o->p;\n    const double w_pen= o->w_pen_f;\n    const int k= o->n_hor;\n\n")
+        w(self.aux_block(self.fin_need, ("aux",), True))
+        w("    return 1;\n}\n\n")
+        w("static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {\n    const double *x= t->x;\n    const double *u= t->u;\n    const double w_pen= o->w_pen_l;\n    double **p= o->p;\n\n")
+        w(self.aux_block(self.run_need, ("d1", "d2"), True))
+        w("#if FULL_DDP\n")
+        w(self.aux_block(self.run_need_full, ("d1", "d2"), True))
+        w("#endif\n    return 1;\n}\n\n")
+
+        # --- derivatives (time-varying entries) ---
+        w("static int bp_derivsL(trajEl_t *t, int k, double **p) {\n    const double *x= t->x;\n    const double *u= t->u;\n\n// derivatives of f\n")
+        w(self.block(self.jaco_items("fx", self.fx), True))
+        w("\n")
+        w(self.block(self.jaco_items("fu", self.fu), True))
+        w("\n#if FULL_DDP\n")
+        for nm, ten in (("fxx", self.fxx), ("fuu", self.fuu), ("fxu", self.fxu)):
+            if not self.all_zero(ten):
+                w(self.block(self.jaco2_items(nm, ten), True))
+                w("\n")
+        w("#endif\n\n// derivatives of L\n")
+        w(self.block(self.grad_items("cx", self.Lx), True))
+        w("\n")
+        w(self.block(self.hess_items("cxx", self.Lxx), True))
+        w("\n")
+        w(self.block(self.grad_items("cu", self.Lu), True))
+        w("\n")
+        w(self.block(self.hess_items("cuu", self.Luu), True))
+        w("\n")
+        w(self.block(self.hess_items("cxu", self.Lxu), True))
+        w("\n    return 1;\n}\n\n")
+
+        w("static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {\n    const double *x= t->x;\n    const double w_pen= o->w_pen_f;\n    double **p= o->p;\n    const int k= o->n_hor;\n\n")
+        w(self.aux_block(self.fin_need, ("d1", "d2"), True))
+        w("    return 1;\n}\n\n")
+        w("static int bp_derivsF(trajFin_t *t, int k, double **p) {\n    const double *x= t->x;\n\n")
+        w(self.block(self.grad_items("cx", self.Fx), True))
+        w("\n")
+        w(self.block(self.hess_items("cxx", self.Fxx), True))
+        w("    return 1;\n}\n\n")
+
+        # --- constants ---
+        w("static int init_running(trajEl_t *t, tOptSet *o) {\n    int k;\n    double **p= o->p;\n\n    for(k= 0; k<o->n_hor; k++, t++) {\n")
+        w(self.aux_block(self.run_need | self.run_need_full, ("aux",), False, ind=8))
+        w(self.aux_block(self.run_need, ("d1", "d2"), False, ind=8))
+        w("#if FULL_DDP\n")
+        w(self.aux_block(self.run_need_full, ("d1", "d2"), False, ind=8))
+        w("#endif\n\n// derivatives of L\n")
+        for items in (self.grad_items("cx", self.Lx), self.hess_items("cxx", self.Lxx), self.grad_items("cu", self.Lu),
+                      self.hess_items("cuu", self.Luu), self.hess_items("cxu", self.Lxu)):
+            w(self.block(items, False, ind=8))
+            w("\n")
+        w("// derivatives of f\n")
+        w(self.block(self.jaco_items("fx", self.fx), False, ind=8))
+        w("\n")
+        w(self.block(self.jaco_items("fu", self.fu), False, ind=8))
+        w("\n#if FULL_DDP\n")
+        for nm, ten, sz in (("fxx", self.fxx, "N_X*sizeofQxx"), ("fuu", self.fuu, "N_X*sizeofQuu"), ("fxu", self.fxu, "N_X*sizeofQxu")):
+            if self.all_zero(ten):
+                w("        { int i_; for(i_= 0; i_<%s; i_++) t->%s[i_]= 0.0; }\n" % (sz, nm))
+            else:
+                w(self.block(self.jaco2_items(nm, ten), False, ind=8))
+            w("\n")
+        w("#endif\n    }\n\n    return 1;\n}\n\n")
+
+        w("static int init_final(trajFin_t *t, tOptSet *o) {\n    double **p= o->p;\n    const int k= o->n_hor;\n\n")
+        w(self.aux_block(self.fin_need, ("aux",), False))
+        w(self.aux_block(self.fin_need, ("d1", "d2"), False))
+        w(self.block(self.grad_items("cx", self.Fx), False))
+        w("\n")
+        w(self.block(self.hess_items("cxx", self.Fxx), False))
+        w("\n    return 1;\n}\n\n")
+
+        w("""int init_trajectory(traj_t *t, tOptSet *o) {
+    if(!init_running(t->t, o)) return 0;
+    if(!init_final(&t->f, o)) return 0;
+
+    return 1;
+}
+
+static int init_multipliers_running(tOptSet *o) {
+    return 1;
+}
+
+static int init_multipliers_final(tOptSet *o) {
+    return 1;
+}
+
+int init_multipliers(tOptSet *o) {
+    if(!init_multipliers_running(o)) return 0;
+    if(!init_multipliers_final(o)) return 0;
+
+    return 1;
+}
+
+int init_opt(tOptSet *o) {
+    int i;
+
+    for(i= 0; i<NUMBER_OF_THREADS+1; i++)
+        if(!init_trajectory(&o->trajectories[i], o)) return 0;
+
+    o->nominal= &o->trajectories[0];
+    for(i= 1; i<NUMBER_OF_THREADS+1; i++)
+        o->candidates[i-1]= &o->trajectories[i];
+
+    if(!init_multipliers(o)) return 0;
+
+    return 1;
+}
+
+static int update_multipliers_running(tOptSet *o, int init) {
+    return 1;
+}
+
+static int update_multipliers_final(tOptSet *o, int init) {
+    return 1;
+}
+
+int update_multipliers(tOptSet *o, int init) {
+    if(!update_multipliers_running(o, init)) return 0;
+    if(!update_multipliers_final(o, init)) return 0;
+
+    return 1;
+}
+
+int get_g_size() {
+    return(0);
+}
+
+int calcG(double g[], trajEl_t *t, int k, double **p) {
+    return(1);
+}
+""")
+        return "".join(o)
+
+
+def load_problem(path):
+    spec = importlib.util.spec_from_file_location("ilqg_problem_def", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(Problem)
+
+
+def main(argv):
+    if len(argv) != 3:
+        print(__doc__)
+        return 2
+    prob = load_problem(argv[1])
+    em = Emitter(prob)
+    os.makedirs(argv[2], exist_ok=True)
+    with open(os.path.join(argv[2], "iLQG_problem.h"), "w") as f:
+        f.write(em.problem_h())
+    with open(os.path.join(argv[2], "iLQG_func.c"), "w") as f:
+        f.write(em.func_c())
+    print("wrote %s/{iLQG_problem.h,iLQG_func.c}: n=%d m=%d params=%s aux=%s" %
+          (argv[2], em.n, em.m, em.param_names, [s.name for s in em.D.order]))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))
