@@ -183,3 +183,61 @@ class Driver:
         out["alpha_idx"] = ai[:n].copy()
         out["bp_calls"] = bp[:n].copy()
         return out
+
+
+class Kernels:
+    """Direct ctypes access to the small dense kernels exported by a solver
+    library (same C symbols in the reference, the oracle and the product)."""
+
+    def __init__(self, path):
+        lib = C.CDLL(path)
+        self.lib = lib
+        lib.cholesky_tri.argtypes = [_dp, C.c_int, _dp]
+        lib.cholesky_tri_inv.argtypes = [_dp, _dp, C.c_int, _dp]
+        lib.boxQP.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, C.c_int]
+        lib.addMulVec.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int]
+        lib.addSquareTri.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, _dp]
+        lib.addMul2Tri.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp]
+
+    @staticmethod
+    def tri(n):
+        return n * (n + 1) // 2
+
+    def cholesky(self, A, n):
+        U = np.zeros(self.tri(n))
+        ok = self.lib.cholesky_tri(np.ascontiguousarray(A), n, U)
+        return ok, U
+
+    def cholesky_inv(self, U, n):
+        inv = np.zeros(self.tri(n))
+        self.lib.cholesky_tri_inv(np.ascontiguousarray(U), inv, n, np.zeros(n))
+        return inv
+
+    def boxqp(self, H, g, lower, upper, x0):
+        n = len(g)
+        x = np.array(x0, dtype=np.float64)
+        t = self.tri(n)
+        Hfree, U, invH = np.zeros(t), np.zeros(t), np.zeros(t)
+        grad, gc, search = np.zeros(n), np.zeros(n), np.zeros(n)
+        clamp = np.zeros(n, dtype=np.int32)
+        nfree = np.zeros(1, dtype=np.int32)
+        rc = self.lib.boxQP(np.array(H, dtype=np.float64), np.ascontiguousarray(g, dtype=np.float64),
+                            np.ascontiguousarray(lower, dtype=np.float64), np.ascontiguousarray(upper, dtype=np.float64),
+                            x, Hfree, U, grad, gc, search, clamp, nfree, invH, n)
+        return dict(rc=rc, x=x, clamp=clamp, n_free=int(nfree[0]), invH=invH)
+
+    def add_mul_vec(self, base, a, b, n_r, n_c):
+        base = np.array(base, dtype=np.float64)
+        self.lib.addMulVec(base, np.ascontiguousarray(a), np.ascontiguousarray(b), n_r, n_c)
+        return base
+
+    def add_square_tri(self, base, b, a, n_r, n_c):
+        base = np.array(base, dtype=np.float64)
+        self.lib.addSquareTri(base, np.ascontiguousarray(b), np.ascontiguousarray(a), n_r, n_c, np.zeros(n_r * n_c))
+        return base
+
+    def add_mul2_tri(self, base, b, a, n_ra, n_ca, c, n_rc, n_cc):
+        base = np.array(base, dtype=np.float64)
+        self.lib.addMul2Tri(base, np.ascontiguousarray(b), np.ascontiguousarray(a), n_ra, n_ca,
+                            np.ascontiguousarray(c), n_rc, n_cc, np.zeros(n_ra * n_cc))
+        return base

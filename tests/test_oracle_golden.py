@@ -1,0 +1,125 @@
+"""The CPU restatement (oracle/) against the golden fixtures recorded from the
+reference's own sources (tests/golden/make_goldens.py).  Both are compiled with
+-ffp-contract=off and the restatement keeps the reference's operation order, so
+every comparison here is EXACT (bitwise) — that is what "pinned" means in the
+oracle's header."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle.harness import CAR_PARAMS, Driver, Kernels, lib_path
+
+
+@pytest.fixture(scope="module")
+def K(oracle_built):
+    return Kernels(lib_path("oracle", full_ddp=0))
+
+
+def tri(n):
+    return n * (n + 1) // 2
+
+
+def test_cholesky_and_inverse(K):
+    g = golden("kernels.npz")
+    for n, A, ok, U, inv in zip(g["chol_n"], g["chol_A"], g["chol_ok"], g["chol_U"], g["chol_inv"]):
+        t = tri(n)
+        ok2, U2 = K.cholesky(A[:t].copy(), int(n))
+        assert ok2 == ok
+        if ok:
+            assert np.array_equal(U2, U[:t])
+            assert np.array_equal(K.cholesky_inv(U2, int(n)), inv[:t])
+
+
+def test_boxqp_every_return_code(K):
+    g = golden("kernels.npz")
+    seen = set()
+    for i in range(len(g["qp_n"])):
+        n = int(g["qp_n"][i]); t = tri(n)
+        r = K.boxqp(g["qp_H"][i][:t], g["qp_g"][i][:n], g["qp_lo"][i][:n], g["qp_hi"][i][:n], g["qp_x0"][i][:n])
+        assert r["rc"] == g["qp_rc"][i]
+        seen.add(r["rc"])
+        assert np.array_equal(r["x"], g["qp_x"][i][:n])
+        if r["rc"] != -1 or True:
+            assert np.array_equal(r["clamp"], g["qp_clamp"][i][:n])
+            assert r["n_free"] == g["qp_nfree"][i]
+        if r["rc"] >= 1 and r["rc"] != 6:
+            nf = r["n_free"]
+            assert np.array_equal(r["invH"][:tri(nf)], g["qp_invH"][i][:tri(nf)])
+    assert seen == {-2, -1, 2, 4, 5, 6}  # rc 1 (100 iterations) is unreachable by random search
+
+
+@pytest.mark.parametrize("tag,n,m", [("car", 4, 2), ("syn", 16, 8)])
+def test_matmult_helpers(K, tag, n, m):
+    g = golden("kernels.npz")
+    p = lambda k: g["mm_%s_%s" % (tag, k)]
+    assert np.array_equal(K.add_mul_vec(p("base_u"), p("vx"), p("fu"), n, m), p("mulvec"))
+    assert np.array_equal(K.add_square_tri(p("base_uu"), p("V"), p("fu"), n, m), p("sq_uu"))
+    assert np.array_equal(K.add_square_tri(p("base_xx"), p("V"), p("fx"), n, n), p("sq_xx"))
+    assert np.array_equal(K.add_mul2_tri(p("base_xu"), p("V"), p("fx"), n, n, p("fu"), n, m), p("mul2"))
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_single_backward_pass_and_line_search(oracle_built, fd):
+    g = golden("car_single_fd%d.npz" % fd)
+    d = Driver(lib_path("oracle", full_ddp=fd), 500, CAR_PARAMS)
+    assert d.init(g["x0"], g["u0"]) == 1
+    assert d.scalars()["cost"] == float(g["init_cost"])
+    x, u = d.traj(0)
+    assert np.array_equal(x, g["x_nom"]) and np.array_equal(u, g["u_nom"])
+    assert d.calc_derivs() == 1
+    rec, fin = d.derivs()
+    assert np.array_equal(rec, g["rec"]) and np.array_equal(fin, g["fin"])
+    assert d.back_pass() == int(g["bp_rc"]) == 0
+    l, L = d.gains()
+    s = d.scalars()
+    assert np.array_equal(l, g["l"]) and np.array_equal(L, g["L"])
+    assert s["dV0"] == g["dV"][0] and s["dV1"] == g["dV"][1] and s["g_norm"] == float(g["g_norm"])
+    for a, c, ok in zip(g["alphas"], g["alpha_cost"], g["alpha_ok"]):
+        ok2, c2 = d.forward_pass(a)
+        assert ok2 == ok and c2 == c
+    assert d.line_search(0) == int(g["ls_accept"])
+    assert d.log_linesearch(0) == int(g["ls_index"])
+    s = d.scalars()
+    assert s["new_cost"] == float(g["new_cost"]) and s["dcost"] == float(g["dcost"]) and s["expected"] == float(g["expected"])
+    xc, uc = d.traj(1)
+    assert np.array_equal(xc, g["x_cand"]) and np.array_equal(uc, g["u_cand"])
+
+    # forced Cholesky failure path: back_pass reports 1 (back_pass.c:168-171)
+    d.set_derivs(g["bad_rec"], g["fin"])
+    d.set_lambda(1.0)
+    assert d.back_pass() == int(g["bad_rc"]) == 1
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_full_solves(oracle_built, fd):
+    g = golden("car_solves_fd%d.npz" % fd)
+    for b in range(0, len(g["rc"]), 3):  # every third trajectory keeps the CPU suite short
+        d = Driver(lib_path("oracle", full_ddp=fd), 500, CAR_PARAMS, dict(max_iter=int(g["max_iter"])))
+        assert d.init(g["x0"][b], g["u0"][b]) == 1
+        assert d.solve() == g["rc"][b]
+        s = d.scalars()
+        assert int(s["iterations"]) == g["iterations"][b]
+        assert s["cost"] == g["cost"][b] and s["lambda"] == g["lam"][b] and s["g_norm"] == g["g_norm"][b]
+        x, u = d.traj(0)
+        assert np.array_equal(x, g["x"][b]) and np.array_equal(u, g["u"][b])
+        t = d.trace()
+        n = int(g["tr_len"][b])
+        for k in ("lambda", "cost", "new_cost", "alpha_idx", "bp_calls"):
+            assert np.array_equal(t[k], g["tr_" + k][b][:n]), k
+        d.close()
+
+
+def test_options_follow_reference_rules(oracle_built):
+    """setOptParam: same keys, validation and messages as reference iLQG.c:91-216"""
+    d = Driver(lib_path("oracle"), 10, CAR_PARAMS)
+    assert d.set_opt("tolFun", 1e-6) is None
+    assert d.set_opt("tolFun", 0.0) == "parameter must be positive"
+    assert d.set_opt("tolFun", [1.0, 2.0]) == "parameter must be scalar"
+    assert d.set_opt("lambdaFactor", 0.5) == "parameter must be > 1"
+    assert d.set_opt("regType", 3) == "parameter must be in range [1..2]"
+    assert d.set_opt("zMin", 1.0) == "parameter must be in range [0..1)"
+    assert d.set_opt("debug_level", 7) == "parameter must be in range [0..6]"
+    assert d.set_opt("alpha", [1.0, 0.5, 0.5]) == "all alpha must be monotonically decreasing"
+    assert d.set_opt("alpha", [1.5]) == "all alpha must be in the range [1.0..0.0)"
+    assert d.set_opt("w_pen_init", 1.0) == "no such parameter"  # the stale key of testBrachi.m:13
+    assert d.set_opt("alpha", [1.0, 0.5, 0.25]) is None

@@ -1,0 +1,47 @@
+"""Where the reference build exists (this container: compiled from
+/root/reference; GPU box: the prebuilt oracle/_ref/*.so shipped with the
+snapshot), check the CPU restatement against it directly on fresh seeded
+inputs — exact equality, beyond the committed fixtures."""
+import numpy as np
+import pytest
+
+from conftest import load_package, ref_available
+from oracle.harness import CAR_PARAMS, Driver, Kernels, lib_path
+
+pytestmark = pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (no reference sources here)")
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_randomised_solves_match_reference(oracle_built, fd):
+    synth = load_package().synth
+    x0s, u0s = synth.car_batch(3, first=5000)
+    for b in range(3):
+        out = []
+        for kind in ("ref", "oracle"):
+            d = Driver(lib_path(kind, full_ddp=fd), 500, CAR_PARAMS, dict(max_iter=60))
+            assert d.init(x0s[b], u0s[b]) == 1
+            rc = d.solve()
+            out.append((rc, d.scalars(), d.traj(0), d.gains(), d.trace()))
+            d.close()
+        a, o = out
+        assert a[0] == o[0] and a[1] == o[1]
+        for i in (2, 3):
+            assert np.array_equal(a[i][0], o[i][0]) and np.array_equal(a[i][1], o[i][1])
+        for k in a[4]:
+            assert np.array_equal(a[4][k], o[4][k]), k
+
+
+def test_random_boxqp_match_reference(oracle_built):
+    Kr, Ko = Kernels(lib_path("ref")), Kernels(lib_path("oracle"))
+    rng = np.random.default_rng(7)
+    for trial in range(300):
+        n = int(rng.integers(1, 9))
+        A = rng.standard_normal((n, n))
+        M = A @ A.T + 10.0 ** rng.uniform(-6, 0) * np.eye(n)  # positive definite: rc -2 (which prints) is avoided
+        H = np.array([M[r, c] for c in range(n) for r in range(c + 1)])
+        g = rng.standard_normal(n)
+        lo = -np.abs(rng.standard_normal(n)); hi = np.abs(rng.standard_normal(n))
+        x0 = rng.standard_normal(n)
+        a, o = Kr.boxqp(H, g, lo, hi, x0), Ko.boxqp(H, g, lo, hi, x0)
+        assert a["rc"] == o["rc"] and a["n_free"] == o["n_free"]
+        assert np.array_equal(a["x"], o["x"]) and np.array_equal(a["clamp"], o["clamp"])
