@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark: batched iLQG iterations/s on CarParking (n=4, m=2, N=500), 65 536
+trajectories per GPU, fp64 (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one lock-step iLQG iteration of the whole batch: calc_derivs of the
+nominal trajectories, back_pass (with its lambda retries), line_search over all 8
+step sizes, accept/reject bookkeeping — for every trajectory.  The timed window
+is the FIRST K iterations after the initial roll-out (no CarParking trajectory
+converges before iteration 50, so all trajectories are active throughout).
+Warm-up iterations run on the same inputs and the solver is then re-initialised
+(untimed), so the timed work is always iterations 1..K.
+
+One process per GPU; trajectories are independent, so ranks share nothing but a
+single RCCL gather of the per-trajectory costs at the end of the timed window
+(weak scaling: 65 536 trajectories per GPU).  PyTorch is used only for process
+rendezvous, the RCCL collective and device synchronisation.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel from its
+HIP-event time measured inside this run; `cpu_baseline` times the CPU checker
+(the reference's own sources when oracle/_ref was shipped, else the C port) on a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_HOR = 500
+NX, NU = 4, 2
+SXX, SUU, NXU = 10, 3, 8
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+# ALGORITHMIC bytes per time step and trajectory (doubles x 8 B)
+ALG_BYTES = {
+    "k_derivs": (NX + NU + (NX + NU + SXX + SUU + NXU + NX * NX + NXU + 2 * NU)) * 8,      # 61 dbl = 488 B
+    "k_backward": ((NX + SXX + NU + SUU + NXU + NX * NX + NXU + 2 * NU + NU) + NU + NXU) * 8,  # 67 dbl = 536 B
+    "k_rollout[search]": (NX + 2 * NU + NXU) * 8,                                          # 16 dbl read, shared by all alpha
+    "k_rollout[winner]": (NX + NU) * 8,                                                     # 6 dbl written (winner only)
+}
+
+
+def dev_tensor_view(ptr, n, device):
+    """zero-copy torch view of `n` doubles of device memory owned by the solver"""
+    import torch
+
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+    return torch.as_tensor(_Arr(), device=device)
+
+
+def cpu_baseline(batch_per_gpu, iters, budget_s=12.0):
+    """CPU checker on a bounded sample of the same workload, all host cores (threads; the C code
+    runs outside the GIL).  Returns the JSON object for `cpu_baseline`."""
+    from concurrent.futures import ThreadPoolExecutor
+    import __graft_entry__ as g
+    from oracle.harness import CAR_PARAMS, Driver, lib_path
+    synth = g.load_package().synth
+    ref = lib_path("ref", full_ddp=0)
+    kind = "reference" if os.path.exists(ref) else "port"
+    path = ref if kind == "reference" else lib_path("oracle", full_ddp=0)
+    cores = os.cpu_count() or 1
+
+    def run(args):
+        x0, u0 = args
+        d = Driver(path, N_HOR, CAR_PARAMS, dict(max_iter=iters))
+        d.init(x0, u0)
+        d.solve()
+        it = int(d.scalars()["iterations"])
+        d.close()
+        return it
+
+    # calibrate on one trajectory, then size the sample to the time budget
+    x0, u0 = synth.car_batch(1)
+    t0 = time.perf_counter()
+    run((x0[0], u0[0]))
+    per_traj = max(time.perf_counter() - t0, 1e-4)
+    sample = int(max(cores, min(8192, budget_s / per_traj * cores)))
+    x0, u0 = synth.car_batch(sample)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        its = list(ex.map(run, [(x0[i], u0[i]) for i in range(sample)]))
+    dt = time.perf_counter() - t0
+    traj_iters_per_s = sum(its) / dt
+    return {
+        "value": traj_iters_per_s / batch_per_gpu,  # batched iterations/s of a 65 536-trajectory batch
+        "unit": "iterations/s (65536-trajectory batch equivalent)",
+        "cores": cores,
+        "kind": kind,
+        "sample": "%d trajectories x %d iterations (same generator, trajectories 0..%d) in %.1f s on %d threads; "
+                  "%.0f trajectory-iterations/s" % (sample, iters, sample - 1, dt, cores, traj_iters_per_s),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
+    ap.add_argument("--full-ddp", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resweep", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from ddp_generator_amd import ilqg, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B, K, W = args.batch, args.steps, args.warmup
+    x0, u0 = synth.car_batch(B, N_HOR, first=rank * B)
+    s = ilqg.BatchSolver("carparking", args.full_ddp, batch=B, n_hor=N_HOR, device=local, params=ilqg.CAR_PARAMS,
+                         opts=dict(max_iter=max(K, W) + 1, resweep=args.resweep))
+    s.init(x0, u0)
+    if W > 0:
+        s.iterate(W)
+        s.sync()
+        s.init(x0, u0)  # back to iteration 0: the timed window is always iterations 1..K
+    gathered = torch.empty(B * world if rank == 0 else 0, dtype=torch.float64, device=dev)
+    cost_view = dev_tensor_view(s.cost_device_ptr(), B, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    s.timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    s.iterate(K)
+    s.sync()
+    if world > 1:  # the single collective of the path: per-trajectory costs to rank 0 over RCCL/xGMI
+        chunks = list(gathered.chunk(world)) if rank == 0 else None
+        dist.gather(cost_view, chunks, dst=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    times = s.kernel_times()
+    active = s.active()
+    status = s.ints("status")
+    cost = s.scalar("cost")
+
+    if rank == 0:
+        per_iter = {k: v[1] / max(1, K) for k, v in times.items() if v[0]}
+        dominant = max((k for k in per_iter if k in ALG_BYTES), key=lambda k: per_iter[k])
+        n_launch, total_ms = times[dominant]
+        avg_ms = total_ms / n_launch
+        alg_bytes = ALG_BYTES[dominant] * N_HOR * B
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        iter_bytes = sum(ALG_BYTES.values()) * N_HOR * B  # 1 200 B per step and trajectory
+        out = {
+            "metric": "iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)",
+            "value": K / dt,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * dt / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "CarParking batch=%d per GPU x %d GPU, 8-alpha line search, FULL_DDP=%d, "
+                                   "first %d iterations after the initial roll-out" % (B, world, args.full_ddp, K),
+                       "batch_per_gpu": B, "n_hor": N_HOR, "n_x": NX, "n_u": NU, "full_ddp": args.full_ddp,
+                       "mapping": "one lane per trajectory (64 trajectories per wavefront)",
+                       "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_launch},
+            "iteration_roofline": {"algorithmic_bytes_per_iteration": iter_bytes,
+                                   "achieved_GBs": iter_bytes * (K / dt) / 1e9 / world * 1.0,
+                                   "frac_of_peak": iter_bytes * (K / dt) / world / 1e9 / HBM_PEAK_GBS},
+            "kernels_ms_per_iteration": per_iter,
+            "trajectories_still_active": int(active),
+            "cost_mean_after_window": float(cost.mean()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, K)
+        print(json.dumps(out))
+    s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

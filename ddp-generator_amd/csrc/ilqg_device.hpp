@@ -1,0 +1,482 @@
+// Device-side dense kernels of the iLQG backward pass for small, compile-time
+// problem sizes.  Every loop has constant bounds and every array index is a
+// compile-time constant after unrolling, so all operands live in VGPRs (a
+// runtime-indexed private array would be demoted to scratch memory).
+//
+// "Lane mapping": one lane owns one trajectory and runs this scalar code on
+// its own registers; 64 trajectories per wavefront.  The operation order of
+// the reference is kept (ascending sums, same temporaries), so results differ
+// from the CPU only through fused multiply-add contraction.
+//
+// What each routine replaces in the reference:
+//   add_mul_vec / add_square_tri / add_mul2_tri   matMult.c:3-72
+//   chol_factor / chol_inverse                    cholesky.c:6-27, 51-74
+//   box_qp                                        boxQP.c:39-238
+//   back_step                                     back_pass.c:80-251 (one time step)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ilqg {
+
+#define ILQG_DEV __device__ __forceinline__
+
+__host__ __device__ constexpr int tri(int n) { return n * (n + 1) / 2; }
+__host__ __device__ constexpr int ut(int r, int c) { return c * (c + 1) / 2 + r; }               // r <= c
+__host__ __device__ constexpr int sy(int i, int j) { return i > j ? ut(j, i) : ut(i, j); }
+
+// ---------------------------------------------------------------------------
+// matMult.c
+// ---------------------------------------------------------------------------
+// base[c] += sum_r a[r] * b[r + c*NR]
+template <int NR, int NC>
+ILQG_DEV void add_mul_vec(double *base, const double *a, const double *b) {
+#pragma unroll
+    for(int c = 0; c < NC; c++)
+#pragma unroll
+        for(int r = 0; r < NR; r++) base[c] += a[r] * b[r + c * NR];
+}
+
+// packed-upper base (NC x NC) += A' B A, B packed symmetric NR x NR, A is NR x NC
+template <int NR, int NC>
+ILQG_DEV void add_square_tri(double *base, const double *B, const double *A) {
+    double ba[NR * NC];
+#pragma unroll
+    for(int r = 0; r < NR; r++)
+#pragma unroll
+        for(int c = 0; c < NC; c++) {
+            double acc = 0.0;
+#pragma unroll
+            for(int s = 0; s < NR; s++) acc += B[sy(r, s)] * A[s + c * NR];
+            ba[r + c * NR] = acc;
+        }
+#pragma unroll
+    for(int c = 0; c < NC; c++)
+#pragma unroll
+        for(int r = 0; r <= c; r++) {
+            double acc = 0.0;
+#pragma unroll
+            for(int s = 0; s < NR; s++) acc += A[s + r * NR] * ba[s + c * NR];
+            if(r != c) {
+#pragma unroll
+                for(int s = 0; s < NR; s++) acc += A[s + c * NR] * ba[s + r * NR];
+                acc *= 0.5;
+            }
+            base[ut(r, c)] += acc;
+        }
+}
+
+// full base (NCA x NCC) += A' B C, B packed symmetric NRA x NRA, A is NRA x NCA, C is NRA x NCC
+template <int NRA, int NCA, int NCC>
+ILQG_DEV void add_mul2_tri(double *base, const double *B, const double *A, const double *C) {
+    double bc[NRA * NCC];
+#pragma unroll
+    for(int r = 0; r < NRA; r++)
+#pragma unroll
+        for(int q = 0; q < NCC; q++) {
+            double acc = 0.0;
+#pragma unroll
+            for(int s = 0; s < NRA; s++) acc += B[sy(r, s)] * C[s + q * NRA];
+            bc[r + q * NRA] = acc;
+        }
+#pragma unroll
+    for(int r = 0; r < NCA; r++)
+#pragma unroll
+        for(int q = 0; q < NCC; q++) {
+            double acc = 0.0;
+#pragma unroll
+            for(int s = 0; s < NRA; s++) acc += A[s + r * NRA] * bc[s + q * NRA];
+            base[r + q * NCA] += acc;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// cholesky.c (plain part)
+// ---------------------------------------------------------------------------
+// A = U'U on packed upper triangles.  false as soon as a pivot is <= 0.
+template <int M>
+ILQG_DEV bool chol_factor(const double *A, double *U) {
+    bool ok = true;
+#pragma unroll
+    for(int i = 0; i < M; i++)
+#pragma unroll
+        for(int j = 0; j <= i; j++) {
+            double dot = 0.0;
+#pragma unroll
+            for(int k = 0; k < j; k++) dot += U[ut(k, i)] * U[ut(k, j)];
+            const double s = A[ut(j, i)] - dot;
+            if(i == j) {
+                if(s <= 0.0) ok = false;
+                U[ut(j, i)] = sqrt(s);
+            } else {
+                U[ut(j, i)] = 1.0 / U[ut(j, j)] * s;
+            }
+        }
+    return ok;
+}
+
+// explicit packed inverse of U'U
+template <int M>
+ILQG_DEV void chol_inverse(const double *U, double *inv) {
+#pragma unroll
+    for(int l = 0; l < M; l++) {
+        double x[M];
+#pragma unroll
+        for(int k = 0; k < M; k++) x[k] = (k == l) ? 1.0 : 0.0;
+#pragma unroll
+        for(int k = l; k < M; k++) {
+#pragma unroll
+            for(int i = l; i < k; i++) x[k] -= x[i] * U[ut(i, k)];
+            x[k] /= U[ut(k, k)];
+        }
+#pragma unroll
+        for(int k = M - 1; k >= l; k--) {
+#pragma unroll
+            for(int i = k + 1; i < M; i++) x[k] -= x[i] * U[ut(k, i)];
+            x[k] /= U[ut(k, k)];
+            inv[ut(l, k)] = x[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// boxQP.c
+// ---------------------------------------------------------------------------
+template <int M>
+ILQG_DEV double qp_value(const double *H, const double *g, const double *x) {
+    double v = 0.0;
+#pragma unroll
+    for(int i = 0; i < M; i++) {
+        double hx = 0.0;
+#pragma unroll
+        for(int j = 0; j < M; j++) hx += H[sy(i, j)] * x[j];
+        v += x[i] * (g[i] + 0.5 * hx);
+    }
+    return v;
+}
+
+// Projected-Newton box QP.  Same iteration, constants and return codes as
+// boxQP.c:39-238.  One representational difference: the reference compacts
+// the free rows/columns into a smaller matrix (which needs runtime indices);
+// here the clamped rows/columns of a full-size copy are replaced by identity
+// before factorising.  The factor and inverse of that matrix are the free
+// block's factor and inverse embedded at the original indices (all extra terms
+// are exact zeros), so `invH` is returned in FULL index form: invH[sy(i,j)]
+// for free i,j equals the reference's invHfree[sy(i_free,j_free)].
+template <int M>
+ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const double *upper, double *x,
+                    int *clamp, int &n_free_out, double *invH) {
+    constexpr int T = tri(M);
+    const int max_iter = 100;
+    const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+    double grad[M], search[M], xc[M];
+    double value, oldvalue = 0.0;
+
+#pragma unroll
+    for(int i = 0; i < M; i++) {
+        if(x[i] > upper[i]) x[i] = upper[i];
+        if(x[i] < lower[i]) x[i] = lower[i];
+        clamp[i] = 0;
+    }
+#pragma unroll
+    for(int i = 0; i < T; i++) invH[i] = 0.0;
+    n_free_out = 0;
+    value = qp_value<M>(H, g, x);
+
+    for(int iter = 0; iter < max_iter; iter++) {
+        if(iter > 0 && (oldvalue - value) < min_rel_improve * fabs(oldvalue)) return 4;
+        oldvalue = value;
+
+        bool all_clamped = true, changed = false;
+        int n_free = 0;
+        double gnorm = 0.0;
+#pragma unroll
+        for(int i = 0; i < M; i++) {
+            double hx = 0.0;
+#pragma unroll
+            for(int j = 0; j < M; j++) hx += H[sy(i, j)] * x[j];
+            grad[i] = g[i] + hx;
+            const int was = clamp[i];
+            if(x[i] <= lower[i] && grad[i] > 0)
+                clamp[i] = 1;
+            else if(x[i] >= upper[i] && grad[i] < 0)
+                clamp[i] = 2;
+            else {
+                clamp[i] = 0;
+                all_clamped = false;
+                gnorm += grad[i] * grad[i];
+                n_free++;
+            }
+            if((!was) != (!clamp[i])) changed = true;
+        }
+        n_free_out = n_free;
+        if(all_clamped) return 6;
+
+        if(iter == 0 || changed) {
+            double Hm[T], U[T];
+#pragma unroll
+            for(int j = 0; j < M; j++)
+#pragma unroll
+                for(int i = 0; i <= j; i++)
+                    Hm[ut(i, j)] = (clamp[i] || clamp[j]) ? ((i == j) ? 1.0 : 0.0) : H[ut(i, j)];
+            if(!chol_factor<M>(Hm, U)) return -1;
+            chol_inverse<M>(U, invH);
+        }
+
+        if(gnorm < min_grad * min_grad) return 5;
+
+        // search(free) = -invH(free,free) * (g + H x_clamped)(free) - x(free); search(clamped) = 0
+        double gc[M];
+#pragma unroll
+        for(int i = 0; i < M; i++) {
+            double hc = 0.0;
+#pragma unroll
+            for(int j = 0; j < M; j++)
+                if(clamp[j]) hc += H[sy(i, j)] * x[j];
+            gc[i] = g[i] + hc;
+        }
+#pragma unroll
+        for(int i = 0; i < M; i++) {
+            double s = -x[i];
+#pragma unroll
+            for(int j = 0; j < M; j++)
+                if(!clamp[j]) s -= invH[sy(i, j)] * gc[j];
+            search[i] = clamp[i] ? 0.0 : s;
+        }
+
+        double sdotg = 0.0;
+#pragma unroll
+        for(int i = 0; i < M; i++) sdotg += search[i] * grad[i];
+        if(sdotg >= 0.0) return -2;
+
+        double step = 1.0, vc;
+        for(;;) {
+#pragma unroll
+            for(int i = 0; i < M; i++) {
+                xc[i] = x[i] + step * search[i];
+                if(xc[i] > upper[i]) xc[i] = upper[i];
+                if(xc[i] < lower[i]) xc[i] = lower[i];
+            }
+            vc = qp_value<M>(H, g, xc);
+            if(((vc - oldvalue) / (step * sdotg)) >= armijo) break;
+            step = step * step_dec;
+            if(step < min_step) return 2;
+        }
+#pragma unroll
+        for(int i = 0; i < M; i++) x[i] = xc[i];
+        value = vc;
+    }
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
+// one time step of back_pass.c
+// ---------------------------------------------------------------------------
+// Offsets of the packed per-step derivative record (doubles).  The order is
+// the read order of back_pass.c; optional blocks sit at the end so that the
+// device record is always a prefix of the full host record.
+template <int NX, int NU, bool FULL, bool HX>
+struct RecLayout {
+    static constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
+    static constexpr int CX = 0;
+    static constexpr int CXX = CX + NX;
+    static constexpr int CU = CXX + SXX;
+    static constexpr int CUU = CU + NU;
+    static constexpr int CXU = CUU + SUU;
+    static constexpr int FX = CXU + NXU;
+    static constexpr int FU = FX + NX * NX;
+    static constexpr int LOWER = FU + NXU;
+    static constexpr int UPPER = LOWER + NU;
+    static constexpr int BASE_END = UPPER + NU;
+    static constexpr int FXX = BASE_END;
+    static constexpr int FUU = FXX + (FULL ? NX * SXX : 0);
+    static constexpr int FXU = FUU + (FULL ? NX * SUU : 0);
+    static constexpr int FULL_END = FXU + (FULL ? NX * NXU : 0);
+    static constexpr int LSIGN = FULL_END;
+    static constexpr int USIGN = LSIGN + NU;
+    static constexpr int LHX = USIGN + NU;
+    static constexpr int UHX = LHX + NXU;
+    static constexpr int HOST_SIZE = UHX + NXU;              // what the host always exchanges
+    static constexpr int SIZE = HX ? HOST_SIZE : FULL_END;   // what the device stores per step
+};
+
+// r: derivative record of this step (registers), uk: nominal control,
+// Vx/Vxx: value function of step k+1 in, of step k out, l: warm start in /
+// feed-forward out, K: feedback gains out (NU x NX column-major).
+// Returns the box-QP code (< 1 means the sweep must be abandoned).
+template <int NX, int NU, bool FULL, bool HX>
+ILQG_DEV int back_step(const double *r, const double *uk, double *Vx, double *Vxx, double *l, double *K,
+                       const double lambda, const int regType, double &dV0, double &dV1, double &gsum) {
+    using R = RecLayout<NX, NU, FULL, HX>;
+    constexpr int SXX = R::SXX, SUU = R::SUU, NXU = R::NXU;
+    const double *cx = r + R::CX, *cxx = r + R::CXX, *cu = r + R::CU, *cuu = r + R::CUU, *cxu = r + R::CXU;
+    const double *fx = r + R::FX, *fu = r + R::FU, *lower = r + R::LOWER, *upper = r + R::UPPER;
+
+    double Qu[NU], Qx[NX], Qxu[NXU], Quu[SUU], Qxx[SXX];
+#pragma unroll
+    for(int i = 0; i < NU; i++) Qu[i] = cu[i];
+    add_mul_vec<NX, NU>(Qu, Vx, fu);
+#pragma unroll
+    for(int i = 0; i < NX; i++) Qx[i] = cx[i];
+    add_mul_vec<NX, NX>(Qx, Vx, fx);
+
+#pragma unroll
+    for(int i = 0; i < NXU; i++) Qxu[i] = cxu[i];
+    add_mul2_tri<NX, NX, NU>(Qxu, Vxx, fx, fu);
+    if(FULL) {
+        const double *fxu = r + R::FXU;
+#pragma unroll
+        for(int j = 0; j < NXU; j++) {
+            double acc = 0.0;
+#pragma unroll
+            for(int i = 0; i < NX; i++) acc += Vx[i] * fxu[j + i * NXU];
+            Qxu[j] += acc;
+        }
+    }
+#pragma unroll
+    for(int i = 0; i < SUU; i++) Quu[i] = cuu[i];
+    add_square_tri<NX, NU>(Quu, Vxx, fu);
+    if(FULL) {
+        const double *fuu = r + R::FUU;
+#pragma unroll
+        for(int j = 0; j < SUU; j++) {
+            double acc = 0.0;
+#pragma unroll
+            for(int i = 0; i < NX; i++) acc += Vx[i] * fuu[j + i * SUU];
+            Quu[j] += acc;
+        }
+    }
+#pragma unroll
+    for(int i = 0; i < SXX; i++) Qxx[i] = cxx[i];
+    add_square_tri<NX, NX>(Qxx, Vxx, fx);
+    if(FULL) {
+        const double *fxx = r + R::FXX;
+#pragma unroll
+        for(int j = 0; j < SXX; j++) {
+            double acc = 0.0;
+#pragma unroll
+            for(int i = 0; i < NX; i++) acc += Vx[i] * fxx[j + i * SXX];
+            Qxx[j] += acc;
+        }
+    }
+
+    // regularisation (back_pass.c:134-159); regType 2 keeps the reference's
+    // literal index expressions
+    double QuuF[SUU], Qxu_reg[NXU];
+#pragma unroll
+    for(int i = 0; i < SUU; i++) QuuF[i] = Quu[i];
+#pragma unroll
+    for(int i = 0; i < NXU; i++) Qxu_reg[i] = Qxu[i];
+    if(regType == 2) {
+#pragma unroll
+        for(int j = 0; j < NU; j++)
+#pragma unroll
+            for(int i = 0; i <= j; i++) {
+                double acc = 0.0;
+#pragma unroll
+                for(int q = 0; q < NU; q++) acc += fu[sy(q, i)] * fu[sy(q, j)];
+                QuuF[ut(i, j)] += acc * lambda;
+            }
+#pragma unroll
+        for(int i = 0; i < NX; i++)
+#pragma unroll
+            for(int j = 0; j < NU; j++) {
+                double acc = 0.0;
+#pragma unroll
+                for(int q = 0; q < NX; q++) acc += fx[q + i * NX] * fu[q + j * NU];
+                Qxu_reg[i + j * NX] += acc * lambda;
+            }
+    }
+    if(regType == 1) {
+#pragma unroll
+        for(int i = 0; i < NU; i++) QuuF[ut(i, i)] += lambda;
+    }
+
+    int clamp[NU], n_free;
+    double invH[SUU];
+    const int rc = box_qp<NU>(QuuF, Qu, lower, upper, l, clamp, n_free, invH);
+    if(rc < 1) return rc;
+
+    // feedback gains (back_pass.c:175-201)
+#pragma unroll
+    for(int i = 0; i < NU; i++) {
+        double row[NX];
+#pragma unroll
+        for(int q = 0; q < NX; q++) row[q] = 0.0;
+        if(clamp[i]) {
+            if(HX) {
+                const double sg = (clamp[i] == 1) ? r[R::LSIGN + i] : r[R::USIGN + i];
+#pragma unroll
+                for(int q = 0; q < NX; q++) row[q] -= sg * ((clamp[i] == 1) ? r[R::LHX + q + i * NX] : r[R::UHX + q + i * NX]);
+            }
+        } else {
+#pragma unroll
+            for(int j = 0; j < NU; j++) {
+                if(!clamp[j]) {
+#pragma unroll
+                    for(int q = 0; q < NX; q++) row[q] -= invH[sy(i, j)] * Qxu_reg[q + j * NX];
+                } else if(HX) {
+                    double w = 0.0;
+#pragma unroll
+                    for(int s = 0; s < NU; s++)
+                        if(!clamp[s]) w -= invH[sy(i, s)] * QuuF[sy(s, j)];
+                    const double sg = (clamp[j] == 1) ? r[R::LSIGN + j] : r[R::USIGN + j];
+#pragma unroll
+                    for(int q = 0; q < NX; q++)
+                        row[q] -= w * (sg * ((clamp[j] == 1) ? r[R::LHX + q + j * NX] : r[R::UHX + q + j * NX]));
+                }
+            }
+        }
+#pragma unroll
+        for(int q = 0; q < NX; q++) K[i + q * NU] = row[q];
+    }
+
+    // expected cost change (back_pass.c:205-214)
+#pragma unroll
+    for(int i = 0; i < NU; i++) dV0 += Qu[i] * l[i];
+#pragma unroll
+    for(int i = 0; i < NU; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for(int j = 0; j < NU; j++) acc += l[j] * Quu[sy(j, i)];
+        dV1 += 0.5 * l[i] * acc;
+    }
+
+    // value function with the unregularised Quu / Qxu (back_pass.c:219-241)
+#pragma unroll
+    for(int i = 0; i < NX; i++) Vx[i] = Qx[i];
+    add_mul2_tri<NU, NX, 1>(Vx, Quu, K, l);
+#pragma unroll
+    for(int i = 0; i < NX; i++)
+#pragma unroll
+        for(int j = 0; j < NU; j++) Vx[i] += K[j + i * NU] * Qu[j];
+#pragma unroll
+    for(int i = 0; i < NX; i++)
+#pragma unroll
+        for(int j = 0; j < NU; j++) Vx[i] += Qxu[i + j * NX] * l[j];
+
+#pragma unroll
+    for(int i = 0; i < SXX; i++) Vxx[i] = Qxx[i];
+    add_square_tri<NU, NX>(Vxx, Quu, K);
+#pragma unroll
+    for(int i = 0; i < NX; i++)
+#pragma unroll
+        for(int j = 0; j < NX; j++)
+#pragma unroll
+            for(int q = 0; q < NU; q++) {
+                double term = K[q + i * NU] * Qxu[j + q * NX];
+                if(i == j) term *= 2.0;
+                Vxx[sy(i, j)] += term;
+            }
+
+    // gradient-norm summand (back_pass.c:246-251)
+    double gmax = 0.0;
+#pragma unroll
+    for(int i = 0; i < NU; i++) {
+        const double gi = fabs(l[i]) / (fabs(uk[i]) + 1.0);
+        if(gi > gmax) gmax = gi;
+    }
+    gsum += gmax;
+    return rc;
+}
+
+}  // namespace ilqg

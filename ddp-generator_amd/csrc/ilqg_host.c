@@ -1,0 +1,728 @@
+/* Host side of the batched iLQG library — plain C, as in the reference.
+ *
+ * Part 1: the reference's own link-time symbols (include/iLQG.h, back_pass.h,
+ *         line_search.h, boxQP.h), operating on one tOptSet.  The hot path —
+ *         back_pass() and line_search() — runs on the GPU through the shim
+ *         (ilqg_shim.h) with a batch of one; the outer loop iLQG() stays on the
+ *         host exactly where the reference has it (iLQG.c:224-379) and keeps
+ *         calling the generated host callbacks calc_derivs()/forward_pass().
+ *         There is NO CPU implementation of the hot path in this library: with
+ *         no usable HIP device these entry points print an error and abort().
+ * Part 2: the batch interface of include/ilqg_batch.h: all trajectories and the
+ *         per-trajectory solver state live in HBM, one launch sequence per
+ *         lock-step iteration, no host round trip inside an iteration.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mex.h"
+#include "iLQG.h"
+#include "back_pass.h"
+#include "line_search.h"
+#include "boxQP.h"
+#include "matMult.h"
+#include "printMat.h"
+
+#include "ilqg_batch.h"
+#include "ilqg_shim.h"
+
+#define REC_HOST_SIZE_BASE (N_X + sizeofQxx + N_U + sizeofQuu + sizeofQxu + N_X * N_X + N_X * N_U + 2 * N_U)
+#if FULL_DDP
+#define REC_HOST_SIZE (REC_HOST_SIZE_BASE + N_X * sizeofQxx + N_X * sizeofQuu + N_X * sizeofQxu + 2 * N_U + 2 * N_X * N_U)
+#else
+#define REC_HOST_SIZE (REC_HOST_SIZE_BASE + 2 * N_U + 2 * N_X * N_U)
+#endif
+#define FIN_SIZE (N_X + sizeofQxx)
+
+struct ilqg_batch {
+    ilqg_dev_t *dev;
+    int device, B, N;
+    tOptSet opt;                     /* option holder, filled through setOptParam() */
+    double alpha_store[ILQG_MAX_ALPHA];
+    int resweep;
+    double **p;                      /* owned copies of the problem parameters */
+    int params_pushed;
+    char err[512];
+};
+
+static char g_create_err[512];
+
+static void fatal_no_device(const char *what, const char *msg) {
+    fprintf(stderr,
+            "ilqg: %s needs the HIP backend, which is unavailable: %s\n"
+            "ilqg: this library has no CPU fallback for the hot path.\n",
+            what, msg ? msg : "");
+    abort();
+}
+
+/* =========================================================================
+ * options                                      reference iLQG.c:36-216
+ * ========================================================================= */
+static double ilqg_default_alpha[8] = {1.0, 0.3727594, 0.1389495, 0.0517947,
+                                       0.0193070, 0.0071969, 0.0026827, 0.0010000};
+
+void standard_parameters(tOptSet *o) {
+    o->alpha = ilqg_default_alpha;
+    o->n_alpha = 8;
+    o->tolFun = 1e-7;
+    o->tolConstraint = 1e-7;
+    o->tolGrad = 1e-5;
+    o->max_iter = 20;
+    o->lambdaInit = 1;
+    o->dlambdaInit = 1;
+    o->lambdaFactor = 1.6;
+    o->lambdaMax = 1e10;
+    o->lambdaMin = 1e-6;
+    o->regType = 1;
+    o->zMin = 0.0;
+    o->debug_level = 2;
+    o->w_pen_init_l = 1.0;
+    o->w_pen_init_f = 1.0;
+    o->w_pen_max_l = INF;
+    o->w_pen_max_f = INF;
+    o->w_pen_fact1 = 4.0;
+    o->w_pen_fact2 = 1.0;
+}
+
+static char err_scalar[] = "parameter must be scalar";
+static char err_alpha_range[] = "all alpha must be in the range [1.0..0.0)";
+static char err_alpha_mono[] = "all alpha must be monotonically decreasing";
+static char err_pos[] = "parameter must be positive";
+static char err_gt_one[] = "parameter must be > 1";
+static char err_one_two[] = "parameter must be in range [1..2]";
+static char err_zero_one[] = "parameter must be in range [0..1)";
+static char err_debug[] = "parameter must be in range [0..6]";
+static char err_unknown[] = "no such parameter";
+
+/* one row per scalar option: where it lives, its type, the lowest/highest
+ * admissible value and the message of the reference for a violation */
+enum { CHK_GT0, CHK_GE0, CHK_GE1, CHK_1_2, CHK_0_1, CHK_0_6 };
+typedef struct {
+    const char *name;
+    size_t offset;
+    int is_int;
+    int check;
+} opt_row_t;
+
+#define ROW_D(field, chk) {#field, offsetof(tOptSet, field), 0, chk}
+#define ROW_I(field, chk) {#field, offsetof(tOptSet, field), 1, chk}
+static const opt_row_t opt_rows[] = {
+    ROW_D(tolFun, CHK_GT0),       ROW_D(tolConstraint, CHK_GT0), ROW_D(tolGrad, CHK_GT0),
+    ROW_I(max_iter, CHK_GE0),     ROW_D(lambdaInit, CHK_GE0),    ROW_D(dlambdaInit, CHK_GE0),
+    ROW_D(lambdaFactor, CHK_GE1), ROW_D(lambdaMax, CHK_GE0),     ROW_D(lambdaMin, CHK_GE0),
+    ROW_I(regType, CHK_1_2),      ROW_D(zMin, CHK_0_1),          ROW_I(debug_level, CHK_0_6),
+    ROW_D(w_pen_init_l, CHK_GE0), ROW_D(w_pen_init_f, CHK_GE0),  ROW_D(w_pen_max_l, CHK_GE0),
+    ROW_D(w_pen_max_f, CHK_GE0),  ROW_D(w_pen_fact1, CHK_GE1),   ROW_D(w_pen_fact2, CHK_GE1),
+};
+
+char *setOptParam(tOptSet *o, const char *name, const double *value, const int n) {
+    size_t r;
+    int i;
+    if(strcmp(name, "alpha") == 0) {
+        for(i = 0; i < n; i++) {
+            if(value[i] < 0.0 || value[i] > 1.0) return err_alpha_range;
+            if(i > 0 && value[i] >= value[i - 1]) return err_alpha_mono;
+        }
+        o->alpha = value; /* borrowed, as in the reference (iLQG.c:101) */
+        o->n_alpha = n;
+        return NULL;
+    }
+    for(r = 0; r < sizeof(opt_rows) / sizeof(opt_rows[0]); r++) {
+        const opt_row_t *row = &opt_rows[r];
+        double v;
+        if(strcmp(name, row->name) != 0) continue;
+        if(n != 1) return err_scalar;
+        v = value[0];
+        switch(row->check) {
+            case CHK_GT0: if(v <= 0.0) return err_pos; break;
+            case CHK_GE0: if(v < 0.0) return err_pos; break;
+            case CHK_GE1: if(v < 1.0) return err_gt_one; break;
+            case CHK_1_2: if(v < 1.0 || v > 2.0) return err_one_two; break;
+            case CHK_0_1: if(v < 0.0 || v >= 1.0) return err_zero_one; break;
+            case CHK_0_6: if(v < 0.0 || v > 6.0) return err_debug; break;
+        }
+        if(row->is_int)
+            *(int *)((char *)o + row->offset) = (int)v;
+        else
+            *(double *)((char *)o + row->offset) = v;
+        return NULL;
+    }
+    return err_unknown;
+}
+
+void makeCandidateNominal(tOptSet *o, int idx) {
+    traj_t *swap = o->candidates[idx];
+    o->candidates[idx] = o->nominal;
+    o->nominal = swap;
+}
+
+void printVec(const double *A, const int n, const char *nm) {
+    int i;
+    PRNT("%s= [", nm);
+    for(i = 0; i < n; i++) PRNT(i ? ", %g" : "%g", A[i]);
+    PRNT("]\n");
+}
+
+void printTri(const double *A, const int n, const char *nm) {
+    int r, c;
+    PRNT("%s= [\n", nm);
+    for(r = 0; r < n; r++) {
+        for(c = 0; c < n; c++) PRNT(c ? ", %g" : "  %g", A[SYMTRI_MAT_IDX(r, c)]);
+        PRNT("\n");
+    }
+    PRNT("]\n");
+}
+
+void printMat(const double *A, const int n, const int m, const char *nm) {
+    int r, c;
+    PRNT("%s= [\n", nm);
+    for(r = 0; r < n; r++) {
+        for(c = 0; c < m; c++) PRNT(c ? ", %g" : "  %g", A[r + n * c]);
+        PRNT("\n");
+    }
+    PRNT("]\n");
+}
+
+void printParams(double **p, int k) {
+    int i;
+    for(i = 0; i < n_params; i++) {
+        if(paramdesc[i]->size == -1)
+            PRNT("%s[k]= %g\n", paramdesc[i]->name, p[i][k]);
+        else if(paramdesc[i]->size == 1)
+            PRNT("%s= %g\n", paramdesc[i]->name, p[i][0]);
+        else
+            printVec(p[i], paramdesc[i]->size, paramdesc[i]->name);
+    }
+}
+
+/* =========================================================================
+ * batch interface
+ * ========================================================================= */
+static int fail(ilqg_batch_t *c, const char *what) {
+    snprintf(c->err, sizeof(c->err), "%s: %s", what, ilqg_dev_error());
+    return 1;
+}
+
+static int fail_msg(ilqg_batch_t *c, const char *msg) {
+    snprintf(c->err, sizeof(c->err), "%s", msg);
+    return 1;
+}
+
+void ilqg_problem_dims(int *out) {
+    ilqg_dev_dims(out);
+    out[6] = n_params;
+}
+
+const char *ilqg_problem_param_name(int i) { return (i >= 0 && i < n_params) ? paramdesc[i]->name : NULL; }
+int ilqg_problem_param_size(int i) { return (i >= 0 && i < n_params) ? paramdesc[i]->size : 0; }
+int ilqg_device_count(void) { return ilqg_dev_count(); }
+
+const char *ilqg_batch_error(const ilqg_batch_t *c) { return c ? c->err : g_create_err; }
+
+static int param_len(const ilqg_batch_t *c, int i) { return paramdesc[i]->size == -1 ? c->N + 1 : paramdesc[i]->size; }
+
+ilqg_batch_t *ilqg_batch_create(int device, int batch, int n_hor) {
+    int i;
+    ilqg_batch_t *c = (ilqg_batch_t *)calloc(1, sizeof(*c));
+    if(!c) return NULL;
+    c->device = device;
+    c->B = batch;
+    c->N = n_hor;
+    c->resweep = 1;
+    standard_parameters(&c->opt);
+    if(ilqg_dev_create(&c->dev, device, batch, n_hor)) {
+        snprintf(g_create_err, sizeof(g_create_err), "ilqg_batch_create: %s", ilqg_dev_error());
+        free(c);
+        return NULL;
+    }
+    c->p = (double **)calloc(n_params > 0 ? n_params : 1, sizeof(double *));
+    for(i = 0; i < n_params; i++) c->p[i] = (double *)calloc(param_len(c, i), sizeof(double));
+    return c;
+}
+
+void ilqg_batch_destroy(ilqg_batch_t *c) {
+    int i;
+    if(!c) return;
+    ilqg_dev_destroy(c->dev);
+    for(i = 0; i < n_params; i++) free(c->p[i]);
+    free(c->p);
+    free(c);
+}
+
+int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value, int n) {
+    char *e;
+    if(strcmp(name, "resweep") == 0) {
+        if(n != 1) return fail_msg(c, err_scalar);
+        c->resweep = value[0] != 0.0;
+        return 0;
+    }
+    if(strcmp(name, "alpha") == 0) {
+        if(n > ILQG_MAX_ALPHA) return fail_msg(c, "at most 16 alpha values");
+        memcpy(c->alpha_store, value, sizeof(double) * n);
+        value = c->alpha_store;
+    }
+    e = setOptParam(&c->opt, name, value, n);
+    if(e) {
+        snprintf(c->err, sizeof(c->err), "%s", e);
+        return 1;
+    }
+    return 0;
+}
+
+int ilqg_batch_set_param(ilqg_batch_t *c, const char *name, const double *value, int n) {
+    int i;
+    for(i = 0; i < n_params; i++) {
+        if(strcmp(paramdesc[i]->name, name) != 0) continue;
+        if(param_len(c, i) != n) {
+            snprintf(c->err, sizeof(c->err), "Parameter name '%s' must be a vector length %d.", name, param_len(c, i));
+            return 1;
+        }
+        memcpy(c->p[i], value, sizeof(double) * n);
+        c->params_pushed = 0;
+        return 0;
+    }
+    snprintf(c->err, sizeof(c->err), "Parameter name '%s' is not a parameter of this problem.", name);
+    return 1;
+}
+
+/* options and parameters are pushed lazily before any stage */
+static int push_config(ilqg_batch_t *c) {
+    ilqg_dev_opts_t d;
+    int i;
+    const tOptSet *o = &c->opt;
+    memset(&d, 0, sizeof(d));
+    if(o->n_alpha < 1 || o->n_alpha > ILQG_MAX_ALPHA) return fail_msg(c, "n_alpha must be in 1..16");
+    d.n_alpha = o->n_alpha;
+    for(i = 0; i < o->n_alpha; i++) d.alpha[i] = o->alpha[i];
+    d.tolFun = o->tolFun; d.tolGrad = o->tolGrad; d.tolConstraint = o->tolConstraint;
+    d.lambdaInit = o->lambdaInit; d.dlambdaInit = o->dlambdaInit; d.lambdaFactor = o->lambdaFactor;
+    d.lambdaMax = o->lambdaMax; d.lambdaMin = o->lambdaMin;
+    d.zMin = o->zMin; d.regType = o->regType; d.max_iter = o->max_iter;
+    d.w_pen_init_l = o->w_pen_init_l; d.w_pen_init_f = o->w_pen_init_f;
+    d.w_pen_max_l = o->w_pen_max_l; d.w_pen_max_f = o->w_pen_max_f;
+    d.w_pen_fact1 = o->w_pen_fact1; d.w_pen_fact2 = o->w_pen_fact2;
+    d.resweep = c->resweep;
+    if(ilqg_dev_set_opts(c->dev, &d)) return fail(c, "options");
+    if(!c->params_pushed) {
+        int sizes[64];
+        if(n_params > 64) return fail_msg(c, "more than 64 problem parameters");
+        for(i = 0; i < n_params; i++) sizes[i] = paramdesc[i]->size;
+        if(ilqg_dev_set_params(c->dev, n_params, sizes, (const double *const *)c->p)) return fail(c, "parameters");
+        c->params_pushed = 1;
+    }
+    return 0;
+}
+
+int ilqg_batch_set_x0(ilqg_batch_t *c, const double *x0) {
+    return ilqg_dev_write_steps(c->dev, ILQG_F_X, x0, 1) ? fail(c, "set_x0") : 0;
+}
+
+int ilqg_batch_set_u(ilqg_batch_t *c, const double *u) {
+    return ilqg_dev_write(c->dev, ILQG_F_U, u) ? fail(c, "set_u") : 0;
+}
+
+int ilqg_batch_init(ilqg_batch_t *c) {
+    if(push_config(c)) return 1;
+    if(ilqg_dev_rollout_init(c->dev)) return fail(c, "initial roll-out");
+    if(ilqg_dev_reset(c->dev)) return fail(c, "reset");
+    return 0;
+}
+
+int ilqg_batch_iterate(ilqg_batch_t *c, int n) {
+    if(push_config(c)) return 1;
+    return ilqg_dev_iterate(c->dev, n) ? fail(c, "iterate") : 0;
+}
+
+int ilqg_batch_solve(ilqg_batch_t *c) {
+    int it, active = 1;
+    if(push_config(c)) return 1;
+    /* poll the active count every few iterations: one small D2H copy */
+    for(it = 0; it < c->opt.max_iter && active; it += 4) {
+        int n = c->opt.max_iter - it < 4 ? c->opt.max_iter - it : 4;
+        if(ilqg_dev_iterate(c->dev, n)) return fail(c, "iterate");
+        if(ilqg_dev_count_active(c->dev, &active)) return fail(c, "active count");
+    }
+    return 0;
+}
+
+int ilqg_batch_sync(ilqg_batch_t *c) { return ilqg_dev_sync(c->dev) ? fail(c, "sync") : 0; }
+int ilqg_batch_active(ilqg_batch_t *c, int *n) { return ilqg_dev_count_active(c->dev, n) ? fail(c, "active count") : 0; }
+
+int ilqg_batch_calc_derivs(ilqg_batch_t *c) {
+    if(push_config(c)) return 1;
+    return ilqg_dev_derivs(c->dev) ? fail(c, "calc_derivs") : 0;
+}
+
+int ilqg_batch_back_pass(ilqg_batch_t *c, int single_sweep) {
+    if(push_config(c)) return 1;
+    return ilqg_dev_backward(c->dev, single_sweep) ? fail(c, "back_pass") : 0;
+}
+
+int ilqg_batch_line_search(ilqg_batch_t *c) {
+    if(push_config(c)) return 1;
+    if(ilqg_dev_search(c->dev)) return fail(c, "line_search");
+    return ilqg_dev_winner(c->dev) ? fail(c, "line_search (winner)") : 0;
+}
+
+int ilqg_batch_update(ilqg_batch_t *c) {
+    if(push_config(c)) return 1;
+    return ilqg_dev_update(c->dev) ? fail(c, "update") : 0;
+}
+
+int ilqg_batch_get_x(ilqg_batch_t *c, double *x) { return ilqg_dev_read(c->dev, ILQG_F_X, x) ? fail(c, "get_x") : 0; }
+int ilqg_batch_get_u(ilqg_batch_t *c, double *u) { return ilqg_dev_read(c->dev, ILQG_F_U, u) ? fail(c, "get_u") : 0; }
+
+int ilqg_batch_get_gains(ilqg_batch_t *c, double *l, double *L) {
+    if(ilqg_dev_read(c->dev, ILQG_F_LG, l)) return fail(c, "get_gains");
+    return ilqg_dev_read(c->dev, ILQG_F_KG, L) ? fail(c, "get_gains") : 0;
+}
+
+int ilqg_batch_set_gains(ilqg_batch_t *c, const double *l, const double *L) {
+    if(ilqg_dev_write(c->dev, ILQG_F_LG, l)) return fail(c, "set_gains");
+    return ilqg_dev_write(c->dev, ILQG_F_KG, L) ? fail(c, "set_gains") : 0;
+}
+
+int ilqg_batch_get_derivs(ilqg_batch_t *c, double *rec, double *fin) {
+    if(ilqg_dev_read(c->dev, ILQG_F_DER, rec)) return fail(c, "get_derivs");
+    return ilqg_dev_read(c->dev, ILQG_F_FIN, fin) ? fail(c, "get_derivs") : 0;
+}
+
+int ilqg_batch_set_derivs(ilqg_batch_t *c, const double *rec, const double *fin) {
+    if(ilqg_dev_write(c->dev, ILQG_F_DER, rec)) return fail(c, "set_derivs");
+    return ilqg_dev_write(c->dev, ILQG_F_FIN, fin) ? fail(c, "set_derivs") : 0;
+}
+
+static const struct { const char *name; int field; } scalar_names[] = {
+    {"cost", ILQG_F_COST},         {"new_cost", ILQG_F_NEW_COST}, {"dcost", ILQG_F_DCOST},
+    {"expected", ILQG_F_EXPECTED}, {"lambda", ILQG_F_LAMBDA},     {"dlambda", ILQG_F_DLAMBDA},
+    {"g_norm", ILQG_F_GNORM},      {"dV0", ILQG_F_DV0},           {"dV1", ILQG_F_DV1},
+    {"alpha_cost", ILQG_F_ALPHA_COST},
+};
+static const struct { const char *name; int field; } int_names[] = {
+    {"status", ILQG_I_STATUS},     {"iterations", ILQG_I_ITER},   {"alpha_idx", ILQG_I_ALPHA_IDX},
+    {"accepted", ILQG_I_ACCEPTED}, {"bp_calls", ILQG_I_BP_CALLS}, {"bp_rc", ILQG_I_BP_RC},
+    {"need_derivs", ILQG_I_NEED_DERIVS}, {"alpha_ok", ILQG_I_ALPHA_OK},
+};
+
+static int find_scalar(const char *name) {
+    size_t i;
+    for(i = 0; i < sizeof(scalar_names) / sizeof(scalar_names[0]); i++)
+        if(strcmp(scalar_names[i].name, name) == 0) return scalar_names[i].field;
+    return -1;
+}
+
+static int find_int(const char *name) {
+    size_t i;
+    for(i = 0; i < sizeof(int_names) / sizeof(int_names[0]); i++)
+        if(strcmp(int_names[i].name, name) == 0) return int_names[i].field;
+    return -1;
+}
+
+int ilqg_batch_get_scalar(ilqg_batch_t *c, const char *name, double *out) {
+    int f = find_scalar(name);
+    if(f < 0) return fail_msg(c, "no such scalar field");
+    return ilqg_dev_read(c->dev, f, out) ? fail(c, name) : 0;
+}
+
+int ilqg_batch_set_scalar(ilqg_batch_t *c, const char *name, const double *in) {
+    int f = find_scalar(name);
+    if(f < 0) return fail_msg(c, "no such scalar field");
+    return ilqg_dev_write(c->dev, f, in) ? fail(c, name) : 0;
+}
+
+int ilqg_batch_get_int(ilqg_batch_t *c, const char *name, int *out) {
+    int f = find_int(name);
+    if(f < 0) return fail_msg(c, "no such int field");
+    return ilqg_dev_read_int(c->dev, f, out) ? fail(c, name) : 0;
+}
+
+int ilqg_batch_set_int(ilqg_batch_t *c, const char *name, const int *in) {
+    int f = find_int(name);
+    if(f < 0) return fail_msg(c, "no such int field");
+    return ilqg_dev_write_int(c->dev, f, in) ? fail(c, name) : 0;
+}
+
+void *ilqg_batch_cost_device_ptr(ilqg_batch_t *c) { return ilqg_dev_field_ptr(c->dev, ILQG_F_COST); }
+void *ilqg_batch_stream(ilqg_batch_t *c) { return ilqg_dev_stream(c->dev); }
+
+int ilqg_batch_timing(ilqg_batch_t *c, int enable) { return ilqg_dev_timing(c->dev, enable) ? fail(c, "timing") : 0; }
+int ilqg_batch_kernel_count(void) { return ILQG_K_COUNT; }
+const char *ilqg_batch_kernel_name(int k) { return ilqg_dev_kernel_name(k); }
+int ilqg_batch_get_timing(ilqg_batch_t *c, int kernel, int *launches, double *total_ms) {
+    return ilqg_dev_get_timing(c->dev, kernel, launches, total_ms) ? fail(c, "get_timing") : 0;
+}
+
+int ilqg_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                     const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
+    return ilqg_dev_boxqp_batch(device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);
+}
+
+/* =========================================================================
+ * drop-in single-trajectory entry points (batch of one on the device)
+ * ========================================================================= */
+static int env_device(void) {
+    const char *e = getenv("ILQG_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+static ilqg_batch_t *backend_of(tOptSet *o, const char *who) {
+    ilqg_batch_t *c = (ilqg_batch_t *)o->backend;
+    int i;
+    if(c && c->N != o->n_hor) {
+        ilqg_batch_destroy(c);
+        c = NULL;
+    }
+    if(!c) {
+        c = ilqg_batch_create(env_device(), 1, o->n_hor);
+        if(!c) fatal_no_device(who, ilqg_batch_error(NULL));
+        o->backend = c;
+    }
+    /* mirror the caller's options and (borrowed) parameters */
+    c->opt.alpha = o->alpha;
+    c->opt.n_alpha = o->n_alpha;
+    c->opt.tolFun = o->tolFun; c->opt.tolGrad = o->tolGrad; c->opt.tolConstraint = o->tolConstraint;
+    c->opt.lambdaInit = o->lambdaInit; c->opt.dlambdaInit = o->dlambdaInit; c->opt.lambdaFactor = o->lambdaFactor;
+    c->opt.lambdaMax = o->lambdaMax; c->opt.lambdaMin = o->lambdaMin;
+    c->opt.zMin = o->zMin; c->opt.regType = o->regType; c->opt.max_iter = o->max_iter;
+    c->opt.w_pen_init_l = o->w_pen_l; c->opt.w_pen_init_f = o->w_pen_f; /* current penalty weights */
+    c->opt.w_pen_max_l = o->w_pen_max_l; c->opt.w_pen_max_f = o->w_pen_max_f;
+    c->opt.w_pen_fact1 = o->w_pen_fact1; c->opt.w_pen_fact2 = o->w_pen_fact2;
+    for(i = 0; i < n_params; i++) {
+        if(memcmp(c->p[i], o->p[i], sizeof(double) * param_len(c, i)) != 0) {
+            memcpy(c->p[i], o->p[i], sizeof(double) * param_len(c, i));
+            c->params_pushed = 0;
+        }
+    }
+    if(push_config(c)) fatal_no_device(who, c->err);
+    return c;
+}
+
+void ilqg_release(tOptSet *o) {
+    if(o && o->backend) {
+        ilqg_batch_destroy((ilqg_batch_t *)o->backend);
+        o->backend = NULL;
+    }
+}
+
+#define DEV_OK(call, who)                                   \
+    do {                                                    \
+        if(call) fatal_no_device(who, ilqg_dev_error());    \
+    } while(0)
+
+static void pack_xu(const traj_t *tr, int N, double *x, double *u) {
+    int k;
+    for(k = 0; k < N; k++) {
+        memcpy(x + k * N_X, tr->t[k].x, sizeof(double) * N_X);
+        memcpy(u + k * N_U, tr->t[k].u, sizeof(double) * N_U);
+    }
+    memcpy(x + N * N_X, tr->f.x, sizeof(double) * N_X);
+}
+
+/* Backward Riccati sweep of the nominal trajectory on the GPU.
+ * Same contract as reference back_pass.c:38-257: reads the derivative fields
+ * calc_derivs() left in o->nominal, writes t[k].l, t[k].L, o->dV, o->g_norm;
+ * returns 0, or 1 when the box QP failed at some step. */
+int back_pass(tOptSet *o) {
+    ilqg_batch_t *c = backend_of(o, "back_pass()");
+    const int N = o->n_hor;
+    double *rec = (double *)malloc(sizeof(double) * ((size_t)N * REC_HOST_SIZE + FIN_SIZE));
+    double *fin = rec + (size_t)N * REC_HOST_SIZE;
+    double *x = (double *)malloc(sizeof(double) * ((size_t)(N + 1) * N_X + (size_t)N * N_U));
+    double *u = x + (size_t)(N + 1) * N_X;
+    double *l = (double *)malloc(sizeof(double) * (size_t)N * (N_U + N_U * N_X));
+    double *L = l + (size_t)N * N_U;
+    double *r = rec, v;
+    int k, rc, zero = 0;
+
+    for(k = 0; k < N; k++) {
+        const trajEl_t *t = &o->nominal->t[k];
+#define PUT(field, cnt) do { memcpy(r, (field), sizeof(double) * (cnt)); r += (cnt); } while(0)
+        PUT(t->cx, N_X); PUT(t->cxx, sizeofQxx); PUT(t->cu, N_U); PUT(t->cuu, sizeofQuu);
+        PUT(t->cxu, sizeofQxu); PUT(t->fx, N_X * N_X); PUT(t->fu, N_X * N_U);
+        PUT(t->lower, N_U); PUT(t->upper, N_U);
+#if FULL_DDP
+        PUT(t->fxx, N_X * sizeofQxx); PUT(t->fuu, N_X * sizeofQuu); PUT(t->fxu, N_X * sizeofQxu);
+#endif
+        PUT(t->lower_sign, N_U); PUT(t->upper_sign, N_U);
+        PUT(t->lower_hx, N_X * N_U); PUT(t->upper_hx, N_X * N_U);
+    }
+    r = fin;
+    PUT(o->nominal->f.cx, N_X); PUT(o->nominal->f.cxx, sizeofQxx);
+#undef PUT
+    pack_xu(o->nominal, N, x, u);
+
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_DER, rec), "back_pass()");
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_FIN, fin), "back_pass()");
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_U, u), "back_pass()");
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_LAMBDA, &o->lambda), "back_pass()");
+    DEV_OK(ilqg_dev_write_int(c->dev, ILQG_I_STATUS, &zero), "back_pass()");
+    DEV_OK(ilqg_dev_backward(c->dev, 1), "back_pass()");
+    DEV_OK(ilqg_dev_read_int(c->dev, ILQG_I_BP_RC, &rc), "back_pass()");
+    DEV_OK(ilqg_dev_read(c->dev, ILQG_F_LG, l), "back_pass()");
+    DEV_OK(ilqg_dev_read(c->dev, ILQG_F_KG, L), "back_pass()");
+    DEV_OK(ilqg_dev_read(c->dev, ILQG_F_DV0, &o->dV[0]), "back_pass()");
+    DEV_OK(ilqg_dev_read(c->dev, ILQG_F_DV1, &o->dV[1]), "back_pass()");
+    if(!rc) {
+        DEV_OK(ilqg_dev_read(c->dev, ILQG_F_GNORM, &v), "back_pass()");
+        o->g_norm = v;
+    }
+    for(k = 0; k < N; k++) {
+        memcpy(o->nominal->t[k].l, l + k * N_U, sizeof(double) * N_U);
+        memcpy(o->nominal->t[k].L, L + k * N_U * N_X, sizeof(double) * N_U * N_X);
+    }
+    free(rec); free(x); free(l);
+    return rc;
+}
+
+/* Line search on the GPU: all step sizes of o->alpha are rolled out in
+ * parallel, the first acceptable one (lowest index, reference
+ * line_search.c:37-60) is re-rolled and stored.  Same contract as reference
+ * line_search.c:33-78: candidate left in o->candidates[0], o->new_cost /
+ * dcost / expected and the optional logs written; returns 1 if accepted. */
+int line_search(tOptSet *o, int iter) {
+    ilqg_batch_t *c = backend_of(o, "line_search()");
+    const int N = o->n_hor;
+    double *x = (double *)malloc(sizeof(double) * ((size_t)(N + 1) * N_X + (size_t)N * N_U));
+    double *u = x + (size_t)(N + 1) * N_X;
+    double *l = (double *)malloc(sizeof(double) * (size_t)N * (N_U + N_U * N_X));
+    double *L = l + (size_t)N * N_U;
+    int k, accepted, idx, zero = 0;
+    double cnew, dcost, expected, z, tmp;
+
+    pack_xu(o->nominal, N, x, u);
+    for(k = 0; k < N; k++) {
+        memcpy(l + k * N_U, o->nominal->t[k].l, sizeof(double) * N_U);
+        memcpy(L + k * N_U * N_X, o->nominal->t[k].L, sizeof(double) * N_U * N_X);
+    }
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_X, x), "line_search()");
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_U, u), "line_search()");
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_LG, l), "line_search()");
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_KG, L), "line_search()");
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_COST, &o->cost), "line_search()");
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_DV0, &o->dV[0]), "line_search()");
+    DEV_OK(ilqg_dev_write(c->dev, ILQG_F_DV1, &o->dV[1]), "line_search()");
+    DEV_OK(ilqg_dev_write_int(c->dev, ILQG_I_STATUS, &zero), "line_search()");
+    DEV_OK(ilqg_dev_search(c->dev), "line_search()");
+    DEV_OK(ilqg_dev_winner(c->dev), "line_search()");
+    DEV_OK(ilqg_dev_read_int(c->dev, ILQG_I_ACCEPTED, &accepted), "line_search()");
+    DEV_OK(ilqg_dev_read_int(c->dev, ILQG_I_ALPHA_IDX, &idx), "line_search()");
+    DEV_OK(ilqg_dev_read(c->dev, ILQG_F_NEW_COST, &cnew), "line_search()");
+    DEV_OK(ilqg_dev_read(c->dev, ILQG_F_DCOST, &dcost), "line_search()");
+    DEV_OK(ilqg_dev_read(c->dev, ILQG_F_EXPECTED, &expected), "line_search()");
+    if(accepted) {
+        traj_t *cand = o->candidates[0];
+        DEV_OK(ilqg_dev_read(c->dev, ILQG_F_X, x), "line_search()");
+        DEV_OK(ilqg_dev_read(c->dev, ILQG_F_U, u), "line_search()");
+        for(k = 0; k < N; k++) {
+            memcpy(cand->t[k].x, x + k * N_X, sizeof(double) * N_X);
+            memcpy(cand->t[k].u, u + k * N_U, sizeof(double) * N_U);
+        }
+        memcpy(cand->f.x, x + N * N_X, sizeof(double) * N_X);
+        /* let the generated code refresh the members it caches per step (auxiliaries, c)
+         * from the stored x,u: its cost-only mode touches nothing else (iLQG_func.tem:160-176) */
+        forward_pass(cand, o, 0.0, &tmp, 1);
+    }
+    z = (expected > 0) ? dcost / expected : 0;
+    if(o->log_linesearch != NULL) o->log_linesearch[iter] = idx;
+    if(o->log_z != NULL) o->log_z[iter] = z;
+    if(o->log_cost != NULL) o->log_cost[iter] = cnew;
+    o->new_cost = cnew;
+    o->dcost = dcost;
+    o->expected = expected;
+    free(x); free(l);
+    return accepted;
+}
+
+/* reference boxQP.c:39-238, executed by the device routine the backward kernel uses */
+int boxQP(double *H, const double *g, const double *lower, const double *upper, double *x, double *Hfree,
+          double *L, double *grad, double *grad_clamped, double *search, int *is_clamped, int *n_free_,
+          double *invHfree, const int n) {
+    int rc = 0, i, j, fi, fj;
+    double inv_full[36];
+    (void)Hfree; (void)L; (void)grad; (void)grad_clamped; (void)search;
+    if(n != 2 && n != 8 && n != N_U) {
+        fprintf(stderr, "ilqg: boxQP on the device supports n in {2, 8, N_U}, got %d\n", n);
+        abort();
+    }
+    if(ilqg_dev_boxqp_batch(env_device(), n, 1, H, g, lower, upper, x, is_clamped, n_free_, inv_full, &rc))
+        fatal_no_device("boxQP()", ilqg_dev_error());
+    /* compact the full-index inverse to the reference's free-block numbering */
+    for(j = 0, fj = 0; j < n; j++) {
+        if(is_clamped[j]) continue;
+        for(i = 0, fi = 0; i <= j; i++) {
+            if(is_clamped[i]) continue;
+            invHfree[UTRI_MAT_IDX(fi, fj)] = inv_full[UTRI_MAT_IDX(i, j)];
+            fi++;
+        }
+        fj++;
+    }
+    return rc;
+}
+
+static void lambda_increase(tOptSet *o, double *dlambda) {
+    *dlambda = max(*dlambda * o->lambdaFactor, o->lambdaFactor);
+    o->lambda = max(o->lambda * *dlambda, o->lambdaMin);
+}
+
+static void lambda_decrease(tOptSet *o, double *dlambda) {
+    *dlambda = min(*dlambda / o->lambdaFactor, 1.0 / o->lambdaFactor);
+    o->lambda = o->lambda * *dlambda * (o->lambda > o->lambdaMin);
+}
+
+/* Outer iteration for ONE trajectory, where the reference has it: on the host
+ * (iLQG.c:224-379), with the two hot stages on the GPU.  `done` starts at 0, so
+ * a calc_derivs failure in the first iteration returns 0 instead of reading an
+ * uninitialised flag. */
+int iLQG(tOptSet *o) {
+    int iter, done = 0, stepped, fresh = 1;
+    double dlambda = o->dlambdaInit;
+
+    o->lambda = o->lambdaInit;
+    o->w_pen_l = o->w_pen_init_l;
+    o->w_pen_f = o->w_pen_init_f;
+    update_multipliers(o, 1);
+
+    for(iter = 0; iter < o->max_iter; iter++) {
+        if(fresh) {
+            if(!calc_derivs(o)) break;
+            fresh = 0;
+        }
+        for(done = 0; !done;) {
+            if(!back_pass(o)) {
+                done = 1;
+            } else {
+                lambda_increase(o, &dlambda);
+                if(o->lambda > o->lambdaMax) break;
+            }
+        }
+        if(o->g_norm < o->tolGrad && o->lambda < 1e-5) {
+            lambda_decrease(o, &dlambda);
+            break;
+        }
+        if(!done) break;
+
+        stepped = line_search(o, iter);
+        if(stepped) {
+            lambda_decrease(o, &dlambda);
+            makeCandidateNominal(o, 0);
+            o->cost = o->new_cost;
+            fresh = 1;
+            if(o->dcost < o->tolFun) break;
+            update_multipliers(o, 0);
+            forward_pass(o->nominal, o, 0.0, &o->cost, 1);
+        } else {
+            lambda_increase(o, &dlambda);
+            if(o->w_pen_fact2 > 1.0) {
+                o->w_pen_l = min(o->w_pen_max_l, o->w_pen_l * o->w_pen_fact2);
+                o->w_pen_f = min(o->w_pen_max_f, o->w_pen_f * o->w_pen_fact2);
+                forward_pass(o->nominal, o, 0.0, &o->cost, 1);
+            }
+            if(o->lambda > o->lambdaMax) break;
+        }
+    }
+    o->iterations = iter;
+    return (done && iter < o->max_iter) ? 1 : 0;
+}

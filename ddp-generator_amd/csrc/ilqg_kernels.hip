@@ -1,0 +1,985 @@
+// HIP kernels and the extern-"C" shim of the batched iLQG solver (gfx950).
+//
+// One translation unit per problem: the generated problem file iLQG_func.c is
+// #included below, UNMODIFIED, inside a region that marks every function as a
+// device function, so the kernels call the very callbacks the reference's
+// solver calls on the host (ddpf, ddpL, ddpF, clampU, limitsU, bp_derivsL,
+// bp_derivsF, calc*Aux*, init_running/init_final — reference
+// iLQG_func.tem:40-347).  A Maxima-generated problem file drops in the same way.
+//
+// Mapping ("lane mapping"): one lane = one trajectory, 64 trajectories per
+// wavefront.  Device arrays are [time step][field][trajectory] so that a
+// wavefront reads/writes 512 contiguous bytes per field.  All small matrices
+// of a trajectory live in that lane's VGPRs (ilqg_device.hpp).
+//
+// Kernels                             replaces (reference)
+//   k_derivs     lane = (traj, step)   calc_derivs            iLQG_func.tem:187-221
+//   k_backward   lane = traj           back_pass + retry loop back_pass.c:38-257, iLQG.c:261-303
+//   k_rollout    lane = (traj, alpha)  forward_pass           iLQG_func.tem:121-185
+//   k_select     lane = traj           line_search selection  line_search.c:37-75
+//   k_update     lane = traj           accept / reject        iLQG.c:311-361
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "mex.h"
+
+// NaN/Inf guards in generated code still `return 0`; their printing is dropped on the device
+#define PRNT(...) ((void)0)
+
+extern "C" {
+#pragma clang attribute push(__attribute__((device)), apply_to = function)
+#pragma clang attribute push(__attribute__((internal_linkage)), apply_to = variable(is_global))
+#include "iLQG.h"
+#include "matMult.h"
+#include "iLQG_func.c"
+#pragma clang attribute pop
+#pragma clang attribute pop
+}
+
+#include "ilqg_device.hpp"
+#include "ilqg_shim.h"
+
+namespace {
+
+using namespace ilqg;
+
+constexpr int NX = N_X, NU = N_U;
+constexpr bool FULL = FULL_DDP != 0;
+#ifdef ILQG_STATE_DEPENDENT_LIMITS
+constexpr bool HX = ILQG_STATE_DEPENDENT_LIMITS != 0;
+#else
+constexpr bool HX = true;  // Maxima-generated header: assume the general case
+#endif
+using RL = RecLayout<NX, NU, FULL, HX>;
+constexpr int SXX = RL::SXX, SUU = RL::SUU, NXU = RL::NXU, REC = RL::SIZE, REC_HOST = RL::HOST_SIZE;
+constexpr int FIN = NX + SXX;
+constexpr int WAVE = 64;
+
+thread_local std::string g_err;
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if(e_ != hipSuccess) {                                                              \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while(0)
+
+struct DevPtrs {
+    double *f[ILQG_F_COUNT];
+    int *i[ILQG_I_COUNT];
+    int *derivs_failed;
+    double **p;
+    int B, Bp, N;
+};
+
+__device__ __forceinline__ void make_optset(tOptSet &o, const DevPtrs &P, const ilqg_dev_opts_t &O) {
+    o.p = P.p;
+    o.n_hor = P.N;
+    o.w_pen_l = O.w_pen_init_l;
+    o.w_pen_f = O.w_pen_init_f;
+    o.tolConstraint = O.tolConstraint;
+    o.w_pen_fact1 = O.w_pen_fact1;
+    o.w_pen_fact2 = O.w_pen_fact2;
+    o.w_pen_max_l = O.w_pen_max_l;
+    o.w_pen_max_f = O.w_pen_max_f;
+}
+
+// ---------------------------------------------------------------------------
+// host layout [b][k][f]  <->  device layout [k][f][b]
+// ---------------------------------------------------------------------------
+__global__ void k_to_soa(const double *__restrict__ aos, double *__restrict__ soa, int B, int Bp, int steps, int wh,
+                         int wd) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * steps * wd;
+    if(i >= total) return;
+    const int fcol = (int)(i % wd);
+    const int k = (int)((i / wd) % steps);
+    const int b = (int)(i / ((size_t)wd * steps));
+    soa[((size_t)k * wd + fcol) * Bp + b] = aos[((size_t)b * steps + k) * wh + fcol];
+}
+
+__global__ void k_to_aos(const double *__restrict__ soa, double *__restrict__ aos, int B, int Bp, int steps, int wh,
+                         int wd) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * steps * wh;
+    if(i >= total) return;
+    const int fcol = (int)(i % wh);
+    const int k = (int)((i / wh) % steps);
+    const int b = (int)(i / ((size_t)wh * steps));
+    aos[i] = (fcol < wd) ? soa[((size_t)k * wd + fcol) * Bp + b] : 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// calc_derivs: one lane per (trajectory, time step); step N is the final record
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(tid % P.Bp);
+    const int k = (int)(tid / P.Bp);
+    if(k > P.N || b >= P.B) return;
+    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_NEED_DERIVS][b]) return;
+    const size_t Bp = P.Bp;
+
+    tOptSet o;
+    make_optset(o, P, O);
+    int ok = 1;
+    if(k < P.N) {
+        tOptSet o1 = o;
+        o1.n_hor = 1;  // init_running loops over n_hor elements: write this element's constants only
+        trajEl_t t;
+        init_running(&t, &o1);
+#pragma unroll
+        for(int i = 0; i < NX; i++) t.x[i] = P.f[ILQG_F_X][((size_t)k * NX + i) * Bp + b];
+#pragma unroll
+        for(int i = 0; i < NU; i++) t.u[i] = P.f[ILQG_F_U][((size_t)k * NU + i) * Bp + b];
+        // auxiliaries are not kept in HBM: recompute them from the stored (x,u) exactly as
+        // forward_pass did (iLQG_func.tem:160-164), then the reference's calc_derivs body
+        ok &= calcXVariableAux(&t, nullptr, k, &o);
+        ok &= calcXUVariableAux(&t, nullptr, k, &o);
+        ok &= calcLAuxDeriv(&t, nullptr, k, &o);
+        ok &= bp_derivsL(&t, k, o.p);
+        limitsU(&t, k, o.p, P.N);
+
+        double *out = P.f[ILQG_F_DER] + (size_t)k * REC * Bp + b;
+#define PUT(off, arr, cnt) \
+    _Pragma("unroll") for(int i = 0; i < (cnt); i++) out[(size_t)((off) + i) * Bp] = (arr)[i];
+        PUT(RL::CX, t.cx, NX)
+        PUT(RL::CXX, t.cxx, SXX)
+        PUT(RL::CU, t.cu, NU)
+        PUT(RL::CUU, t.cuu, SUU)
+        PUT(RL::CXU, t.cxu, NXU)
+        PUT(RL::FX, t.fx, NX * NX)
+        PUT(RL::FU, t.fu, NXU)
+        PUT(RL::LOWER, t.lower, NU)
+        PUT(RL::UPPER, t.upper, NU)
+#if FULL_DDP
+        PUT(RL::FXX, t.fxx, NX * SXX)
+        PUT(RL::FUU, t.fuu, NX * SUU)
+        PUT(RL::FXU, t.fxu, NX * NXU)
+#endif
+        if(HX) {
+            PUT(RL::LSIGN, t.lower_sign, NU)
+            PUT(RL::USIGN, t.upper_sign, NU)
+            PUT(RL::LHX, t.lower_hx, NXU)
+            PUT(RL::UHX, t.upper_hx, NXU)
+        }
+    } else {
+        trajFin_t fin;
+        init_final(&fin, &o);
+#pragma unroll
+        for(int i = 0; i < NX; i++) fin.x[i] = P.f[ILQG_F_X][((size_t)P.N * NX + i) * Bp + b];
+        ok &= calcFVariableAux(&fin, nullptr, &o);
+        ok &= calcFAuxDeriv(&fin, nullptr, &o);
+        ok &= bp_derivsF(&fin, P.N, o.p);
+        double *out = P.f[ILQG_F_FIN] + b;
+        PUT(0, fin.cx, NX)
+        PUT(NX, fin.cxx, SXX)
+#undef PUT
+    }
+    if(!ok) P.derivs_failed[b] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// back_pass: one lane per trajectory, sequential in time, next record prefetched
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_record(double *dst, double *udst, const DevPtrs &P, int k, int b) {
+    const size_t Bp = P.Bp;
+    const double *src = P.f[ILQG_F_DER] + (size_t)k * REC * Bp + b;
+#pragma unroll
+    for(int i = 0; i < REC; i++) dst[i] = src[(size_t)i * Bp];
+    const double *us = P.f[ILQG_F_U] + (size_t)k * NU * Bp + b;
+#pragma unroll
+    for(int i = 0; i < NU; i++) udst[i] = us[(size_t)i * Bp];
+}
+
+// one sweep k = N-1..0; returns 0 ok, 1 box-QP failed (back_pass.c:168-171)
+__device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double lambda, int regType, double &dV0,
+                                              double &dV1, double &g_norm) {
+    const size_t Bp = P.Bp;
+    const int N = P.N;
+    double Vx[NX], Vxx[SXX], l[NU], K[NXU];
+#pragma unroll
+    for(int i = 0; i < NX; i++) Vx[i] = P.f[ILQG_F_FIN][(size_t)i * Bp + b];
+#pragma unroll
+    for(int i = 0; i < SXX; i++) Vxx[i] = P.f[ILQG_F_FIN][(size_t)(NX + i) * Bp + b];
+#pragma unroll
+    for(int i = 0; i < NU; i++) l[i] = 0.0;  // warm start of the last step (back_pass.c:163-164)
+    dV0 = 0.0;
+    dV1 = 0.0;
+    double gsum = 0.0;
+
+    double cur[REC], ucur[NU];
+    load_record(cur, ucur, P, N - 1, b);
+    int failed = 0;
+    for(int k = N - 1; k >= 0; k--) {
+        double nxt[REC], unxt[NU];
+        if(k > 0) load_record(nxt, unxt, P, k - 1, b);  // in flight while this step computes
+        // l still holds the solution of step k+1: the warm start (back_pass.c:165-166)
+        const int rc = back_step<NX, NU, FULL, HX>(cur, ucur, Vx, Vxx, l, K, lambda, regType, dV0, dV1, gsum);
+        if(rc < 1) {
+            failed = 1;
+            break;
+        }
+        double *lo = P.f[ILQG_F_LG] + (size_t)k * NU * Bp + b;
+#pragma unroll
+        for(int i = 0; i < NU; i++) lo[(size_t)i * Bp] = l[i];
+        double *ko = P.f[ILQG_F_KG] + (size_t)k * NXU * Bp + b;
+#pragma unroll
+        for(int i = 0; i < NXU; i++) ko[(size_t)i * Bp] = K[i];
+#pragma unroll
+        for(int i = 0; i < REC; i++) cur[i] = nxt[i];
+#pragma unroll
+        for(int i = 0; i < NU; i++) ucur[i] = unxt[i];
+    }
+    if(!failed) g_norm = gsum / ((double)(N - 1));  // N summands over N-1 (back_pass.c:254)
+    return failed;
+}
+
+__global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t O, int single_sweep) {
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if(b >= P.B) return;
+    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
+    P.i[ILQG_I_NEED_DERIVS][b] = 0;
+    if(P.derivs_failed[b]) {  // iLQG.c:247-249
+        P.i[ILQG_I_STATUS][b] = ILQG_ST_DERIVS_FAILED;
+        return;
+    }
+    double lambda = P.f[ILQG_F_LAMBDA][b], dlambda = P.f[ILQG_F_DLAMBDA][b];
+    double dV0 = 0.0, dV1 = 0.0, g_norm = P.f[ILQG_F_GNORM][b];
+    int calls = 0, rc;
+    for(;;) {
+        rc = backward_sweep(P, b, lambda, O.regType, dV0, dV1, g_norm);
+        calls++;
+        if(single_sweep || !rc) break;
+        // raise the regularisation and retry (iLQG.c:271-274)
+        const double t1 = dlambda * O.lambdaFactor;
+        dlambda = (t1 > O.lambdaFactor) ? t1 : O.lambdaFactor;
+        const double t2 = lambda * dlambda;
+        lambda = (t2 > O.lambdaMin) ? t2 : O.lambdaMin;
+        if(lambda > O.lambdaMax) break;
+    }
+    if(!single_sweep) {
+        if(rc) {
+            P.i[ILQG_I_STATUS][b] = ILQG_ST_NO_DESCENT;
+        } else if(g_norm < O.tolGrad && lambda < 1e-5) {  // iLQG.c:297-303
+            const double t1 = dlambda / O.lambdaFactor, t2 = 1.0 / O.lambdaFactor;
+            dlambda = (t1 < t2) ? t1 : t2;
+            lambda = lambda * dlambda * (lambda > O.lambdaMin);
+            P.i[ILQG_I_STATUS][b] = ILQG_ST_CONVERGED_GRAD;
+        }
+    }
+    P.f[ILQG_F_LAMBDA][b] = lambda;
+    P.f[ILQG_F_DLAMBDA][b] = dlambda;
+    P.f[ILQG_F_DV0][b] = dV0;
+    P.f[ILQG_F_DV1][b] = dV1;
+    P.f[ILQG_F_GNORM][b] = g_norm;
+    P.i[ILQG_I_BP_CALLS][b] = calls;
+    P.i[ILQG_I_BP_RC][b] = rc;
+}
+
+// ---------------------------------------------------------------------------
+// forward_pass: one lane per (trajectory, step size)
+// ---------------------------------------------------------------------------
+enum { ROLL_INIT = 0, ROLL_SEARCH = 1, ROLL_WINNER = 2, ROLL_COST = 3 };
+
+// `mode` is a run-time argument on purpose: the search pass and the winner pass
+// must execute the same machine code so that the re-rolled winner reproduces
+// the cost the selection was based on, bit for bit.
+__global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, int mode) {
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    const int ai = blockIdx.y;
+    if(b >= P.B) return;
+    const size_t Bp = P.Bp;
+    const int N = P.N;
+    double alpha = 0.0;
+    if(mode == ROLL_SEARCH) {
+        if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
+        alpha = O.alpha[ai];
+    } else if(mode == ROLL_WINNER) {
+        if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) return;
+        alpha = O.alpha[P.i[ILQG_I_ALPHA_IDX][b] - 1];
+    } else if(mode == ROLL_COST) {
+        if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) return;
+    }
+    const bool cost_only = (mode == ROLL_COST);
+    const bool store = (mode == ROLL_INIT || mode == ROLL_WINNER);
+
+    tOptSet o;
+    make_optset(o, P, O);
+    tOptSet o1 = o;
+    o1.n_hor = 1;
+    trajEl_t ct;
+    init_running(&ct, &o1);  // constant auxiliaries of this problem (iLQG_func.tem:312-347)
+
+    double xc[NX];
+#pragma unroll
+    for(int i = 0; i < NX; i++) xc[i] = P.f[ILQG_F_X][(size_t)i * Bp + b];  // x0 (iLQG_func.tem:141-142)
+    double csum = 0.0;
+    int ok = 1;
+    for(int k = 0; k < N; k++) {
+        double xn[NX], un[NU];
+#pragma unroll
+        for(int i = 0; i < NX; i++) xn[i] = P.f[ILQG_F_X][((size_t)k * NX + i) * Bp + b];
+#pragma unroll
+        for(int i = 0; i < NU; i++) un[i] = P.f[ILQG_F_U][((size_t)k * NU + i) * Bp + b];
+        if(cost_only) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) ct.x[i] = xn[i];
+#pragma unroll
+            for(int i = 0; i < NU; i++) ct.u[i] = un[i];
+        } else {
+#pragma unroll
+            for(int i = 0; i < NX; i++) ct.x[i] = xc[i];
+            if(alpha) {
+                // u = u_nom + alpha*l + L (x - x_nom), state by state (iLQG_func.tem:146-155)
+                double lk[NU], Kk[NXU];
+#pragma unroll
+                for(int i = 0; i < NU; i++) lk[i] = P.f[ILQG_F_LG][((size_t)k * NU + i) * Bp + b];
+#pragma unroll
+                for(int i = 0; i < NXU; i++) Kk[i] = P.f[ILQG_F_KG][((size_t)k * NXU + i) * Bp + b];
+#pragma unroll
+                for(int j = 0; j < NU; j++) ct.u[j] = un[j] + lk[j] * alpha;
+#pragma unroll
+                for(int i = 0; i < NX; i++) {
+                    const double dx = ct.x[i] - xn[i];
+#pragma unroll
+                    for(int j = 0; j < NU; j++) ct.u[j] += Kk[j + i * NU] * dx;
+                }
+            } else {
+#pragma unroll
+                for(int j = 0; j < NU; j++) ct.u[j] = un[j];
+            }
+        }
+        if(!calcXVariableAux(&ct, nullptr, k, &o)) { ok = 0; break; }
+        if(!cost_only) clampU(ct.u, &ct, k, o.p, N);
+        if(!calcXUVariableAux(&ct, nullptr, k, &o)) { ok = 0; break; }
+        double xnext[NX];
+        if(!cost_only) {
+            if(!ddpf(xnext, &ct, k, o.p, N)) { ok = 0; break; }
+        }
+        if(!ddpL(&ct, k, &o)) { ok = 0; break; }
+        csum += ct.c;
+        if(store) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) P.f[ILQG_F_X][((size_t)k * NX + i) * Bp + b] = ct.x[i];
+#pragma unroll
+            for(int i = 0; i < NU; i++) P.f[ILQG_F_U][((size_t)k * NU + i) * Bp + b] = ct.u[i];
+        }
+        if(!cost_only) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) xc[i] = xnext[i];
+        }
+    }
+    if(ok) {
+        trajFin_t cf;
+        init_final(&cf, &o);
+        if(cost_only) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) cf.x[i] = P.f[ILQG_F_X][((size_t)N * NX + i) * Bp + b];
+        } else {
+#pragma unroll
+            for(int i = 0; i < NX; i++) cf.x[i] = xc[i];
+        }
+        if(!calcFVariableAux(&cf, nullptr, &o)) ok = 0;
+        if(ok && !ddpF(&cf, &o)) ok = 0;
+        if(ok) {
+            csum += cf.c;
+            if(store) {
+#pragma unroll
+                for(int i = 0; i < NX; i++) P.f[ILQG_F_X][((size_t)N * NX + i) * Bp + b] = cf.x[i];
+            }
+        }
+    }
+
+    if(mode == ROLL_SEARCH) {
+        P.f[ILQG_F_ALPHA_COST][(size_t)ai * Bp + b] = csum;
+        P.i[ILQG_I_ALPHA_OK][(size_t)ai * Bp + b] = ok;
+    } else if(mode == ROLL_WINNER) {
+        P.f[ILQG_F_NEW_COST][b] = csum;
+    } else if(mode == ROLL_COST) {
+        P.f[ILQG_F_COST][b] = csum;
+    } else {
+        P.f[ILQG_F_COST][b] = csum;
+        if(!ok) P.i[ILQG_I_STATUS][b] = ILQG_ST_INIT_FAILED;
+    }
+}
+
+// line_search.c:37-75: the FIRST step size (lowest index) whose forward pass
+// was finite and whose z = dcost/expected exceeds zMin wins
+__global__ void k_select(DevPtrs P, ilqg_dev_opts_t O) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
+    const size_t Bp = P.Bp;
+    const double cost = P.f[ILQG_F_COST][b], dV0 = P.f[ILQG_F_DV0][b], dV1 = P.f[ILQG_F_DV1][b];
+    double cnew = 0.0, dcost = P.f[ILQG_F_DCOST][b], expected = P.f[ILQG_F_EXPECTED][b];
+    int i, ok = 0;
+    for(i = 0; i < O.n_alpha; i++) {
+        const double a = O.alpha[i];
+        ok = P.i[ILQG_I_ALPHA_OK][(size_t)i * Bp + b];
+        cnew = P.f[ILQG_F_ALPHA_COST][(size_t)i * Bp + b];
+        if(!ok) continue;
+        dcost = cost - cnew;
+        expected = -a * (dV0 + a * dV1);
+        const double z = (expected > 0) ? dcost / expected : 0.0;
+        if(z > O.zMin) break;
+        ok = 0;
+    }
+    P.i[ILQG_I_ALPHA_IDX][b] = i + 1;
+    P.i[ILQG_I_ACCEPTED][b] = ok;
+    P.f[ILQG_F_NEW_COST][b] = cnew;
+    P.f[ILQG_F_DCOST][b] = dcost;
+    P.f[ILQG_F_EXPECTED][b] = expected;
+}
+
+// iLQG.c:311-361 and the loop bookkeeping of iLQG.c:239,365-378
+__global__ void k_update(DevPtrs P, ilqg_dev_opts_t O) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
+    double lambda = P.f[ILQG_F_LAMBDA][b], dlambda = P.f[ILQG_F_DLAMBDA][b];
+    int iter = P.i[ILQG_I_ITER][b];
+    int status = ILQG_ST_ACTIVE;
+    if(P.i[ILQG_I_ACCEPTED][b]) {
+        const double t1 = dlambda / O.lambdaFactor, t2 = 1.0 / O.lambdaFactor;
+        dlambda = (t1 < t2) ? t1 : t2;
+        lambda = lambda * dlambda * (lambda > O.lambdaMin);
+        P.f[ILQG_F_COST][b] = P.f[ILQG_F_NEW_COST][b];
+        P.i[ILQG_I_NEED_DERIVS][b] = 1;
+        if(P.f[ILQG_F_DCOST][b] < O.tolFun) status = ILQG_ST_CONVERGED_FUN;
+    } else {
+        const double t1 = dlambda * O.lambdaFactor;
+        dlambda = (t1 > O.lambdaFactor) ? t1 : O.lambdaFactor;
+        const double t2 = lambda * dlambda;
+        lambda = (t2 > O.lambdaMin) ? t2 : O.lambdaMin;
+        if(lambda > O.lambdaMax) status = ILQG_ST_LAMBDA_MAX;
+    }
+    if(status == ILQG_ST_ACTIVE) {
+        iter++;
+        if(iter >= O.max_iter) status = ILQG_ST_MAX_ITER;
+    }
+    P.f[ILQG_F_LAMBDA][b] = lambda;
+    P.f[ILQG_F_DLAMBDA][b] = dlambda;
+    P.i[ILQG_I_ITER][b] = iter;
+    P.i[ILQG_I_STATUS][b] = status;
+}
+
+// solver entry state (iLQG.c:226-237)
+__global__ void k_reset(DevPtrs P, ilqg_dev_opts_t O) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if(b >= P.Bp) return;
+    const bool live = b < P.B && P.i[ILQG_I_STATUS][b] != ILQG_ST_INIT_FAILED;
+    P.f[ILQG_F_LAMBDA][b] = O.lambdaInit;
+    P.f[ILQG_F_DLAMBDA][b] = O.dlambdaInit;
+    P.i[ILQG_I_ITER][b] = 0;
+    P.i[ILQG_I_NEED_DERIVS][b] = 1;
+    P.i[ILQG_I_ACCEPTED][b] = 0;
+    P.i[ILQG_I_BP_CALLS][b] = 0;
+    P.derivs_failed[b] = 0;
+    if(live) P.i[ILQG_I_STATUS][b] = (O.max_iter > 0) ? ILQG_ST_ACTIVE : ILQG_ST_MAX_ITER;
+}
+
+__global__ void k_count_active(const int *status, int B, int *out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int active = (b < B && status[b] == ILQG_ST_ACTIVE) ? 1 : 0;
+    const unsigned long long m = __ballot(active);
+    if((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
+
+// unit-test kernel for box_qp<M>, one problem per lane
+template <int M>
+__global__ __launch_bounds__(64, 1) void k_boxqp_test(int count, const double *H, const double *g, const double *lower, const double *upper,
+                             double *x, int *clamp, int *n_free, double *invH, int *rc) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= count) return;
+    constexpr int T = tri(M);
+    double h[T], gg[M], lo[M], up[M], xx[M], inv[T];
+    int cl[M], nf;
+#pragma unroll
+    for(int i = 0; i < T; i++) h[i] = H[(size_t)t * T + i];
+#pragma unroll
+    for(int i = 0; i < M; i++) {
+        gg[i] = g[(size_t)t * M + i];
+        lo[i] = lower[(size_t)t * M + i];
+        up[i] = upper[(size_t)t * M + i];
+        xx[i] = x[(size_t)t * M + i];
+    }
+    rc[t] = box_qp<M>(h, gg, lo, up, xx, cl, nf, inv);
+    n_free[t] = nf;
+#pragma unroll
+    for(int i = 0; i < M; i++) {
+        x[(size_t)t * M + i] = xx[i];
+        clamp[t * M + i] = cl[i];
+    }
+#pragma unroll
+    for(int i = 0; i < T; i++) invH[(size_t)t * T + i] = inv[i];
+}
+
+}  // namespace
+
+// ===========================================================================
+// shim
+// ===========================================================================
+struct ilqg_dev {
+    int device, B, Bp, N;
+    hipStream_t stream;
+    DevPtrs P;
+    ilqg_dev_opts_t O;
+    std::vector<double *> param_bufs;
+    double *staging;
+    size_t staging_bytes;
+    int *counter;
+    bool timing;
+    struct Span { int kernel; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    double t_ms[ILQG_K_COUNT];
+    int t_n[ILQG_K_COUNT];
+};
+
+namespace {
+
+struct FieldInfo { int steps_plus; int wd, wh; };  // steps = steps_plus<0 ? 1 : N + steps_plus
+
+FieldInfo field_info(int f) {
+    switch(f) {
+        case ILQG_F_X: return {1, NX, NX};
+        case ILQG_F_U: return {0, NU, NU};
+        case ILQG_F_LG: return {0, NU, NU};
+        case ILQG_F_KG: return {0, NXU, NXU};
+        case ILQG_F_DER: return {0, REC, REC_HOST};
+        case ILQG_F_FIN: return {-1, FIN, FIN};
+        case ILQG_F_ALPHA_COST: return {-1, ILQG_MAX_ALPHA, ILQG_MAX_ALPHA};
+        default: return {-1, 1, 1};
+    }
+}
+
+int field_steps(const ilqg_dev *d, int f) {
+    const FieldInfo fi = field_info(f);
+    return fi.steps_plus < 0 ? 1 : d->N + fi.steps_plus;
+}
+
+int int_field_width(int f) { return f == ILQG_I_ALPHA_OK ? ILQG_MAX_ALPHA : 1; }
+
+int ensure_staging(ilqg_dev *d, size_t bytes) {
+    if(bytes <= d->staging_bytes) return 0;
+    if(d->staging) HIP_TRY(hipFree(d->staging));
+    d->staging = nullptr;
+    d->staging_bytes = 0;
+    HIP_TRY(hipMalloc((void **)&d->staging, bytes));
+    d->staging_bytes = bytes;
+    return 0;
+}
+
+struct Timed {
+    ilqg_dev *d;
+    int kernel;
+    hipEvent_t a, b;
+    Timed(ilqg_dev *d_, int k) : d(d_), kernel(k), a(nullptr), b(nullptr) {
+        if(d->timing) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, d->stream);
+        }
+    }
+    ~Timed() {
+        if(d->timing) {
+            hipEventRecord(b, d->stream);
+            d->spans.push_back({kernel, a, b});
+        }
+    }
+};
+
+int drain_spans(ilqg_dev *d) {
+    if(d->spans.empty()) return 0;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for(auto &s : d->spans) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, s.a, s.b);
+        d->t_ms[s.kernel] += ms;
+        d->t_n[s.kernel]++;
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    d->spans.clear();
+    return 0;
+}
+
+inline dim3 grid1(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+extern "C" {
+
+const char *ilqg_dev_error(void) { return g_err.c_str(); }
+
+int ilqg_dev_count(void) {
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void ilqg_dev_dims(int *out) {
+    out[0] = NX;
+    out[1] = NU;
+    out[2] = FULL ? 1 : 0;
+    out[3] = REC_HOST;
+    out[4] = REC;
+    out[5] = HX ? 1 : 0;
+    out[6] = 0;
+}
+
+const char *ilqg_dev_kernel_name(int k) {
+    static const char *names[ILQG_K_COUNT] = {"k_derivs", "k_backward", "k_rollout[search]", "k_select",
+                                              "k_rollout[winner]", "k_update", "k_rollout[cost]", "k_rollout[init]",
+                                              "k_to_soa/k_to_aos"};
+    return (k >= 0 && k < ILQG_K_COUNT) ? names[k] : "?";
+}
+
+int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
+    *out = nullptr;
+    if(batch < 1 || n_hor < 2) {
+        g_err = "ilqg_dev_create: need batch >= 1 and n_hor >= 2";
+        return 1;
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if(device < 0 || device >= ndev) {
+        g_err = "ilqg_dev_create: no such HIP device";
+        return 1;
+    }
+    HIP_TRY(hipSetDevice(device));
+    ilqg_dev *d = new ilqg_dev();
+    d->device = device;
+    d->B = batch;
+    d->Bp = (batch + WAVE - 1) / WAVE * WAVE;
+    d->N = n_hor;
+    d->staging = nullptr;
+    d->staging_bytes = 0;
+    d->timing = false;
+    memset(d->t_ms, 0, sizeof(d->t_ms));
+    memset(d->t_n, 0, sizeof(d->t_n));
+    memset(&d->P, 0, sizeof(d->P));
+    memset(&d->O, 0, sizeof(d->O));
+    d->P.B = d->B;
+    d->P.Bp = d->Bp;
+    d->P.N = d->N;
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    for(int f = 0; f < ILQG_F_COUNT; f++) {
+        const FieldInfo fi = field_info(f);
+        const size_t bytes = (size_t)field_steps(d, f) * fi.wd * d->Bp * sizeof(double);
+        HIP_TRY(hipMalloc((void **)&d->P.f[f], bytes));
+        HIP_TRY(hipMemsetAsync(d->P.f[f], 0, bytes, d->stream));
+    }
+    for(int f = 0; f < ILQG_I_COUNT; f++) {
+        const size_t bytes = (size_t)int_field_width(f) * d->Bp * sizeof(int);
+        HIP_TRY(hipMalloc((void **)&d->P.i[f], bytes));
+        HIP_TRY(hipMemsetAsync(d->P.i[f], 0, bytes, d->stream));
+    }
+    HIP_TRY(hipMalloc((void **)&d->P.derivs_failed, d->Bp * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(d->P.derivs_failed, 0, d->Bp * sizeof(int), d->stream));
+    HIP_TRY(hipMalloc((void **)&d->counter, sizeof(int)));
+    d->P.p = nullptr;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    *out = d;
+    return 0;
+}
+
+void ilqg_dev_destroy(ilqg_dev_t *d) {
+    if(!d) return;
+    hipSetDevice(d->device);
+    hipStreamSynchronize(d->stream);
+    for(auto &s : d->spans) {
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    for(int f = 0; f < ILQG_F_COUNT; f++) hipFree(d->P.f[f]);
+    for(int f = 0; f < ILQG_I_COUNT; f++) hipFree(d->P.i[f]);
+    hipFree(d->P.derivs_failed);
+    hipFree(d->counter);
+    for(double *p : d->param_bufs) hipFree(p);
+    if(d->P.p) hipFree(d->P.p);
+    if(d->staging) hipFree(d->staging);
+    hipStreamDestroy(d->stream);
+    delete d;
+}
+
+int ilqg_dev_set_params(ilqg_dev_t *d, int n_params, const int *sizes, const double *const *values) {
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for(double *p : d->param_bufs) hipFree(p);
+    d->param_bufs.clear();
+    if(d->P.p) hipFree(d->P.p);
+    d->P.p = nullptr;
+    std::vector<double *> ptrs(n_params > 0 ? n_params : 1, nullptr);
+    for(int i = 0; i < n_params; i++) {
+        const int sz = sizes[i] == -1 ? d->N + 1 : sizes[i];
+        double *buf = nullptr;
+        HIP_TRY(hipMalloc((void **)&buf, sz * sizeof(double)));
+        HIP_TRY(hipMemcpy(buf, values[i], sz * sizeof(double), hipMemcpyHostToDevice));
+        d->param_bufs.push_back(buf);
+        ptrs[i] = buf;
+    }
+    HIP_TRY(hipMalloc((void **)&d->P.p, ptrs.size() * sizeof(double *)));
+    HIP_TRY(hipMemcpy(d->P.p, ptrs.data(), ptrs.size() * sizeof(double *), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ilqg_dev_set_opts(ilqg_dev_t *d, const ilqg_dev_opts_t *o) {
+    if(o->n_alpha < 1 || o->n_alpha > ILQG_MAX_ALPHA) {
+        g_err = "ilqg_dev_set_opts: n_alpha must be in 1..16";
+        return 1;
+    }
+    d->O = *o;
+    return 0;
+}
+
+int ilqg_dev_field_width(int field) { return field_info(field).wh; }
+int ilqg_dev_field_steps(ilqg_dev_t *d, int field) { return field_steps(d, field); }
+void *ilqg_dev_field_ptr(ilqg_dev_t *d, int field) { return d->P.f[field]; }
+void *ilqg_dev_stream(ilqg_dev_t *d) { return (void *)d->stream; }
+
+int ilqg_dev_write(ilqg_dev_t *d, int field, const double *host) {
+    return ilqg_dev_write_steps(d, field, host, field_steps(d, field));
+}
+
+int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps) {
+    HIP_TRY(hipSetDevice(d->device));
+    const FieldInfo fi = field_info(field);
+    if(steps < 1 || steps > field_steps(d, field)) {
+        g_err = "ilqg_dev_write_steps: bad step count";
+        return 1;
+    }
+    const size_t n = (size_t)d->B * steps * fi.wh;
+    if(ensure_staging(d, n * sizeof(double))) return 1;
+    HIP_TRY(hipMemcpyAsync(d->staging, host, n * sizeof(double), hipMemcpyHostToDevice, d->stream));
+    {
+        Timed t(d, ILQG_K_TRANSPOSE);
+        const size_t total = (size_t)d->B * steps * fi.wd;
+        hipLaunchKernelGGL(k_to_soa, grid1(total, 256), dim3(256), 0, d->stream, d->staging, d->P.f[field], d->B, d->Bp,
+                           steps, fi.wh, fi.wd);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+int ilqg_dev_read(ilqg_dev_t *d, int field, double *host) {
+    HIP_TRY(hipSetDevice(d->device));
+    const FieldInfo fi = field_info(field);
+    const int steps = field_steps(d, field);
+    const size_t n = (size_t)d->B * steps * fi.wh;
+    if(ensure_staging(d, n * sizeof(double))) return 1;
+    {
+        Timed t(d, ILQG_K_TRANSPOSE);
+        hipLaunchKernelGGL(k_to_aos, grid1(n, 256), dim3(256), 0, d->stream, d->P.f[field], d->staging, d->B, d->Bp,
+                           steps, fi.wh, fi.wd);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, d->staging, n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+// int fields are [width][Bp] on the device, [B][width] on the host
+int ilqg_dev_write_int(ilqg_dev_t *d, int field, const int *host) {
+    HIP_TRY(hipSetDevice(d->device));
+    const int w = int_field_width(field);
+    std::vector<int> tmp((size_t)w * d->Bp, 0);
+    for(int b = 0; b < d->B; b++)
+        for(int j = 0; j < w; j++) tmp[(size_t)j * d->Bp + b] = host[(size_t)b * w + j];
+    HIP_TRY(hipMemcpyAsync(d->P.i[field], tmp.data(), tmp.size() * sizeof(int), hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+int ilqg_dev_read_int(ilqg_dev_t *d, int field, int *host) {
+    HIP_TRY(hipSetDevice(d->device));
+    const int w = int_field_width(field);
+    std::vector<int> tmp((size_t)w * d->Bp, 0);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), d->P.i[field], tmp.size() * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for(int b = 0; b < d->B; b++)
+        for(int j = 0; j < w; j++) host[(size_t)b * w + j] = tmp[(size_t)j * d->Bp + b];
+    return 0;
+}
+
+#define NEED_PARAMS(d)                                                   \
+    if(!(d)->P.p) {                                                      \
+        g_err = "problem parameters not set (ilqg_dev_set_params)";      \
+        return 1;                                                        \
+    }
+
+int ilqg_dev_reset(ilqg_dev_t *d) {
+    HIP_TRY(hipSetDevice(d->device));
+    hipLaunchKernelGGL(k_reset, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int n_alpha) {
+    Timed t(d, kernel_id);
+    hipLaunchKernelGGL(k_rollout, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE), 0, d->stream, d->P, d->O, mode);
+    return 0;
+}
+
+int ilqg_dev_rollout_init(ilqg_dev_t *d) {
+    NEED_PARAMS(d);
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipMemsetAsync(d->P.i[ILQG_I_STATUS], 0, d->Bp * sizeof(int), d->stream));
+    launch_rollout(d, ROLL_INIT, ILQG_K_ROLLOUT_INIT, 1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ilqg_dev_derivs(ilqg_dev_t *d) {
+    NEED_PARAMS(d);
+    HIP_TRY(hipSetDevice(d->device));
+    {
+        Timed t(d, ILQG_K_DERIVS);
+        const size_t total = (size_t)d->Bp * (d->N + 1);
+        hipLaunchKernelGGL(k_derivs, grid1(total, 256), dim3(256), 0, d->stream, d->P, d->O);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ilqg_dev_backward(ilqg_dev_t *d, int single_sweep) {
+    HIP_TRY(hipSetDevice(d->device));
+    {
+        Timed t(d, ILQG_K_BACKWARD);
+        hipLaunchKernelGGL(k_backward, dim3(d->Bp / WAVE), dim3(WAVE), 0, d->stream, d->P, d->O, single_sweep);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ilqg_dev_search(ilqg_dev_t *d) {
+    NEED_PARAMS(d);
+    HIP_TRY(hipSetDevice(d->device));
+    launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, d->O.n_alpha);
+    {
+        Timed t(d, ILQG_K_SELECT);
+        hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ilqg_dev_winner(ilqg_dev_t *d) {
+    NEED_PARAMS(d);
+    HIP_TRY(hipSetDevice(d->device));
+    launch_rollout(d, ROLL_WINNER, ILQG_K_ROLLOUT_WINNER, 1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ilqg_dev_update(ilqg_dev_t *d) {
+    NEED_PARAMS(d);
+    HIP_TRY(hipSetDevice(d->device));
+    {
+        Timed t(d, ILQG_K_UPDATE);
+        hipLaunchKernelGGL(k_update, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O);
+    }
+    if(d->O.resweep) launch_rollout(d, ROLL_COST, ILQG_K_ROLLOUT_COST, 1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ilqg_dev_iterate(ilqg_dev_t *d, int n) {
+    for(int it = 0; it < n; it++) {
+        if(ilqg_dev_derivs(d)) return 1;
+        if(ilqg_dev_backward(d, 0)) return 1;
+        if(ilqg_dev_search(d)) return 1;
+        if(ilqg_dev_winner(d)) return 1;
+        if(ilqg_dev_update(d)) return 1;
+    }
+    return 0;
+}
+
+int ilqg_dev_sync(ilqg_dev_t *d) {
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+int ilqg_dev_count_active(ilqg_dev_t *d, int *n_active) {
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipMemsetAsync(d->counter, 0, sizeof(int), d->stream));
+    hipLaunchKernelGGL(k_count_active, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P.i[ILQG_I_STATUS], d->B,
+                       d->counter);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(n_active, d->counter, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+int ilqg_dev_timing(ilqg_dev_t *d, int enable) {
+    if(drain_spans(d)) return 1;
+    d->timing = enable != 0;
+    memset(d->t_ms, 0, sizeof(d->t_ms));
+    memset(d->t_n, 0, sizeof(d->t_n));
+    return 0;
+}
+
+int ilqg_dev_get_timing(ilqg_dev_t *d, int kernel, int *launches, double *total_ms) {
+    if(kernel < 0 || kernel >= ILQG_K_COUNT) {
+        g_err = "ilqg_dev_get_timing: bad kernel id";
+        return 1;
+    }
+    if(drain_spans(d)) return 1;
+    *launches = d->t_n[kernel];
+    *total_ms = d->t_ms[kernel];
+    return 0;
+}
+
+int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                         const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
+    if(n != 2 && n != 8 && n != NU) {
+        g_err = "ilqg_dev_boxqp_batch: n must be 2, 8 or N_U";
+        return 1;
+    }
+    HIP_TRY(hipSetDevice(device));
+    const size_t T = n * (n + 1) / 2;
+    double *dH, *dg, *dlo, *dup, *dx, *dinv;
+    int *dcl, *dnf, *drc;
+    HIP_TRY(hipMalloc((void **)&dH, count * T * 8));
+    HIP_TRY(hipMalloc((void **)&dinv, count * T * 8));
+    HIP_TRY(hipMalloc((void **)&dg, count * n * 8));
+    HIP_TRY(hipMalloc((void **)&dlo, count * n * 8));
+    HIP_TRY(hipMalloc((void **)&dup, count * n * 8));
+    HIP_TRY(hipMalloc((void **)&dx, count * n * 8));
+    HIP_TRY(hipMalloc((void **)&dcl, count * n * 4));
+    HIP_TRY(hipMalloc((void **)&dnf, count * 4));
+    HIP_TRY(hipMalloc((void **)&drc, count * 4));
+    HIP_TRY(hipMemcpy(dH, H, count * T * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dg, g, count * n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dlo, lower, count * n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dup, upper, count * n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dx, x, count * n * 8, hipMemcpyHostToDevice));
+    const dim3 grid = grid1(count, 64), block(64);
+    if(n == 2)
+        hipLaunchKernelGGL(k_boxqp_test<2>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
+    else if(n == 8)
+        hipLaunchKernelGGL(k_boxqp_test<8>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
+    else
+        hipLaunchKernelGGL(k_boxqp_test<NU>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(x, dx, count * n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(invH, dinv, count * T * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(clamp, dcl, count * n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(n_free, dnf, count * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rc, drc, count * 4, hipMemcpyDeviceToHost));
+    hipFree(dH); hipFree(dinv); hipFree(dg); hipFree(dlo); hipFree(dup); hipFree(dx);
+    hipFree(dcl); hipFree(dnf); hipFree(drc);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+/* Thin extern-"C" boundary between the C host code (ilqg_host.c) and the HIP
+ * kernels (ilqg_kernels.hip).  Plain pointers, ints and doubles only.
+ *
+ * Host-side data crosses this boundary in trajectory-major layout
+ * [trajectory][time step][field], i.e. what a caller holding `trajEl_t`
+ * arrays can produce with a memcpy per field (reference iLQG_mex.c:113-137
+ * walks its trajectories the same way).  On the device the batch is stored
+ * batch-innermost, [time step][field][trajectory], so that one wavefront of 64
+ * trajectories reads 512 contiguous bytes per field.
+ */
+#ifndef ILQG_SHIM_H
+#define ILQG_SHIM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILQG_MAX_ALPHA 16
+
+typedef struct ilqg_dev ilqg_dev_t;
+
+/* solver options, same meaning as the fields of tOptSet (reference iLQG.h:37-76) */
+typedef struct {
+    int n_alpha;
+    double alpha[ILQG_MAX_ALPHA];
+    double tolFun, tolGrad, tolConstraint;
+    double lambdaInit, dlambdaInit, lambdaFactor, lambdaMax, lambdaMin;
+    double zMin;
+    int regType;
+    int max_iter;
+    double w_pen_init_l, w_pen_init_f, w_pen_max_l, w_pen_max_f, w_pen_fact1, w_pen_fact2;
+    int resweep; /* 1: repeat the reference's cost-only sweep after an accepted step (iLQG.c:338) */
+} ilqg_dev_opts_t;
+
+/* per-trajectory status of the lock-step solver */
+enum {
+    ILQG_ST_ACTIVE = 0,
+    ILQG_ST_CONVERGED_GRAD = 1, /* g_norm < tolGrad && lambda < 1e-5      (iLQG.c:297-303) */
+    ILQG_ST_CONVERGED_FUN = 2,  /* accepted step with dcost < tolFun      (iLQG.c:330-335) */
+    ILQG_ST_MAX_ITER = 3,       /* max_iter iterations done               (iLQG.c:372-376) */
+    ILQG_ST_NO_DESCENT = 4,     /* back pass: lambda > lambdaMax          (iLQG.c:273-274) */
+    ILQG_ST_LAMBDA_MAX = 5,     /* rejected step: lambda > lambdaMax      (iLQG.c:356-360) */
+    ILQG_ST_DERIVS_FAILED = 6,  /* NaN/Inf in calc_derivs                 (iLQG.c:247-249) */
+    ILQG_ST_INIT_FAILED = 7     /* NaN/Inf in the initial roll-out        (iLQG_mex.c:116) */
+};
+
+/* double-valued device fields.  [N] = n_hor */
+enum {
+    ILQG_F_X = 0,    /* [N+1][N_X]   nominal states                     */
+    ILQG_F_U,        /* [N][N_U]     nominal controls                   */
+    ILQG_F_LG,       /* [N][N_U]     feed-forward gains l               */
+    ILQG_F_KG,       /* [N][N_U*N_X] feedback gains L (column-major)    */
+    ILQG_F_DER,      /* [N][host record] derivative records             */
+    ILQG_F_FIN,      /* [N_X+sizeofQxx] final cx, cxx                   */
+    ILQG_F_COST,     /* scalars per trajectory from here on             */
+    ILQG_F_NEW_COST,
+    ILQG_F_DCOST,
+    ILQG_F_EXPECTED,
+    ILQG_F_LAMBDA,
+    ILQG_F_DLAMBDA,
+    ILQG_F_GNORM,
+    ILQG_F_DV0,
+    ILQG_F_DV1,
+    ILQG_F_ALPHA_COST, /* [n_alpha] cost of every step size of the last line search */
+    ILQG_F_COUNT
+};
+
+/* int-valued device fields, one value per trajectory unless noted */
+enum {
+    ILQG_I_STATUS = 0,
+    ILQG_I_ITER,        /* reference's o->iterations                     */
+    ILQG_I_NEED_DERIVS,
+    ILQG_I_ALPHA_IDX,   /* 1-based accepted step index, n_alpha+1 = none */
+    ILQG_I_ACCEPTED,
+    ILQG_I_BP_CALLS,    /* backward sweeps in the last iteration         */
+    ILQG_I_BP_RC,       /* result of the last backward sweep: 0 ok, 1 failed */
+    ILQG_I_ALPHA_OK,    /* [n_alpha] forward pass finite?                */
+    ILQG_I_COUNT
+};
+
+/* kernels, for timing queries */
+enum {
+    ILQG_K_DERIVS = 0,
+    ILQG_K_BACKWARD,
+    ILQG_K_ROLLOUT_SEARCH,
+    ILQG_K_SELECT,
+    ILQG_K_ROLLOUT_WINNER,
+    ILQG_K_UPDATE,
+    ILQG_K_ROLLOUT_COST,
+    ILQG_K_ROLLOUT_INIT,
+    ILQG_K_TRANSPOSE,
+    ILQG_K_COUNT
+};
+
+/* all functions return 0 on success, non-zero on error (message via ilqg_dev_error) */
+const char *ilqg_dev_error(void);
+int ilqg_dev_count(void);
+int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor);
+void ilqg_dev_destroy(ilqg_dev_t *d);
+
+/* compile-time facts of the problem this library was built for:
+ * out[0..6] = N_X, N_U, FULL_DDP, host record size, device record size, state-dependent limits, n_params */
+void ilqg_dev_dims(int *out);
+
+int ilqg_dev_set_params(ilqg_dev_t *d, int n_params, const int *sizes, const double *const *values);
+int ilqg_dev_set_opts(ilqg_dev_t *d, const ilqg_dev_opts_t *o);
+
+/* host <-> device, host side trajectory-major [batch][steps][width] */
+int ilqg_dev_write(ilqg_dev_t *d, int field, const double *host);
+int ilqg_dev_read(ilqg_dev_t *d, int field, double *host);
+/* only the first `steps` time steps of a field, host [batch][steps][width] (e.g. x0 = step 0 of X) */
+int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps);
+int ilqg_dev_write_int(ilqg_dev_t *d, int field, const int *host);
+int ilqg_dev_read_int(ilqg_dev_t *d, int field, int *host);
+int ilqg_dev_field_width(int field);                 /* doubles per step and trajectory (host view) */
+int ilqg_dev_field_steps(ilqg_dev_t *d, int field);  /* time steps stored */
+/* device address of a per-trajectory scalar field (for collectives on device memory) */
+void *ilqg_dev_field_ptr(ilqg_dev_t *d, int field);
+void *ilqg_dev_stream(ilqg_dev_t *d);
+
+/* stages (all asynchronous on the context's stream) */
+int ilqg_dev_reset(ilqg_dev_t *d);            /* solver entry state (iLQG.c:226-237) */
+int ilqg_dev_rollout_init(ilqg_dev_t *d);     /* forward_pass(alpha = 0) + swap (iLQG_mex.c:113-120) */
+int ilqg_dev_derivs(ilqg_dev_t *d);           /* calc_derivs for trajectories that need it */
+int ilqg_dev_backward(ilqg_dev_t *d, int single_sweep); /* back_pass; 0: with the lambda retry loop and gradient test */
+int ilqg_dev_search(ilqg_dev_t *d);           /* all step sizes in parallel + first-acceptable selection */
+int ilqg_dev_winner(ilqg_dev_t *d);           /* re-roll the accepted step size, storing the trajectory */
+int ilqg_dev_update(ilqg_dev_t *d);           /* accept/reject bookkeeping (iLQG.c:311-361) */
+int ilqg_dev_iterate(ilqg_dev_t *d, int n);   /* n lock-step iterations */
+int ilqg_dev_sync(ilqg_dev_t *d);
+int ilqg_dev_count_active(ilqg_dev_t *d, int *n_active); /* synchronises */
+
+/* per-kernel HIP-event timing on the context's stream */
+int ilqg_dev_timing(ilqg_dev_t *d, int enable);
+int ilqg_dev_get_timing(ilqg_dev_t *d, int kernel, int *launches, double *total_ms);
+const char *ilqg_dev_kernel_name(int kernel);
+
+/* unit-test entry for the device box-QP (same template the backward kernel uses):
+ * `count` independent problems of size n (2 or 8), arrays [count][...] */
+int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                         const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,288 @@
+"""ctypes view of the batched iLQG C-ABI (include/ilqg_batch.h).
+
+This module holds no numerics: every method forwards to the shared library
+built from ddp-generator_amd/csrc (C host + HIP kernels).  If that library is
+missing the import of a solver FAILS LOUDLY — there is no Python or CPU
+fallback for the hot path.
+
+Naming follows the reference's MEX entry
+`[success, x, u, cost] = iLQG<Problem>(x0, u_nom, params, opts)`
+(iLQG_mex.c:19-52): parameters by name, options by name, same option keys and
+error messages (iLQG.c:91-216).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.join(HERE, "lib")
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+STATUS = {0: "active", 1: "converged_grad", 2: "converged_fun", 3: "max_iter", 4: "no_descent",
+          5: "lambda_max", 6: "derivs_failed", 7: "init_failed"}
+# the reference's iLQG() return value for each exit (1 = "success", iLQG.c:365-378 and SURVEY Appendix B-11)
+REFERENCE_SUCCESS = {1: 1, 2: 1, 5: 1, 3: 0, 4: 0, 6: 0, 7: 0}
+
+MAX_ALPHA = 16
+
+
+class IlqgError(RuntimeError):
+    pass
+
+
+def library_path(problem="carparking", full_ddp=0):
+    return os.path.join(LIBDIR, "libilqg_%s_fd%d_hip.so" % (problem, int(full_ddp)))
+
+
+_libs = {}
+
+
+def load_library(problem="carparking", full_ddp=0):
+    path = library_path(problem, full_ddp)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise IlqgError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(make -C ddp-generator_amd/csrc). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    v = C.c_void_p
+    lib.ilqg_problem_dims.argtypes = [_ip]
+    lib.ilqg_problem_param_name.restype = C.c_char_p
+    lib.ilqg_problem_param_name.argtypes = [C.c_int]
+    lib.ilqg_problem_param_size.argtypes = [C.c_int]
+    lib.ilqg_batch_create.restype = v
+    lib.ilqg_batch_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.ilqg_batch_destroy.argtypes = [v]
+    lib.ilqg_batch_error.restype = C.c_char_p
+    lib.ilqg_batch_error.argtypes = [v]
+    lib.ilqg_batch_set_option.argtypes = [v, C.c_char_p, _dp, C.c_int]
+    lib.ilqg_batch_set_param.argtypes = [v, C.c_char_p, _dp, C.c_int]
+    lib.ilqg_batch_set_x0.argtypes = [v, _dp]
+    lib.ilqg_batch_set_u.argtypes = [v, _dp]
+    for f in ("init", "solve", "sync", "calc_derivs", "line_search", "update"):
+        getattr(lib, "ilqg_batch_" + f).argtypes = [v]
+    lib.ilqg_batch_iterate.argtypes = [v, C.c_int]
+    lib.ilqg_batch_back_pass.argtypes = [v, C.c_int]
+    lib.ilqg_batch_active.argtypes = [v, _ip]
+    lib.ilqg_batch_get_x.argtypes = [v, _dp]
+    lib.ilqg_batch_get_u.argtypes = [v, _dp]
+    lib.ilqg_batch_get_gains.argtypes = [v, _dp, _dp]
+    lib.ilqg_batch_set_gains.argtypes = [v, _dp, _dp]
+    lib.ilqg_batch_get_derivs.argtypes = [v, _dp, _dp]
+    lib.ilqg_batch_set_derivs.argtypes = [v, _dp, _dp]
+    lib.ilqg_batch_get_scalar.argtypes = [v, C.c_char_p, _dp]
+    lib.ilqg_batch_set_scalar.argtypes = [v, C.c_char_p, _dp]
+    lib.ilqg_batch_get_int.argtypes = [v, C.c_char_p, _ip]
+    lib.ilqg_batch_set_int.argtypes = [v, C.c_char_p, _ip]
+    lib.ilqg_batch_cost_device_ptr.restype = v
+    lib.ilqg_batch_cost_device_ptr.argtypes = [v]
+    lib.ilqg_batch_stream.restype = v
+    lib.ilqg_batch_stream.argtypes = [v]
+    lib.ilqg_batch_timing.argtypes = [v, C.c_int]
+    lib.ilqg_batch_kernel_name.restype = C.c_char_p
+    lib.ilqg_batch_kernel_name.argtypes = [C.c_int]
+    lib.ilqg_batch_get_timing.argtypes = [v, C.c_int, _ip, _dp]
+    lib.ilqg_boxqp_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _ip]
+    _libs[path] = lib
+    return lib
+
+
+class Problem:
+    """compile-time facts of one problem library"""
+
+    def __init__(self, problem="carparking", full_ddp=0):
+        self.name, self.full_ddp = problem, int(full_ddp)
+        self.lib = load_library(problem, full_ddp)
+        d = np.zeros(8, dtype=np.int32)
+        self.lib.ilqg_problem_dims(d)
+        self.nx, self.nu, _, self.rec_host, self.rec_dev, self.state_dep_limits, self.n_params = [int(x) for x in d[:7]]
+        self.sxx = self.nx * (self.nx + 1) // 2
+        self.suu = self.nu * (self.nu + 1) // 2
+        self.params = [(self.lib.ilqg_problem_param_name(i).decode(), self.lib.ilqg_problem_param_size(i))
+                       for i in range(self.n_params)]
+
+    def device_count(self):
+        return self.lib.ilqg_device_count()
+
+
+class BatchSolver:
+    """B trajectories of one problem advanced in lock step on one GPU."""
+
+    def __init__(self, problem="carparking", full_ddp=0, batch=1, n_hor=500, device=0, params=None, opts=None):
+        self.problem = Problem(problem, full_ddp)
+        self.lib = self.problem.lib
+        self.B, self.N = int(batch), int(n_hor)
+        self.h = self.lib.ilqg_batch_create(int(device), self.B, self.N)
+        if not self.h:
+            raise IlqgError(self.lib.ilqg_batch_error(None).decode())
+        for k, val in (params or {}).items():
+            self.set_param(k, val)
+        for k, val in (opts or {}).items():
+            self.set_option(k, val)
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ilqg_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise IlqgError(self.lib.ilqg_batch_error(self.h).decode())
+
+    # -- configuration -----------------------------------------------------
+    def set_option(self, name, value):
+        v = np.ascontiguousarray(np.atleast_1d(value), dtype=np.float64)
+        self._ck(self.lib.ilqg_batch_set_option(self.h, name.encode(), v, v.size))
+
+    def set_param(self, name, value):
+        v = np.ascontiguousarray(np.atleast_1d(value), dtype=np.float64)
+        self._ck(self.lib.ilqg_batch_set_param(self.h, name.encode(), v, v.size))
+
+    def init(self, x0, u0):
+        """x0 [B,nx], u0 [B,N,nu]: initial roll-out (clamps u) and solver entry state"""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(self.B, self.problem.nx)
+        u0 = np.ascontiguousarray(u0, dtype=np.float64).reshape(self.B, self.N, self.problem.nu)
+        self._ck(self.lib.ilqg_batch_set_x0(self.h, x0))
+        self._ck(self.lib.ilqg_batch_set_u(self.h, u0))
+        self._ck(self.lib.ilqg_batch_init(self.h))
+
+    # -- solver ------------------------------------------------------------
+    def iterate(self, n=1):
+        self._ck(self.lib.ilqg_batch_iterate(self.h, int(n)))
+
+    def solve(self):
+        self._ck(self.lib.ilqg_batch_solve(self.h))
+
+    def sync(self):
+        self._ck(self.lib.ilqg_batch_sync(self.h))
+
+    def active(self):
+        n = np.zeros(1, dtype=np.int32)
+        self._ck(self.lib.ilqg_batch_active(self.h, n))
+        return int(n[0])
+
+    def calc_derivs(self):
+        self._ck(self.lib.ilqg_batch_calc_derivs(self.h))
+
+    def back_pass(self, single_sweep=False):
+        self._ck(self.lib.ilqg_batch_back_pass(self.h, 1 if single_sweep else 0))
+
+    def line_search(self):
+        self._ck(self.lib.ilqg_batch_line_search(self.h))
+
+    def update(self):
+        self._ck(self.lib.ilqg_batch_update(self.h))
+
+    # -- results -----------------------------------------------------------
+    def x(self):
+        out = np.zeros((self.B, self.N + 1, self.problem.nx))
+        self._ck(self.lib.ilqg_batch_get_x(self.h, out))
+        return out
+
+    def u(self):
+        out = np.zeros((self.B, self.N, self.problem.nu))
+        self._ck(self.lib.ilqg_batch_get_u(self.h, out))
+        return out
+
+    def gains(self):
+        l = np.zeros((self.B, self.N, self.problem.nu))
+        L = np.zeros((self.B, self.N, self.problem.nu * self.problem.nx))
+        self._ck(self.lib.ilqg_batch_get_gains(self.h, l, L))
+        return l, L
+
+    def set_gains(self, l, L):
+        self._ck(self.lib.ilqg_batch_set_gains(self.h, np.ascontiguousarray(l, dtype=np.float64),
+                                               np.ascontiguousarray(L, dtype=np.float64)))
+
+    def derivs(self):
+        rec = np.zeros((self.B, self.N, self.problem.rec_host))
+        fin = np.zeros((self.B, self.problem.nx + self.problem.sxx))
+        self._ck(self.lib.ilqg_batch_get_derivs(self.h, rec, fin))
+        return rec, fin
+
+    def set_derivs(self, rec, fin):
+        rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(self.B, self.N, self.problem.rec_host)
+        fin = np.ascontiguousarray(fin, dtype=np.float64).reshape(self.B, self.problem.nx + self.problem.sxx)
+        self._ck(self.lib.ilqg_batch_set_derivs(self.h, rec, fin))
+
+    def scalar(self, name):
+        w = MAX_ALPHA if name == "alpha_cost" else 1
+        out = np.zeros((self.B, w))
+        self._ck(self.lib.ilqg_batch_get_scalar(self.h, name.encode(), out))
+        return out if w > 1 else out[:, 0]
+
+    def set_scalar(self, name, value):
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float64), (self.B,)))
+        self._ck(self.lib.ilqg_batch_set_scalar(self.h, name.encode(), v))
+
+    def ints(self, name):
+        w = MAX_ALPHA if name == "alpha_ok" else 1
+        out = np.zeros((self.B, w), dtype=np.int32)
+        self._ck(self.lib.ilqg_batch_get_int(self.h, name.encode(), out))
+        return out if w > 1 else out[:, 0]
+
+    def set_ints(self, name, value):
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.int32), (self.B,)))
+        self._ck(self.lib.ilqg_batch_set_int(self.h, name.encode(), v))
+
+    def success(self):
+        """the reference's iLQG() return value per trajectory"""
+        return np.array([REFERENCE_SUCCESS.get(int(s), 0) for s in self.ints("status")], dtype=np.int32)
+
+    # -- plumbing for collectives / profiling ------------------------------
+    def cost_device_ptr(self):
+        return self.lib.ilqg_batch_cost_device_ptr(self.h)
+
+    def stream(self):
+        return self.lib.ilqg_batch_stream(self.h)
+
+    def timing(self, enable=True):
+        self._ck(self.lib.ilqg_batch_timing(self.h, 1 if enable else 0))
+
+    def kernel_times(self):
+        """{kernel name: (launches, total ms)} measured with HIP events on the solver's stream"""
+        out = {}
+        n = np.zeros(1, dtype=np.int32)
+        ms = np.zeros(1)
+        for k in range(self.lib.ilqg_batch_kernel_count()):
+            self._ck(self.lib.ilqg_batch_get_timing(self.h, k, n, ms))
+            out[self.lib.ilqg_batch_kernel_name(k).decode()] = (int(n[0]), float(ms[0]))
+        return out
+
+
+def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, device=0):
+    """device box-QP on `count` independent problems (arrays [count, ...]); unit-test entry"""
+    lib = load_library(problem, full_ddp)
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    count = H.shape[0]
+    t = n * (n + 1) // 2
+    x = np.array(x0, dtype=np.float64).reshape(count, n).copy()
+    clamp = np.zeros((count, n), dtype=np.int32)
+    nfree = np.zeros(count, dtype=np.int32)
+    invH = np.zeros((count, t))
+    rc = np.zeros(count, dtype=np.int32)
+    r = lib.ilqg_boxqp_batch(device, n, count, H.reshape(count, t), np.ascontiguousarray(g, dtype=np.float64),
+                             np.ascontiguousarray(lower, dtype=np.float64), np.ascontiguousarray(upper, dtype=np.float64),
+                             x, clamp, nfree, invH, rc)
+    if r:
+        raise IlqgError("ilqg_boxqp_batch failed")
+    return dict(rc=rc, x=x, clamp=clamp, n_free=nfree, invH=invH)
+
+
+# CarParking demo parameters, reference examples/CarParking/testCar.m:2-11
+CAR_PARAMS = dict(
+    d=[2.0], h=[0.03],
+    pf=[0.01, 0.01, 0.01, 1.0], cf=[0.1, 0.1, 1.0, 0.3],
+    cu=[1e-2, 1e-4], cx=[1e-3, 1e-3], px=[0.1, 0.1],
+    limW=[-0.5, 0.5], limA=[-2.0, 2.0],
+)

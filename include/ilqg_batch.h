@@ -1,0 +1,111 @@
+/* Batched iLQG on MI355X — public C-ABI (additive; the reference has no batch mode).
+ *
+ * The library is built per problem (like the reference, whose N_X/N_U are
+ * compile-time macros of the generated header, iLQG_problem.tem:16-21):
+ *     libilqg_<problem>_fd<FULL_DDP>_hip.so
+ * It exports
+ *   (1) the reference's own link-time symbols — iLQG(), back_pass(),
+ *       line_search(), boxQP(), standard_parameters(), setOptParam(),
+ *       makeCandidateNominal(), printParams() (include/iLQG.h, back_pass.h,
+ *       line_search.h, boxQP.h) — operating on one `tOptSet`, with the hot path
+ *       executed by the HIP kernels, and
+ *   (2) the batch interface below: B independent trajectories of the same
+ *       problem advanced in lock step on one GPU, all state resident in HBM.
+ *
+ * Every entry point takes plain pointers and sizes.  Host arrays are
+ * trajectory-major: x is [B][n_hor+1][N_X], u is [B][n_hor][N_U], l is
+ * [B][n_hor][N_U], L is [B][n_hor][N_U*N_X] (each step an N_U x N_X
+ * column-major matrix, reference iLQG_func.tem:152) — for B = 1 exactly the
+ * column-major x_new(n,N), u_new(m,N-1) matrices of the reference's MEX entry
+ * (iLQG_mex.c:93-97,127-137).
+ *
+ * Functions returning int: 0 = ok, non-zero = error, text via ilqg_batch_error().
+ */
+#ifndef ILQG_BATCH_H
+#define ILQG_BATCH_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ilqg_batch ilqg_batch_t;
+
+/* problem facts of this build: out[0..6] = N_X, N_U, FULL_DDP, derivative
+ * record size (host view), record size stored on the device, 1 if input limits
+ * depend on the state, number of problem parameters */
+void ilqg_problem_dims(int *out);
+/* problem parameters, as the generated paramdesc[] declares them (iLQG_func.tem:11-18);
+ * size -1 = one value per time step (n_hor+1 values) */
+const char *ilqg_problem_param_name(int i);
+int ilqg_problem_param_size(int i);
+
+/* number of HIP devices visible; 0 if none */
+int ilqg_device_count(void);
+
+ilqg_batch_t *ilqg_batch_create(int device, int batch, int n_hor); /* NULL on failure (ilqg_batch_error(NULL)) */
+void ilqg_batch_destroy(ilqg_batch_t *c);
+const char *ilqg_batch_error(const ilqg_batch_t *c);
+
+/* options: same keys, validation and messages as the reference's setOptParam
+ * (iLQG.c:91-216); additionally "resweep" (0/1, default 1: repeat the
+ * reference's cost-only sweep after each accepted step, iLQG.c:338).
+ * Defaults = standard_parameters() (iLQG.c:57-78). */
+int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value, int n);
+/* problem parameter by name, shared by all trajectories (iLQG_mex.c:70-84) */
+int ilqg_batch_set_param(ilqg_batch_t *c, const char *name, const double *value, int n);
+
+/* initial conditions and initial controls, then the initial roll-out
+ * (forward_pass with alpha = 0, which also clamps u; iLQG_mex.c:113-120)
+ * and the solver's entry state (iLQG.c:226-237) */
+int ilqg_batch_set_x0(ilqg_batch_t *c, const double *x0 /* [B][N_X] */);
+int ilqg_batch_set_u(ilqg_batch_t *c, const double *u /* [B][n_hor][N_U] */);
+int ilqg_batch_init(ilqg_batch_t *c);
+
+/* n lock-step iterations of { calc_derivs, back_pass (+ lambda retries),
+ * line_search over all alpha, accept/reject } for every still-active trajectory */
+int ilqg_batch_iterate(ilqg_batch_t *c, int n);
+/* iterate until no trajectory is active (at most max_iter iterations) */
+int ilqg_batch_solve(ilqg_batch_t *c);
+int ilqg_batch_sync(ilqg_batch_t *c);
+int ilqg_batch_active(ilqg_batch_t *c, int *n_active);
+
+/* single stages, for tests and for callers that interleave their own work */
+int ilqg_batch_calc_derivs(ilqg_batch_t *c);
+int ilqg_batch_back_pass(ilqg_batch_t *c, int single_sweep);
+int ilqg_batch_line_search(ilqg_batch_t *c);  /* search + selection + store the winner */
+int ilqg_batch_update(ilqg_batch_t *c);
+
+/* results (copied to host, trajectory-major) */
+int ilqg_batch_get_x(ilqg_batch_t *c, double *x);
+int ilqg_batch_get_u(ilqg_batch_t *c, double *u);
+int ilqg_batch_get_gains(ilqg_batch_t *c, double *l, double *L);
+int ilqg_batch_get_derivs(ilqg_batch_t *c, double *rec /* [B][n_hor][record] */, double *fin /* [B][N_X+sizeofQxx] */);
+int ilqg_batch_set_derivs(ilqg_batch_t *c, const double *rec, const double *fin);
+int ilqg_batch_set_gains(ilqg_batch_t *c, const double *l, const double *L);
+/* name in: cost new_cost dcost expected lambda dlambda g_norm dV0 dV1 ([B] each),
+ * alpha_cost ([B][16]) */
+int ilqg_batch_get_scalar(ilqg_batch_t *c, const char *name, double *out);
+int ilqg_batch_set_scalar(ilqg_batch_t *c, const char *name, const double *in);
+/* name in: status iterations alpha_idx accepted bp_calls bp_rc need_derivs ([B] each), alpha_ok ([B][16]) */
+int ilqg_batch_get_int(ilqg_batch_t *c, const char *name, int *out);
+int ilqg_batch_set_int(ilqg_batch_t *c, const char *name, const int *in);
+
+/* device address of the per-trajectory cost vector (B doubles, for a collective
+ * over device memory) and the HIP stream all work of this context runs on */
+void *ilqg_batch_cost_device_ptr(ilqg_batch_t *c);
+void *ilqg_batch_stream(ilqg_batch_t *c);
+
+/* per-kernel device time measured with HIP events on the context's stream */
+int ilqg_batch_timing(ilqg_batch_t *c, int enable);
+int ilqg_batch_kernel_count(void);
+const char *ilqg_batch_kernel_name(int kernel);
+int ilqg_batch_get_timing(ilqg_batch_t *c, int kernel, int *launches, double *total_ms);
+
+/* device box-QP on `count` independent problems of size n in {2, 8, N_U} (unit tests) */
+int ilqg_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                     const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

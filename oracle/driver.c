@@ -48,6 +48,7 @@ typedef struct drv {
 static drv_t *g_tracing = NULL;
 
 /* ---- --wrap hooks ------------------------------------------------------ */
+#ifndef DRV_NO_WRAP
 int __real_back_pass(tOptSet *o);
 int __real_line_search(tOptSet *o, int iter);
 
@@ -75,6 +76,7 @@ int __wrap_line_search(tOptSet *o, int iter) {
     }
     return r;
 }
+#endif /* DRV_NO_WRAP */
 
 /* ---- problem facts ------------------------------------------------------ */
 void drv_dims(int *out) {
