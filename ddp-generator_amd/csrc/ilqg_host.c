@@ -324,6 +324,10 @@ int ilqg_batch_set_u(ilqg_batch_t *c, const double *u) {
     return ilqg_dev_write(c->dev, ILQG_F_U, u) ? fail(c, "set_u") : 0;
 }
 
+int ilqg_batch_set_x(ilqg_batch_t *c, const double *x) {
+    return ilqg_dev_write(c->dev, ILQG_F_X, x) ? fail(c, "set_x") : 0;
+}
+
 int ilqg_batch_init(ilqg_batch_t *c) {
     if(push_config(c)) return 1;
     if(ilqg_dev_rollout_init(c->dev)) return fail(c, "initial roll-out");

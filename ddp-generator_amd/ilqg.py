@@ -33,15 +33,16 @@ class IlqgError(RuntimeError):
     pass
 
 
-def library_path(problem="carparking", full_ddp=0):
-    return os.path.join(LIBDIR, "libilqg_%s_fd%d_hip.so" % (problem, int(full_ddp)))
+def library_path(problem="carparking", full_ddp=0, strict=False):
+    """strict=True: the -ffp-contract=off build (bit-for-bit CPU parity of the backward pass; tests only)"""
+    return os.path.join(LIBDIR, "libilqg_%s_fd%d_hip%s.so" % (problem, int(full_ddp), "_strict" if strict else ""))
 
 
 _libs = {}
 
 
-def load_library(problem="carparking", full_ddp=0):
-    path = library_path(problem, full_ddp)
+def load_library(problem="carparking", full_ddp=0, strict=False):
+    path = library_path(problem, full_ddp, strict)
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -62,6 +63,7 @@ def load_library(problem="carparking", full_ddp=0):
     lib.ilqg_batch_set_param.argtypes = [v, C.c_char_p, _dp, C.c_int]
     lib.ilqg_batch_set_x0.argtypes = [v, _dp]
     lib.ilqg_batch_set_u.argtypes = [v, _dp]
+    lib.ilqg_batch_set_x.argtypes = [v, _dp]
     for f in ("init", "solve", "sync", "calc_derivs", "line_search", "update"):
         getattr(lib, "ilqg_batch_" + f).argtypes = [v]
     lib.ilqg_batch_iterate.argtypes = [v, C.c_int]
@@ -93,9 +95,9 @@ def load_library(problem="carparking", full_ddp=0):
 class Problem:
     """compile-time facts of one problem library"""
 
-    def __init__(self, problem="carparking", full_ddp=0):
+    def __init__(self, problem="carparking", full_ddp=0, strict=False):
         self.name, self.full_ddp = problem, int(full_ddp)
-        self.lib = load_library(problem, full_ddp)
+        self.lib = load_library(problem, full_ddp, strict)
         d = np.zeros(8, dtype=np.int32)
         self.lib.ilqg_problem_dims(d)
         self.nx, self.nu, _, self.rec_host, self.rec_dev, self.state_dep_limits, self.n_params = [int(x) for x in d[:7]]
@@ -111,8 +113,9 @@ class Problem:
 class BatchSolver:
     """B trajectories of one problem advanced in lock step on one GPU."""
 
-    def __init__(self, problem="carparking", full_ddp=0, batch=1, n_hor=500, device=0, params=None, opts=None):
-        self.problem = Problem(problem, full_ddp)
+    def __init__(self, problem="carparking", full_ddp=0, batch=1, n_hor=500, device=0, params=None, opts=None,
+                 strict=False):
+        self.problem = Problem(problem, full_ddp, strict)
         self.lib = self.problem.lib
         self.B, self.N = int(batch), int(n_hor)
         self.h = self.lib.ilqg_batch_create(int(device), self.B, self.N)
@@ -200,6 +203,14 @@ class BatchSolver:
         self._ck(self.lib.ilqg_batch_get_gains(self.h, l, L))
         return l, L
 
+    def set_x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.B, self.N + 1, self.problem.nx)
+        self._ck(self.lib.ilqg_batch_set_x(self.h, x))
+
+    def set_u(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(self.B, self.N, self.problem.nu)
+        self._ck(self.lib.ilqg_batch_set_u(self.h, u))
+
     def set_gains(self, l, L):
         self._ck(self.lib.ilqg_batch_set_gains(self.h, np.ascontiguousarray(l, dtype=np.float64),
                                                np.ascontiguousarray(L, dtype=np.float64)))
@@ -260,9 +271,9 @@ class BatchSolver:
         return out
 
 
-def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, device=0):
+def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, device=0, strict=False):
     """device box-QP on `count` independent problems (arrays [count, ...]); unit-test entry"""
-    lib = load_library(problem, full_ddp)
+    lib = load_library(problem, full_ddp, strict)
     H = np.ascontiguousarray(H, dtype=np.float64)
     count = H.shape[0]
     t = n * (n + 1) // 2

