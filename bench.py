@@ -47,6 +47,11 @@ ALG_BYTES = {
     "k_rollout[search]": (NX + 2 * NU + NXU) * 8,                                          # 16 dbl read, shared by all alpha
     "k_rollout[winner]": (NX + NU) * 8,                                                     # 6 dbl written (winner only)
 }
+# derivatives evaluated inside the backward kernel: priced against the UNFUSED figure of the two
+# kernels it replaces; what it actually moves is 6 dbl read + 10 written = 128 B
+ALG_BYTES["k_backward[fused derivs]"] = ALG_BYTES["k_derivs"] + ALG_BYTES["k_backward"]
+FUSED_MOVED_BYTES = (NX + NU + NU + NXU) * 8
+ITERATION_BYTES = 1200  # per step and trajectory, SURVEY.md §8(d)
 
 
 def dev_tensor_view(ptr, n, device):
@@ -60,43 +65,35 @@ def dev_tensor_view(ptr, n, device):
 
 
 def cpu_baseline(batch_per_gpu, iters, budget_s=12.0):
-    """CPU checker on a bounded sample of the same workload, all host cores (threads; the C code
-    runs outside the GIL).  Returns the JSON object for `cpu_baseline`."""
-    from concurrent.futures import ThreadPoolExecutor
+    """CPU checker on a bounded sample of the same workload, one pthread per host core, each solving
+    its share of the sample exactly as independent runs of the reference would (oracle/driver.c,
+    drv_solve_many).  Returns the JSON object for `cpu_baseline`."""
     import __graft_entry__ as g
     from oracle.harness import CAR_PARAMS, Driver, lib_path
     synth = g.load_package().synth
     ref = lib_path("ref", full_ddp=0)
     kind = "reference" if os.path.exists(ref) else "port"
     path = ref if kind == "reference" else lib_path("oracle", full_ddp=0)
-    cores = os.cpu_count() or 1
-
-    def run(args):
-        x0, u0 = args
-        d = Driver(path, N_HOR, CAR_PARAMS, dict(max_iter=iters))
-        d.init(x0, u0)
-        d.solve()
-        it = int(d.scalars()["iterations"])
-        d.close()
-        return it
-
-    # calibrate on one trajectory, then size the sample to the time budget
-    x0, u0 = synth.car_batch(1)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    d = Driver(path, N_HOR, CAR_PARAMS, dict(max_iter=iters))
+    # calibrate single-core speed on 8 trajectories, then size the sample to the time budget
+    x0, u0 = synth.car_batch(8)
     t0 = time.perf_counter()
-    run((x0[0], u0[0]))
-    per_traj = max(time.perf_counter() - t0, 1e-4)
-    sample = int(max(cores, min(8192, budget_s / per_traj * cores)))
+    d.solve_many(x0, u0, 1)
+    per_traj = max((time.perf_counter() - t0) / 8, 1e-5)
+    sample = int(max(cores, min(65536, budget_s / per_traj * cores)))
     x0, u0 = synth.car_batch(sample)
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        its = list(ex.map(run, [(x0[i], u0[i]) for i in range(sample)]))
+    cost, its, rc = d.solve_many(x0, u0, cores)
     dt = time.perf_counter() - t0
-    traj_iters_per_s = sum(its) / dt
+    d.close()
+    traj_iters_per_s = float(its.sum()) / dt
     return {
         "value": traj_iters_per_s / batch_per_gpu,  # batched iterations/s of a 65 536-trajectory batch
         "unit": "iterations/s (65536-trajectory batch equivalent)",
         "cores": cores,
         "kind": kind,
+        "single_core_ms_per_trajectory_iteration": 1e3 * per_traj / iters,
         "sample": "%d trajectories x %d iterations (same generator, trajectories 0..%d) in %.1f s on %d threads; "
                   "%.0f trajectory-iterations/s" % (sample, iters, sample - 1, dt, cores, traj_iters_per_s),
     }
@@ -110,7 +107,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
     ap.add_argument("--full-ddp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--resweep", type=int, default=1)
+    ap.add_argument("--resweep", type=int, default=-1, help="-1: library default (off without multipliers)")
+    ap.add_argument("--fuse-derivs", type=int, default=1)
+    ap.add_argument("--ls-split", type=int, default=3)
     args = ap.parse_args()
 
     import torch
@@ -132,7 +131,9 @@ def main():
     B, K, W = args.batch, args.steps, args.warmup
     x0, u0 = synth.car_batch(B, N_HOR, first=rank * B)
     s = ilqg.BatchSolver("carparking", args.full_ddp, batch=B, n_hor=N_HOR, device=local, params=ilqg.CAR_PARAMS,
-                         opts=dict(max_iter=max(K, W) + 1, resweep=args.resweep))
+                         opts=dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_split=args.ls_split))
+    if args.resweep >= 0:
+        s.set_option("resweep", args.resweep)
     s.init(x0, u0)
     if W > 0:
         s.iterate(W)
@@ -163,7 +164,6 @@ def main():
 
     times = s.kernel_times()
     active = s.active()
-    status = s.ints("status")
     cost = s.scalar("cost")
 
     if rank == 0:
@@ -173,7 +173,7 @@ def main():
         avg_ms = total_ms / n_launch
         alg_bytes = ALG_BYTES[dominant] * N_HOR * B
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        iter_bytes = sum(ALG_BYTES.values()) * N_HOR * B  # 1 200 B per step and trajectory
+        iter_bytes = ITERATION_BYTES * N_HOR * B
         out = {
             "metric": "iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)",
             "value": K / dt,
@@ -191,10 +191,12 @@ def main():
                                    "first %d iterations after the initial roll-out" % (B, world, args.full_ddp, K),
                        "batch_per_gpu": B, "n_hor": N_HOR, "n_x": NX, "n_u": NU, "full_ddp": args.full_ddp,
                        "mapping": "one lane per trajectory (64 trajectories per wavefront)",
+                       "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split, "resweep": args.resweep,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_launch},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_launch,
+                         "note": "achieved = algorithmic bytes (SURVEY 8(d), unfused figures) / HIP-event time"},
             "iteration_roofline": {"algorithmic_bytes_per_iteration": iter_bytes,
                                    "achieved_GBs": iter_bytes * (K / dt) / 1e9 / world * 1.0,
                                    "frac_of_peak": iter_bytes * (K / dt) / world / 1e9 / HBM_PEAK_GBS},

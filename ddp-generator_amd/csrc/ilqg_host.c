@@ -42,7 +42,7 @@ struct ilqg_batch {
     int device, B, N;
     tOptSet opt;                     /* option holder, filled through setOptParam() */
     double alpha_store[ILQG_MAX_ALPHA];
-    int resweep;
+    int resweep, fuse_derivs, ls_split;
     double **p;                      /* owned copies of the problem parameters */
     int params_pushed;
     char err[512];
@@ -231,7 +231,12 @@ ilqg_batch_t *ilqg_batch_create(int device, int batch, int n_hor) {
     c->device = device;
     c->B = batch;
     c->N = n_hor;
-    c->resweep = 1;
+    /* the cost-only sweep after an accepted step (iLQG.c:338) only changes the cost when multipliers or
+     * penalty weights changed; a problem without multipliers (empty structs in the generated header)
+     * gets bit-identical costs from it, so it is skipped unless asked for */
+    c->resweep = (sizeof(multipliersEl_t) > 0 || sizeof(multipliersFin_t) > 0) ? 1 : 0;
+    c->fuse_derivs = 1;
+    c->ls_split = 3;
     standard_parameters(&c->opt);
     if(ilqg_dev_create(&c->dev, device, batch, n_hor)) {
         snprintf(g_create_err, sizeof(g_create_err), "ilqg_batch_create: %s", ilqg_dev_error());
@@ -257,6 +262,17 @@ int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value
     if(strcmp(name, "resweep") == 0) {
         if(n != 1) return fail_msg(c, err_scalar);
         c->resweep = value[0] != 0.0;
+        return 0;
+    }
+    if(strcmp(name, "ls_split") == 0) {
+        if(n != 1) return fail_msg(c, err_scalar);
+        if(value[0] < 0.0) return fail_msg(c, err_pos);
+        c->ls_split = (int)value[0];
+        return 0;
+    }
+    if(strcmp(name, "fuse_derivs") == 0) {
+        if(n != 1) return fail_msg(c, err_scalar);
+        c->fuse_derivs = value[0] != 0.0;
         return 0;
     }
     if(strcmp(name, "alpha") == 0) {
@@ -305,6 +321,8 @@ static int push_config(ilqg_batch_t *c) {
     d.w_pen_max_l = o->w_pen_max_l; d.w_pen_max_f = o->w_pen_max_f;
     d.w_pen_fact1 = o->w_pen_fact1; d.w_pen_fact2 = o->w_pen_fact2;
     d.resweep = c->resweep;
+    d.fuse_derivs = c->fuse_derivs;
+    d.ls_split = c->ls_split;
     if(ilqg_dev_set_opts(c->dev, &d)) return fail(c, "options");
     if(!c->params_pushed) {
         int sizes[64];
@@ -360,9 +378,9 @@ int ilqg_batch_calc_derivs(ilqg_batch_t *c) {
     return ilqg_dev_derivs(c->dev) ? fail(c, "calc_derivs") : 0;
 }
 
-int ilqg_batch_back_pass(ilqg_batch_t *c, int single_sweep) {
+int ilqg_batch_back_pass(ilqg_batch_t *c, int mode) {
     if(push_config(c)) return 1;
-    return ilqg_dev_backward(c->dev, single_sweep) ? fail(c, "back_pass") : 0;
+    return ilqg_dev_backward(c->dev, mode) ? fail(c, "back_pass") : 0;
 }
 
 int ilqg_batch_line_search(ilqg_batch_t *c) {

@@ -77,6 +77,9 @@ struct DevPtrs {
     double *f[ILQG_F_COUNT];
     int *i[ILQG_I_COUNT];
     int *derivs_failed;
+    int *pending;        // trajectories that go to the second line-search stage
+    int *n_pending;      // their count (read by the second stage)
+    int *n_pending_next; // counter the first-stage selection appends with (same word as n_pending)
     double **p;
     int B, Bp, N;
 };
@@ -244,10 +247,122 @@ __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double la
     return failed;
 }
 
-__global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t O, int single_sweep) {
+// The same sweep with the derivative record of each step evaluated on the fly from the stored
+// (x_k, u_k) by the generated callbacks instead of being read from HBM: per step 6 doubles are
+// read and 10 written, instead of 57 + 10 (and k_derivs' 61 are not moved at all).  The values
+// are the ones k_derivs would have stored (same callbacks, same inputs).
+// Returns 0 ok, 1 box-QP failed, 2 NaN/Inf in the derivatives (iLQG.c:247-249).
+__device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, const ilqg_dev_opts_t &O, int b, double lambda,
+                                                    double &dV0, double &dV1, double &g_norm) {
+    const size_t Bp = P.Bp;
+    const int N = P.N;
+    tOptSet o;
+    make_optset(o, P, O);
+    tOptSet o1 = o;
+    o1.n_hor = 1;
+
+    double Vx[NX], Vxx[SXX], l[NU], K[NXU];
+    {
+        trajFin_t fin;
+        init_final(&fin, &o);
+#pragma unroll
+        for(int i = 0; i < NX; i++) fin.x[i] = P.f[ILQG_F_X][((size_t)N * NX + i) * Bp + b];
+        int ok = calcFVariableAux(&fin, nullptr, &o);
+        ok &= calcFAuxDeriv(&fin, nullptr, &o);
+        ok &= bp_derivsF(&fin, N, o.p);
+        if(!ok) return 2;
+#pragma unroll
+        for(int i = 0; i < NX; i++) Vx[i] = fin.cx[i];
+#pragma unroll
+        for(int i = 0; i < SXX; i++) Vxx[i] = fin.cxx[i];
+    }
+#pragma unroll
+    for(int i = 0; i < NU; i++) l[i] = 0.0;
+    dV0 = 0.0;
+    dV1 = 0.0;
+    double gsum = 0.0;
+
+    trajEl_t t;
+    init_running(&t, &o1);  // constant entries of the record (iLQG_func.tem:312-347)
+    double xk[NX], uk[NU];
+#pragma unroll
+    for(int i = 0; i < NX; i++) xk[i] = P.f[ILQG_F_X][((size_t)(N - 1) * NX + i) * Bp + b];
+#pragma unroll
+    for(int i = 0; i < NU; i++) uk[i] = P.f[ILQG_F_U][((size_t)(N - 1) * NU + i) * Bp + b];
+    int result = 0;
+    for(int k = N - 1; k >= 0; k--) {
+        double xn[NX], un[NU];
+        if(k > 0) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) xn[i] = P.f[ILQG_F_X][((size_t)(k - 1) * NX + i) * Bp + b];
+#pragma unroll
+            for(int i = 0; i < NU; i++) un[i] = P.f[ILQG_F_U][((size_t)(k - 1) * NU + i) * Bp + b];
+        }
+#pragma unroll
+        for(int i = 0; i < NX; i++) t.x[i] = xk[i];
+#pragma unroll
+        for(int i = 0; i < NU; i++) t.u[i] = uk[i];
+        int ok = calcXVariableAux(&t, nullptr, k, &o);
+        ok &= calcXUVariableAux(&t, nullptr, k, &o);
+        ok &= calcLAuxDeriv(&t, nullptr, k, &o);
+        ok &= bp_derivsL(&t, k, o.p);
+        limitsU(&t, k, o.p, N);
+        if(!ok) {
+            result = 2;
+            break;
+        }
+        double cur[REC];
+#define GETF(off, arr, cnt) _Pragma("unroll") for(int i = 0; i < (cnt); i++) cur[(off) + i] = (arr)[i];
+        GETF(RL::CX, t.cx, NX)
+        GETF(RL::CXX, t.cxx, SXX)
+        GETF(RL::CU, t.cu, NU)
+        GETF(RL::CUU, t.cuu, SUU)
+        GETF(RL::CXU, t.cxu, NXU)
+        GETF(RL::FX, t.fx, NX * NX)
+        GETF(RL::FU, t.fu, NXU)
+        GETF(RL::LOWER, t.lower, NU)
+        GETF(RL::UPPER, t.upper, NU)
+#if FULL_DDP
+        GETF(RL::FXX, t.fxx, NX * SXX)
+        GETF(RL::FUU, t.fuu, NX * SUU)
+        GETF(RL::FXU, t.fxu, NX * NXU)
+#endif
+        if(HX) {
+            GETF(RL::LSIGN, t.lower_sign, NU)
+            GETF(RL::USIGN, t.upper_sign, NU)
+            GETF(RL::LHX, t.lower_hx, NXU)
+            GETF(RL::UHX, t.upper_hx, NXU)
+        }
+#undef GETF
+        const int rc = back_step<NX, NU, FULL, HX>(cur, uk, Vx, Vxx, l, K, lambda, O.regType, dV0, dV1, gsum);
+        if(rc < 1) {
+            result = 1;
+            break;
+        }
+        double *lo = P.f[ILQG_F_LG] + (size_t)k * NU * Bp + b;
+#pragma unroll
+        for(int i = 0; i < NU; i++) lo[(size_t)i * Bp] = l[i];
+        double *ko = P.f[ILQG_F_KG] + (size_t)k * NXU * Bp + b;
+#pragma unroll
+        for(int i = 0; i < NXU; i++) ko[(size_t)i * Bp] = K[i];
+#pragma unroll
+        for(int i = 0; i < NX; i++) xk[i] = xn[i];
+#pragma unroll
+        for(int i = 0; i < NU; i++) uk[i] = un[i];
+    }
+    if(!result) g_norm = gsum / ((double)(N - 1));
+    return result;
+}
+
+// mode: 0 = records from HBM, lambda retry loop and gradient test (iLQG.c:261-303)
+//       1 = records from HBM, ONE sweep (the drop-in back_pass(): the caller owns the retry loop)
+//       2 = as 0 with the derivatives evaluated on the fly (k_derivs is not needed)
+template <int mode>
+__global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t O) {
     const int b = blockIdx.x * WAVE + threadIdx.x;
     if(b >= P.B) return;
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
+    const int single_sweep = (mode == 1);
     P.i[ILQG_I_NEED_DERIVS][b] = 0;
     if(P.derivs_failed[b]) {  // iLQG.c:247-249
         P.i[ILQG_I_STATUS][b] = ILQG_ST_DERIVS_FAILED;
@@ -257,9 +372,12 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
     double dV0 = 0.0, dV1 = 0.0, g_norm = P.f[ILQG_F_GNORM][b];
     int calls = 0, rc;
     for(;;) {
-        rc = backward_sweep(P, b, lambda, O.regType, dV0, dV1, g_norm);
+        if(mode == 2)
+            rc = backward_sweep_fused(P, O, b, lambda, dV0, dV1, g_norm);
+        else
+            rc = backward_sweep(P, b, lambda, O.regType, dV0, dV1, g_norm);
         calls++;
-        if(single_sweep || !rc) break;
+        if(single_sweep || rc != 1) break;
         // raise the regularisation and retry (iLQG.c:271-274)
         const double t1 = dlambda * O.lambdaFactor;
         dlambda = (t1 > O.lambdaFactor) ? t1 : O.lambdaFactor;
@@ -268,7 +386,9 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
         if(lambda > O.lambdaMax) break;
     }
     if(!single_sweep) {
-        if(rc) {
+        if(rc == 2) {
+            P.i[ILQG_I_STATUS][b] = ILQG_ST_DERIVS_FAILED;
+        } else if(rc) {
             P.i[ILQG_I_STATUS][b] = ILQG_ST_NO_DESCENT;
         } else if(g_norm < O.tolGrad && lambda < 1e-5) {  // iLQG.c:297-303
             const double t1 = dlambda / O.lambdaFactor, t2 = 1.0 / O.lambdaFactor;
@@ -289,19 +409,47 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
 // ---------------------------------------------------------------------------
 // forward_pass: one lane per (trajectory, step size)
 // ---------------------------------------------------------------------------
-enum { ROLL_INIT = 0, ROLL_SEARCH = 1, ROLL_WINNER = 2, ROLL_COST = 3 };
+enum { ROLL_INIT = 0, ROLL_SEARCH = 1, ROLL_WINNER = 2, ROLL_COST = 3, ROLL_SEARCH_LIST = 4 };
 
-// `mode` is a run-time argument on purpose: the search pass and the winner pass
+// nominal data of one step (what forward_pass reads of the nominal trajectory, iLQG_func.tem:145-155)
+struct NomStep {
+    double x[NX], u[NU], l[NU], K[NXU];
+};
+
+__device__ __forceinline__ void load_nominal(NomStep &s, const DevPtrs &P, int k, int b, bool gains) {
+    const size_t Bp = P.Bp;
+#pragma unroll
+    for(int i = 0; i < NX; i++) s.x[i] = P.f[ILQG_F_X][((size_t)k * NX + i) * Bp + b];
+#pragma unroll
+    for(int i = 0; i < NU; i++) s.u[i] = P.f[ILQG_F_U][((size_t)k * NU + i) * Bp + b];
+    if(gains) {
+#pragma unroll
+        for(int i = 0; i < NU; i++) s.l[i] = P.f[ILQG_F_LG][((size_t)k * NU + i) * Bp + b];
+#pragma unroll
+        for(int i = 0; i < NXU; i++) s.K[i] = P.f[ILQG_F_KG][((size_t)k * NXU + i) * Bp + b];
+    }
+}
+
+// `mode` is a run-time argument on purpose: the search passes and the winner pass
 // must execute the same machine code so that the re-rolled winner reproduces
 // the cost the selection was based on, bit for bit.
-__global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, int mode) {
-    const int b = blockIdx.x * WAVE + threadIdx.x;
-    const int ai = blockIdx.y;
+//   ROLL_SEARCH       lane = (trajectory blockIdx.x*64+lane, step size a0 + blockIdx.y)
+//   ROLL_SEARCH_LIST  as ROLL_SEARCH for the trajectories listed in P.pending (second stage)
+//   ROLL_WINNER       lane = trajectory, accepted step size, result stored in place
+//   ROLL_INIT         lane = trajectory, alpha = 0 (initial roll-out, iLQG_mex.c:116), stored
+//   ROLL_COST         lane = trajectory, cost of the stored trajectory (forward_pass cost_only = 1)
+__global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, int mode, int a0) {
+    int b = blockIdx.x * WAVE + threadIdx.x;
+    const int ai = a0 + blockIdx.y;
+    if(mode == ROLL_SEARCH_LIST) {
+        if(b >= *P.n_pending) return;
+        b = P.pending[b];
+    }
     if(b >= P.B) return;
     const size_t Bp = P.Bp;
     const int N = P.N;
     double alpha = 0.0;
-    if(mode == ROLL_SEARCH) {
+    if(mode == ROLL_SEARCH || mode == ROLL_SEARCH_LIST) {
         if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
         alpha = O.alpha[ai];
     } else if(mode == ROLL_WINNER) {
@@ -312,6 +460,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
     }
     const bool cost_only = (mode == ROLL_COST);
     const bool store = (mode == ROLL_INIT || mode == ROLL_WINNER);
+    const bool gains = !cost_only && alpha != 0.0;
 
     tOptSet o;
     make_optset(o, P, O);
@@ -325,38 +474,32 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
     for(int i = 0; i < NX; i++) xc[i] = P.f[ILQG_F_X][(size_t)i * Bp + b];  // x0 (iLQG_func.tem:141-142)
     double csum = 0.0;
     int ok = 1;
+    NomStep cur;
+    load_nominal(cur, P, 0, b, gains);
     for(int k = 0; k < N; k++) {
-        double xn[NX], un[NU];
-#pragma unroll
-        for(int i = 0; i < NX; i++) xn[i] = P.f[ILQG_F_X][((size_t)k * NX + i) * Bp + b];
-#pragma unroll
-        for(int i = 0; i < NU; i++) un[i] = P.f[ILQG_F_U][((size_t)k * NU + i) * Bp + b];
+        NomStep nxt;
+        if(k + 1 < N) load_nominal(nxt, P, k + 1, b, gains);  // in flight while this step computes
         if(cost_only) {
 #pragma unroll
-            for(int i = 0; i < NX; i++) ct.x[i] = xn[i];
+            for(int i = 0; i < NX; i++) ct.x[i] = cur.x[i];
 #pragma unroll
-            for(int i = 0; i < NU; i++) ct.u[i] = un[i];
+            for(int i = 0; i < NU; i++) ct.u[i] = cur.u[i];
         } else {
 #pragma unroll
             for(int i = 0; i < NX; i++) ct.x[i] = xc[i];
             if(alpha) {
                 // u = u_nom + alpha*l + L (x - x_nom), state by state (iLQG_func.tem:146-155)
-                double lk[NU], Kk[NXU];
 #pragma unroll
-                for(int i = 0; i < NU; i++) lk[i] = P.f[ILQG_F_LG][((size_t)k * NU + i) * Bp + b];
-#pragma unroll
-                for(int i = 0; i < NXU; i++) Kk[i] = P.f[ILQG_F_KG][((size_t)k * NXU + i) * Bp + b];
-#pragma unroll
-                for(int j = 0; j < NU; j++) ct.u[j] = un[j] + lk[j] * alpha;
+                for(int j = 0; j < NU; j++) ct.u[j] = cur.u[j] + cur.l[j] * alpha;
 #pragma unroll
                 for(int i = 0; i < NX; i++) {
-                    const double dx = ct.x[i] - xn[i];
+                    const double dx = ct.x[i] - cur.x[i];
 #pragma unroll
-                    for(int j = 0; j < NU; j++) ct.u[j] += Kk[j + i * NU] * dx;
+                    for(int j = 0; j < NU; j++) ct.u[j] += cur.K[j + i * NU] * dx;
                 }
             } else {
 #pragma unroll
-                for(int j = 0; j < NU; j++) ct.u[j] = un[j];
+                for(int j = 0; j < NU; j++) ct.u[j] = cur.u[j];
             }
         }
         if(!calcXVariableAux(&ct, nullptr, k, &o)) { ok = 0; break; }
@@ -378,6 +521,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
 #pragma unroll
             for(int i = 0; i < NX; i++) xc[i] = xnext[i];
         }
+        cur = nxt;
     }
     if(ok) {
         trajFin_t cf;
@@ -400,7 +544,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
         }
     }
 
-    if(mode == ROLL_SEARCH) {
+    if(mode == ROLL_SEARCH || mode == ROLL_SEARCH_LIST) {
         P.f[ILQG_F_ALPHA_COST][(size_t)ai * Bp + b] = csum;
         P.i[ILQG_I_ALPHA_OK][(size_t)ai * Bp + b] = ok;
     } else if(mode == ROLL_WINNER) {
@@ -413,16 +557,26 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
     }
 }
 
-// line_search.c:37-75: the FIRST step size (lowest index) whose forward pass
-// was finite and whose z = dcost/expected exceeds zMin wins
-__global__ void k_select(DevPtrs P, ilqg_dev_opts_t O) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// line_search.c:37-75: the FIRST step size (lowest index) whose forward pass was finite and
+// whose z = dcost/expected exceeds zMin wins.  The scan over the step sizes can be cut in two
+// stages [0,a1) and [a1,n_alpha): a trajectory that finds no acceptable step size in the first
+// stage is appended to P.pending and only those are rolled out for the remaining step sizes.
+// The scan state (last cnew / dcost / expected) is carried between the stages, so the result
+// is exactly that of one scan over all step sizes.
+//   from_list = 0: lane = trajectory, scans [a0,a1); from_list = 1: lane = entry of P.pending
+__global__ void k_select(DevPtrs P, ilqg_dev_opts_t O, int a0, int a1, int from_list) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if(from_list) {
+        if(b >= *P.n_pending) return;
+        b = P.pending[b];
+    }
     if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
     const size_t Bp = P.Bp;
     const double cost = P.f[ILQG_F_COST][b], dV0 = P.f[ILQG_F_DV0][b], dV1 = P.f[ILQG_F_DV1][b];
-    double cnew = 0.0, dcost = P.f[ILQG_F_DCOST][b], expected = P.f[ILQG_F_EXPECTED][b];
+    double cnew = (a0 > 0) ? P.f[ILQG_F_NEW_COST][b] : 0.0;
+    double dcost = P.f[ILQG_F_DCOST][b], expected = P.f[ILQG_F_EXPECTED][b];
     int i, ok = 0;
-    for(i = 0; i < O.n_alpha; i++) {
+    for(i = a0; i < a1; i++) {
         const double a = O.alpha[i];
         ok = P.i[ILQG_I_ALPHA_OK][(size_t)i * Bp + b];
         cnew = P.f[ILQG_F_ALPHA_COST][(size_t)i * Bp + b];
@@ -433,6 +587,7 @@ __global__ void k_select(DevPtrs P, ilqg_dev_opts_t O) {
         if(z > O.zMin) break;
         ok = 0;
     }
+    if(!ok && a1 < O.n_alpha) P.pending[atomicAdd(P.n_pending_next, 1)] = b;  // to the second stage
     P.i[ILQG_I_ALPHA_IDX][b] = i + 1;
     P.i[ILQG_I_ACCEPTED][b] = ok;
     P.f[ILQG_F_NEW_COST][b] = cnew;
@@ -638,7 +793,7 @@ void ilqg_dev_dims(int *out) {
 const char *ilqg_dev_kernel_name(int k) {
     static const char *names[ILQG_K_COUNT] = {"k_derivs", "k_backward", "k_rollout[search]", "k_select",
                                               "k_rollout[winner]", "k_update", "k_rollout[cost]", "k_rollout[init]",
-                                              "k_to_soa/k_to_aos"};
+                                              "k_to_soa/k_to_aos", "k_backward[fused derivs]", "k_rollout[search stage 2]"};
     return (k >= 0 && k < ILQG_K_COUNT) ? names[k] : "?";
 }
 
@@ -685,6 +840,10 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
     HIP_TRY(hipMalloc((void **)&d->P.derivs_failed, d->Bp * sizeof(int)));
     HIP_TRY(hipMemsetAsync(d->P.derivs_failed, 0, d->Bp * sizeof(int), d->stream));
     HIP_TRY(hipMalloc((void **)&d->counter, sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d->P.pending, d->Bp * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d->P.n_pending, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), d->stream));
+    d->P.n_pending_next = d->P.n_pending;
     d->P.p = nullptr;
     HIP_TRY(hipStreamSynchronize(d->stream));
     *out = d;
@@ -703,6 +862,8 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     for(int f = 0; f < ILQG_I_COUNT; f++) hipFree(d->P.i[f]);
     hipFree(d->P.derivs_failed);
     hipFree(d->counter);
+    hipFree(d->P.pending);
+    hipFree(d->P.n_pending);
     for(double *p : d->param_bufs) hipFree(p);
     if(d->P.p) hipFree(d->P.p);
     if(d->staging) hipFree(d->staging);
@@ -823,9 +984,9 @@ int ilqg_dev_reset(ilqg_dev_t *d) {
     return 0;
 }
 
-static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int n_alpha) {
+static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_alpha) {
     Timed t(d, kernel_id);
-    hipLaunchKernelGGL(k_rollout, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE), 0, d->stream, d->P, d->O, mode);
+    hipLaunchKernelGGL(k_rollout, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE), 0, d->stream, d->P, d->O, mode, a0);
     return 0;
 }
 
@@ -833,7 +994,7 @@ int ilqg_dev_rollout_init(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
     HIP_TRY(hipMemsetAsync(d->P.i[ILQG_I_STATUS], 0, d->Bp * sizeof(int), d->stream));
-    launch_rollout(d, ROLL_INIT, ILQG_K_ROLLOUT_INIT, 1);
+    launch_rollout(d, ROLL_INIT, ILQG_K_ROLLOUT_INIT, 0, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -850,11 +1011,22 @@ int ilqg_dev_derivs(ilqg_dev_t *d) {
     return 0;
 }
 
-int ilqg_dev_backward(ilqg_dev_t *d, int single_sweep) {
+int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
     HIP_TRY(hipSetDevice(d->device));
+    if(mode < 0 || mode > 2) {
+        g_err = "ilqg_dev_backward: mode must be 0, 1 or 2";
+        return 1;
+    }
+    if(mode == 2) NEED_PARAMS(d);
     {
-        Timed t(d, ILQG_K_BACKWARD);
-        hipLaunchKernelGGL(k_backward, dim3(d->Bp / WAVE), dim3(WAVE), 0, d->stream, d->P, d->O, single_sweep);
+        Timed t(d, mode == 2 ? ILQG_K_BACKWARD_FUSED : ILQG_K_BACKWARD);
+        const dim3 grid(d->Bp / WAVE), block(WAVE);
+        if(mode == 0)
+            hipLaunchKernelGGL(k_backward<0>, grid, block, 0, d->stream, d->P, d->O);
+        else if(mode == 1)
+            hipLaunchKernelGGL(k_backward<1>, grid, block, 0, d->stream, d->P, d->O);
+        else
+            hipLaunchKernelGGL(k_backward<2>, grid, block, 0, d->stream, d->P, d->O);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -863,10 +1035,20 @@ int ilqg_dev_backward(ilqg_dev_t *d, int single_sweep) {
 int ilqg_dev_search(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
-    launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, d->O.n_alpha);
+    const int A = d->O.n_alpha;
+    const int s1 = (d->O.ls_split > 0 && d->O.ls_split < A) ? d->O.ls_split : A;  // step sizes in stage 1
+    HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), d->stream));
+    launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, 0, s1);
     {
         Timed t(d, ILQG_K_SELECT);
-        hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O);
+        hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O, 0, s1, 0);
+    }
+    if(s1 < A) {
+        // second stage: only the trajectories without an acceptable step size so far.  The grid covers the
+        // worst case; blocks beyond the pending count return at once.
+        launch_rollout(d, ROLL_SEARCH_LIST, ILQG_K_ROLLOUT_SEARCH2, s1, A - s1);
+        Timed t(d, ILQG_K_SELECT);
+        hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O, s1, A, 1);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -875,7 +1057,7 @@ int ilqg_dev_search(ilqg_dev_t *d) {
 int ilqg_dev_winner(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
-    launch_rollout(d, ROLL_WINNER, ILQG_K_ROLLOUT_WINNER, 1);
+    launch_rollout(d, ROLL_WINNER, ILQG_K_ROLLOUT_WINNER, 0, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -887,15 +1069,19 @@ int ilqg_dev_update(ilqg_dev_t *d) {
         Timed t(d, ILQG_K_UPDATE);
         hipLaunchKernelGGL(k_update, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O);
     }
-    if(d->O.resweep) launch_rollout(d, ROLL_COST, ILQG_K_ROLLOUT_COST, 1);
+    if(d->O.resweep) launch_rollout(d, ROLL_COST, ILQG_K_ROLLOUT_COST, 0, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int ilqg_dev_iterate(ilqg_dev_t *d, int n) {
     for(int it = 0; it < n; it++) {
-        if(ilqg_dev_derivs(d)) return 1;
-        if(ilqg_dev_backward(d, 0)) return 1;
+        if(d->O.fuse_derivs) {
+            if(ilqg_dev_backward(d, 2)) return 1;
+        } else {
+            if(ilqg_dev_derivs(d)) return 1;
+            if(ilqg_dev_backward(d, 0)) return 1;
+        }
         if(ilqg_dev_search(d)) return 1;
         if(ilqg_dev_winner(d)) return 1;
         if(ilqg_dev_update(d)) return 1;

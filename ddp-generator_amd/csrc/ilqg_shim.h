@@ -30,6 +30,9 @@ typedef struct {
     int max_iter;
     double w_pen_init_l, w_pen_init_f, w_pen_max_l, w_pen_max_f, w_pen_fact1, w_pen_fact2;
     int resweep; /* 1: repeat the reference's cost-only sweep after an accepted step (iLQG.c:338) */
+    int ls_split; /* step sizes rolled out for every trajectory in the first line-search stage; the rest only
+                   * for trajectories still without an acceptable one (0 or >= n_alpha: single stage) */
+    int fuse_derivs; /* 1: ilqg_dev_iterate evaluates derivatives inside the backward kernel (no records in HBM) */
 } ilqg_dev_opts_t;
 
 /* per-trajectory status of the lock-step solver */
@@ -89,6 +92,8 @@ enum {
     ILQG_K_ROLLOUT_COST,
     ILQG_K_ROLLOUT_INIT,
     ILQG_K_TRANSPOSE,
+    ILQG_K_BACKWARD_FUSED,
+    ILQG_K_ROLLOUT_SEARCH2,
     ILQG_K_COUNT
 };
 
@@ -122,7 +127,9 @@ void *ilqg_dev_stream(ilqg_dev_t *d);
 int ilqg_dev_reset(ilqg_dev_t *d);            /* solver entry state (iLQG.c:226-237) */
 int ilqg_dev_rollout_init(ilqg_dev_t *d);     /* forward_pass(alpha = 0) + swap (iLQG_mex.c:113-120) */
 int ilqg_dev_derivs(ilqg_dev_t *d);           /* calc_derivs for trajectories that need it */
-int ilqg_dev_backward(ilqg_dev_t *d, int single_sweep); /* back_pass; 0: with the lambda retry loop and gradient test */
+/* back_pass.  mode 0: records from HBM + lambda retry loop + gradient test; 1: records from HBM, one
+ * sweep (drop-in back_pass()); 2: as 0 with the derivatives evaluated on the fly (no k_derivs needed) */
+int ilqg_dev_backward(ilqg_dev_t *d, int mode);
 int ilqg_dev_search(ilqg_dev_t *d);           /* all step sizes in parallel + first-acceptable selection */
 int ilqg_dev_winner(ilqg_dev_t *d);           /* re-roll the accepted step size, storing the trajectory */
 int ilqg_dev_update(ilqg_dev_t *d);           /* accept/reject bookkeeping (iLQG.c:311-361) */

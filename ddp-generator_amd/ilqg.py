@@ -177,8 +177,9 @@ class BatchSolver:
     def calc_derivs(self):
         self._ck(self.lib.ilqg_batch_calc_derivs(self.h))
 
-    def back_pass(self, single_sweep=False):
-        self._ck(self.lib.ilqg_batch_back_pass(self.h, 1 if single_sweep else 0))
+    def back_pass(self, single_sweep=False, fused=False):
+        """single_sweep: one sweep on stored records (the drop-in back_pass()); fused: derivatives on the fly"""
+        self._ck(self.lib.ilqg_batch_back_pass(self.h, 1 if single_sweep else (2 if fused else 0)))
 
     def line_search(self):
         self._ck(self.lib.ilqg_batch_line_search(self.h))

@@ -47,8 +47,16 @@ void ilqg_batch_destroy(ilqg_batch_t *c);
 const char *ilqg_batch_error(const ilqg_batch_t *c);
 
 /* options: same keys, validation and messages as the reference's setOptParam
- * (iLQG.c:91-216); additionally "resweep" (0/1, default 1: repeat the
- * reference's cost-only sweep after each accepted step, iLQG.c:338).
+ * (iLQG.c:91-216); additionally
+ *   "resweep"     0/1: repeat the reference's cost-only sweep after each accepted step
+ *                 (iLQG.c:338).  Default 1 for problems with multipliers, 0 otherwise: without
+ *                 multipliers that sweep returns the cost of the accepted roll-out bit for bit.
+ *   "fuse_derivs" 0/1, default 1: ilqg_batch_iterate/solve evaluate the derivatives inside the
+ *                 backward kernel instead of materialising the records in HBM.
+ *   "ls_split"    default 3: step sizes alpha[0..ls_split) are rolled out for every trajectory,
+ *                 the remaining ones only for trajectories that found none acceptable among
+ *                 them; 0 = all step sizes for every trajectory.  The accepted step size is the
+ *                 same either way (first acceptable, line_search.c:37-60).
  * Defaults = standard_parameters() (iLQG.c:57-78). */
 int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value, int n);
 /* problem parameter by name, shared by all trajectories (iLQG_mex.c:70-84) */
@@ -73,7 +81,11 @@ int ilqg_batch_active(ilqg_batch_t *c, int *n_active);
 
 /* single stages, for tests and for callers that interleave their own work */
 int ilqg_batch_calc_derivs(ilqg_batch_t *c);
-int ilqg_batch_back_pass(ilqg_batch_t *c, int single_sweep);
+/* mode 0: derivative records from HBM, with the lambda retry loop and the gradient test (iLQG.c:261-303);
+ *      1: records from HBM, exactly one sweep (what the drop-in back_pass() runs);
+ *      2: as 0, derivatives evaluated inside the kernel from (x,u) (what ilqg_batch_iterate uses when
+ *         option "fuse_derivs" is 1) */
+int ilqg_batch_back_pass(ilqg_batch_t *c, int mode);
 int ilqg_batch_line_search(ilqg_batch_t *c);  /* search + selection + store the winner */
 int ilqg_batch_update(ilqg_batch_t *c);
 

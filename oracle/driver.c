@@ -15,6 +15,7 @@
  * solver code.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -318,4 +319,66 @@ int drv_get_trace(drv_t *d, int cap, double *lambda, double *gnorm, double *dV0,
         bp_calls[i] = d->tr_bp_calls[i];
     }
     return d->n_trace;
+}
+
+/* ---- many independent solves on host threads (CPU baseline of bench.py) ----
+ * Trajectories i = 0..n-1 with x0 [n][N_X], u0 [n][n_hor][N_U]; options and
+ * parameters are taken from `tmpl`.  Static split over `n_threads` threads, each
+ * with its own tOptSet, exactly as independent runs of the reference would be. */
+typedef struct {
+    const drv_t *tmpl;
+    const double *x0, *u0;
+    double *cost;
+    int *iters, *rc;
+    int first, last;
+} many_job_t;
+
+static void *many_worker(void *arg) {
+    many_job_t *j = (many_job_t *)arg;
+    const drv_t *t = j->tmpl;
+    int i, q;
+    drv_t *d = drv_create(t->n_hor);
+    for(q = 0; q < n_params; q++) {
+        int sz = paramdesc[q]->size == -1 ? t->n_hor + 1 : paramdesc[q]->size;
+        memcpy(d->pstore[q], t->pstore[q], sizeof(double) * sz);
+    }
+    for(i = j->first; i < j->last; i++) {
+        /* options: copy the scalar settings of the template */
+        d->o.max_iter = t->o.max_iter; d->o.tolFun = t->o.tolFun; d->o.tolGrad = t->o.tolGrad;
+        d->o.lambdaInit = t->o.lambdaInit; d->o.dlambdaInit = t->o.dlambdaInit; d->o.lambdaFactor = t->o.lambdaFactor;
+        d->o.lambdaMax = t->o.lambdaMax; d->o.lambdaMin = t->o.lambdaMin; d->o.regType = t->o.regType;
+        d->o.zMin = t->o.zMin; d->o.debug_level = 0;
+        if(!drv_init(d, j->x0 + (size_t)i * N_X, j->u0 + (size_t)i * t->n_hor * N_U)) {
+            j->rc[i] = -1;
+            continue;
+        }
+        j->rc[i] = iLQG(&d->o);
+        j->cost[i] = d->o.cost;
+        j->iters[i] = d->o.iterations;
+    }
+    drv_destroy(d);
+    return NULL;
+}
+
+int drv_solve_many(drv_t *tmpl, int n, const double *x0, const double *u0, int n_threads, double *cost, int *iters,
+                   int *rc) {
+    int t, per;
+    pthread_t *th;
+    many_job_t *jobs;
+    if(n_threads < 1) n_threads = 1;
+    if(n_threads > n) n_threads = n;
+    th = (pthread_t *)calloc(n_threads, sizeof(pthread_t));
+    jobs = (many_job_t *)calloc(n_threads, sizeof(many_job_t));
+    per = (n + n_threads - 1) / n_threads;
+    for(t = 0; t < n_threads; t++) {
+        jobs[t].tmpl = tmpl; jobs[t].x0 = x0; jobs[t].u0 = u0;
+        jobs[t].cost = cost; jobs[t].iters = iters; jobs[t].rc = rc;
+        jobs[t].first = t * per;
+        jobs[t].last = (t + 1) * per < n ? (t + 1) * per : n;
+        pthread_create(&th[t], NULL, many_worker, &jobs[t]);
+    }
+    for(t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+    return 0;
 }

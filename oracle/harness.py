@@ -64,6 +64,8 @@ def _bind(lib):
     lib.drv_get_scalars.argtypes = [C.c_void_p, _dp]
     lib.drv_get_log_linesearch.argtypes = [C.c_void_p, C.c_int]
     lib.drv_get_trace.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
+    if hasattr(lib, "drv_solve_many"):
+        lib.drv_solve_many.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _ip, _ip]
     return lib
 
 
@@ -139,6 +141,17 @@ class Driver:
 
     def solve(self):
         return self.lib.drv_solve(self.h)
+
+    def solve_many(self, x0, u0, n_threads):
+        """independent solves of len(x0) trajectories on host threads (options/parameters of this driver)"""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        n = x0.shape[0]
+        cost = np.zeros(n)
+        iters = np.zeros(n, dtype=np.int32)
+        rc = np.zeros(n, dtype=np.int32)
+        self.lib.drv_solve_many(self.h, n, x0, u0, int(n_threads), cost, iters, rc)
+        return cost, iters, rc
 
     def traj(self, which=0):
         x = np.zeros((self.N + 1, self.nx))
