@@ -54,16 +54,6 @@ FUSED_MOVED_BYTES = (NX + NU + NU + NXU) * 8
 ITERATION_BYTES = 1200  # per step and trajectory, SURVEY.md §8(d)
 
 
-def dev_tensor_view(ptr, n, device):
-    """zero-copy torch view of `n` doubles of device memory owned by the solver"""
-    import torch
-
-    class _Arr:
-        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
-
-    return torch.as_tensor(_Arr(), device=device)
-
-
 def cpu_baseline(batch_per_gpu, iters, budget_s=12.0):
     """CPU checker on a bounded sample of the same workload, one pthread per host core, each solving
     its share of the sample exactly as independent runs of the reference would (oracle/driver.c,
@@ -118,18 +108,15 @@ def main():
     pkg = g.load_package()
     from ddp_generator_amd import ilqg, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local, world = pkg.dist.env_world()
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        pkg.dist.init("nccl", rank, world, torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     B, K, W = args.batch, args.steps, args.warmup
-    x0, u0 = synth.car_batch(B, N_HOR, first=rank * B)
+    x0, u0 = synth.car_batch(B, N_HOR, first=pkg.dist.shard_first(rank, B))
     s = ilqg.BatchSolver("carparking", args.full_ddp, batch=B, n_hor=N_HOR, device=local, params=ilqg.CAR_PARAMS,
                          opts=dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_split=args.ls_split))
     if args.resweep >= 0:
@@ -139,8 +126,7 @@ def main():
         s.iterate(W)
         s.sync()
         s.init(x0, u0)  # back to iteration 0: the timed window is always iterations 1..K
-    gathered = torch.empty(B * world if rank == 0 else 0, dtype=torch.float64, device=dev)
-    cost_view = dev_tensor_view(s.cost_device_ptr(), B, dev)
+    cost_view = pkg.dist.device_view(s.cost_device_ptr(), B, dev)  # zero-copy view of the solver's cost vector
 
     def barrier():
         if world > 1:
@@ -152,9 +138,8 @@ def main():
     t0 = time.perf_counter()
     s.iterate(K)
     s.sync()
-    if world > 1:  # the single collective of the path: per-trajectory costs to rank 0 over RCCL/xGMI
-        chunks = list(gathered.chunk(world)) if rank == 0 else None
-        dist.gather(cost_view, chunks, dst=0)
+    # the single collective of the path: per-trajectory costs to rank 0 over RCCL/xGMI
+    gathered = pkg.dist.gather_costs(cost_view, rank, world)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -164,7 +149,7 @@ def main():
 
     times = s.kernel_times()
     active = s.active()
-    cost = s.scalar("cost")
+    cost = gathered.cpu().numpy() if world > 1 and rank == 0 else s.scalar("cost")
 
     if rank == 0:
         per_iter = {k: v[1] / max(1, K) for k, v in times.items() if v[0]}

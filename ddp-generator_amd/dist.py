@@ -1,0 +1,49 @@
+"""Multi-GPU plumbing: trajectories are independent, so the batch shards across ranks with no
+data-path collective; the only exchange is ONE gather of the per-trajectory costs
+(BASELINE.json north_star: "a single RCCL gather of costs over xGMI").  One process per GPU,
+`torch.distributed` (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests)."""
+import os
+
+
+def env_world():
+    """(rank, local_rank, world_size) as torch.distributed.run exports them; (0, 0, 1) when absent"""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_first(rank, per_rank):
+    """global index of the first trajectory owned by `rank` (contiguous blocks)"""
+    return rank * per_rank
+
+
+def init(backend, rank, world, device=None):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    kw = {}
+    if device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+
+
+def gather_costs(cost, rank, world, dst=0):
+    """the path's single collective: every rank's cost vector [per_rank] -> rank `dst` [world*per_rank]
+    (None on the other ranks).  `cost` may be a zero-copy view of the solver's device memory."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return cost
+    out = torch.empty(cost.numel() * world, dtype=cost.dtype, device=cost.device) if rank == dst else None
+    chunks = list(out.chunk(world)) if rank == dst else None
+    dist.gather(cost, chunks, dst=dst)
+    return out
+
+
+def device_view(ptr, n, device):
+    """zero-copy torch view of `n` doubles of device memory owned by the solver"""
+    import torch
+
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+    return torch.as_tensor(_Arr(), device=device)

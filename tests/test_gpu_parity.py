@@ -119,7 +119,8 @@ def test_boxqp_random_vs_oracle(ilqg, oracle_built):
 @pytest.mark.parametrize("fd", [0, 1])
 def test_single_pass_golden(ilqg, fd):
     g = golden("car_single_fd%d.npz" % fd)
-    s = ilqg.BatchSolver("carparking", fd, batch=1, n_hor=500, params=ilqg.CAR_PARAMS)
+    # ls_split=0: every step size is rolled out, so all eight per-alpha costs can be compared
+    s = ilqg.BatchSolver("carparking", fd, batch=1, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(ls_split=0))
     s.init(g["x0"][None], g["u0"][None])
     assert close(s.scalar("cost")[0], g["init_cost"])
     assert close(s.x()[0], g["x_nom"]) and close(s.u()[0], g["u_nom"])
