@@ -33,6 +33,24 @@
 // NaN/Inf guards in generated code still `return 0`; their printing is dropped on the device
 #define PRNT(...) ((void)0)
 
+// The generated callbacks call sin(x) and cos(x) of the same few arguments many times, spread
+// over several functions (calcXUVariableAux, ddpf, bp_derivsL, ...).  Once those are inlined
+// into a kernel each call is a separate ~130-instruction body with its own argument
+// reduction, and the optimiser cannot merge bodies that contain branches.  Routing both
+// through ONE non-inlined, side-effect-free sincos keeps them as calls, which global value
+// numbering merges: one evaluation per distinct argument and kernel-loop iteration.
+// Values are those of the device math library (__ocml_sincos_f64).
+#ifndef ILQG_NO_SHARED_SINCOS
+struct ilqg_sc { double s, c; };
+__device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos(double x) {
+    ilqg_sc r;
+    sincos(x, &r.s, &r.c);  // HIP device overload: one argument reduction for both values
+    return r;
+}
+#define sin(x) (ilqg_sincos(x).s)
+#define cos(x) (ilqg_sincos(x).c)
+#endif
+
 extern "C" {
 #pragma clang attribute push(__attribute__((device)), apply_to = function)
 #pragma clang attribute push(__attribute__((internal_linkage)), apply_to = variable(is_global))
@@ -42,6 +60,8 @@ extern "C" {
 #pragma clang attribute pop
 #pragma clang attribute pop
 }
+#undef sin
+#undef cos
 
 #include "ilqg_device.hpp"
 #include "ilqg_shim.h"

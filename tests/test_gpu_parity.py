@@ -71,11 +71,15 @@ def test_boxqp_golden(ilqg, n, strict):
             assert np.array_equal(r["clamp"][j], g["qp_clamp"][i][:n]) and r["n_free"][j] == g["qp_nfree"][i]
             assert np.array_equal(r["x"][j], g["qp_x"][i][:n]), (i, rc)
             continue
-        # product build.  These goldens were picked to hit every exit and span 16 orders of
-        # magnitude in conditioning: the "no further progress" exits 2 and 4 are reached at rounding
-        # resolution and may swap; compare the achieved objective instead of x for them.
-        if rc in (2, 4):
-            assert r["rc"][j] in (2, 4), (i, rc)
+        # product build.  These goldens were picked to hit every exit and span 16 orders of magnitude
+        # in conditioning.  The exits -2 (search direction not a descent direction: sdotg >= 0),
+        # 2 (Armijo step below 1e-22) and 4 (relative improvement below 1e-8) are reached only when the
+        # quantity tested is at rounding resolution, so which one fires depends on the last bit (and
+        # -2 may turn into a regular exit); the strict build above reproduces them exactly.
+        if rc in (-2, 2, 4):
+            assert r["rc"][j] in (-2, 2, 4, 5), (i, rc, r["rc"][j])
+            if rc == -2 or r["rc"][j] == -2:
+                continue
         else:
             assert r["rc"][j] == rc, (i, rc)
             assert np.array_equal(r["clamp"][j], g["qp_clamp"][i][:n]), (i, rc)
