@@ -64,6 +64,7 @@ extern "C" {
 #undef cos
 
 #include "ilqg_device.hpp"
+#include "ilqg_param_layout.h"  // generated at build time from the problem's paramdesc[]
 #include "ilqg_shim.h"
 
 namespace {
@@ -104,8 +105,38 @@ struct DevPtrs {
     int B, Bp, N;
 };
 
-__device__ __forceinline__ void make_optset(tOptSet &o, const DevPtrs &P, const ilqg_dev_opts_t &O) {
-    o.p = P.p;
+// Per-lane snapshot of the problem parameters.  The generated callbacks read parameters as
+// p[i][j] through a `double **`; read from global memory, every such value would have to be
+// re-loaded after each store of the kernel (the compiler cannot prove that the parameter
+// arrays do not alias the output arrays), which costs two dependent memory round trips per
+// use.  Fixed-size parameters are therefore copied once into a private array that the
+// optimiser keeps in registers; per-time-step parameters (size -1) stay in global memory.
+struct ParamValues {
+    double v[ILQG_PTOTAL];
+};
+struct ParamTable {
+    double *ptr[ILQG_NP > 0 ? ILQG_NP : 1];
+};
+__device__ __forceinline__ void load_params(ParamValues &V, ParamTable &T, double **p) {
+    constexpr int sizes[ILQG_NP > 0 ? ILQG_NP : 1] = ILQG_PSIZES;
+    constexpr int offs[ILQG_NP > 0 ? ILQG_NP : 1] = ILQG_POFFSETS;
+#pragma unroll
+    for(int i = 0; i < ILQG_NP; i++) {
+        double *src = p[i];
+        if(sizes[i] > 0) {
+#pragma unroll
+            for(int j = 0; j < sizes[i]; j++) V.v[offs[i] + j] = src[j];
+            T.ptr[i] = &V.v[offs[i]];
+        } else {
+            T.ptr[i] = src;
+        }
+    }
+}
+
+__device__ __forceinline__ void make_optset(tOptSet &o, const DevPtrs &P, const ilqg_dev_opts_t &O,
+                                            ParamValues &V, ParamTable &T) {
+    load_params(V, T, P.p);
+    o.p = T.ptr;
     o.n_hor = P.N;
     o.w_pen_l = O.w_pen_init_l;
     o.w_pen_f = O.w_pen_init_f;
@@ -153,7 +184,9 @@ __global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O) {
     const size_t Bp = P.Bp;
 
     tOptSet o;
-    make_optset(o, P, O);
+    ParamValues pval;
+    ParamTable ptab;
+    make_optset(o, P, O, pval, ptab);
     int ok = 1;
     if(k < P.N) {
         tOptSet o1 = o;
@@ -277,7 +310,9 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, const ilqg
     const size_t Bp = P.Bp;
     const int N = P.N;
     tOptSet o;
-    make_optset(o, P, O);
+    ParamValues pval;
+    ParamTable ptab;
+    make_optset(o, P, O, pval, ptab);
     tOptSet o1 = o;
     o1.n_hor = 1;
 
@@ -483,7 +518,9 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
     const bool gains = !cost_only && alpha != 0.0;
 
     tOptSet o;
-    make_optset(o, P, O);
+    ParamValues pval;
+    ParamTable ptab;
+    make_optset(o, P, O, pval, ptab);
     tOptSet o1 = o;
     o1.n_hor = 1;
     trajEl_t ct;
