@@ -257,6 +257,36 @@ __device__ __forceinline__ void load_record(double *dst, double *udst, const Dev
     for(int i = 0; i < NU; i++) udst[i] = us[(size_t)i * Bp];
 }
 
+// Gains of one step, kept in registers for one more loop iteration: stores are issued at the
+// TOP of the next iteration, ahead of that iteration's prefetch loads.  The memory counter
+// (vmcnt) retires loads and stores in issue order, and the compiler waits with vmcnt(0) at
+// the loop head; with this order everything outstanding at that wait is a full step old.
+struct PendingGains {
+    double l[NU], K[NXU];
+    int k;
+    bool valid;
+};
+
+__device__ __forceinline__ void flush_gains(const DevPtrs &P, int b, const PendingGains &g) {
+    if(!g.valid) return;
+    const size_t Bp = P.Bp;
+    double *lo = P.f[ILQG_F_LG] + (size_t)g.k * NU * Bp + b;
+#pragma unroll
+    for(int i = 0; i < NU; i++) lo[(size_t)i * Bp] = g.l[i];
+    double *ko = P.f[ILQG_F_KG] + (size_t)g.k * NXU * Bp + b;
+#pragma unroll
+    for(int i = 0; i < NXU; i++) ko[(size_t)i * Bp] = g.K[i];
+}
+
+__device__ __forceinline__ void hold_gains(PendingGains &g, const double *l, const double *K, int k) {
+#pragma unroll
+    for(int i = 0; i < NU; i++) g.l[i] = l[i];
+#pragma unroll
+    for(int i = 0; i < NXU; i++) g.K[i] = K[i];
+    g.k = k;
+    g.valid = true;
+}
+
 // one sweep k = N-1..0; returns 0 ok, 1 box-QP failed (back_pass.c:168-171)
 __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double lambda, int regType, double &dV0,
                                               double &dV1, double &g_norm) {
@@ -276,7 +306,11 @@ __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double la
     double cur[REC], ucur[NU];
     load_record(cur, ucur, P, N - 1, b);
     int failed = 0;
+    PendingGains pend;
+    pend.valid = false;
     for(int k = N - 1; k >= 0; k--) {
+        flush_gains(P, b, pend);
+        pend.valid = false;
         double nxt[REC], unxt[NU];
         if(k > 0) load_record(nxt, unxt, P, k - 1, b);  // in flight while this step computes
         // l still holds the solution of step k+1: the warm start (back_pass.c:165-166)
@@ -285,17 +319,13 @@ __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double la
             failed = 1;
             break;
         }
-        double *lo = P.f[ILQG_F_LG] + (size_t)k * NU * Bp + b;
-#pragma unroll
-        for(int i = 0; i < NU; i++) lo[(size_t)i * Bp] = l[i];
-        double *ko = P.f[ILQG_F_KG] + (size_t)k * NXU * Bp + b;
-#pragma unroll
-        for(int i = 0; i < NXU; i++) ko[(size_t)i * Bp] = K[i];
+        hold_gains(pend, l, K, k);
 #pragma unroll
         for(int i = 0; i < REC; i++) cur[i] = nxt[i];
 #pragma unroll
         for(int i = 0; i < NU; i++) ucur[i] = unxt[i];
     }
+    flush_gains(P, b, pend);
     if(!failed) g_norm = gsum / ((double)(N - 1));  // N summands over N-1 (back_pass.c:254)
     return failed;
 }
@@ -345,7 +375,11 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, const ilqg
 #pragma unroll
     for(int i = 0; i < NU; i++) uk[i] = P.f[ILQG_F_U][((size_t)(N - 1) * NU + i) * Bp + b];
     int result = 0;
+    PendingGains pend;
+    pend.valid = false;
     for(int k = N - 1; k >= 0; k--) {
+        flush_gains(P, b, pend);
+        pend.valid = false;
         double xn[NX], un[NU];
         if(k > 0) {
 #pragma unroll
@@ -394,17 +428,13 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, const ilqg
             result = 1;
             break;
         }
-        double *lo = P.f[ILQG_F_LG] + (size_t)k * NU * Bp + b;
-#pragma unroll
-        for(int i = 0; i < NU; i++) lo[(size_t)i * Bp] = l[i];
-        double *ko = P.f[ILQG_F_KG] + (size_t)k * NXU * Bp + b;
-#pragma unroll
-        for(int i = 0; i < NXU; i++) ko[(size_t)i * Bp] = K[i];
+        hold_gains(pend, l, K, k);
 #pragma unroll
         for(int i = 0; i < NX; i++) xk[i] = xn[i];
 #pragma unroll
         for(int i = 0; i < NU; i++) uk[i] = un[i];
     }
+    flush_gains(P, b, pend);
     if(!result) g_norm = gsum / ((double)(N - 1));
     return result;
 }
@@ -533,7 +563,16 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
     int ok = 1;
     NomStep cur;
     load_nominal(cur, P, 0, b, gains);
+    // stores of a step are issued at the top of the next iteration, ahead of its prefetch (see PendingGains)
+    double px[NX], pu[NU];
+    int pk = -1;
     for(int k = 0; k < N; k++) {
+        if(store && pk >= 0) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) P.f[ILQG_F_X][((size_t)pk * NX + i) * Bp + b] = px[i];
+#pragma unroll
+            for(int i = 0; i < NU; i++) P.f[ILQG_F_U][((size_t)pk * NU + i) * Bp + b] = pu[i];
+        }
         NomStep nxt;
         if(k + 1 < N) load_nominal(nxt, P, k + 1, b, gains);  // in flight while this step computes
         if(cost_only) {
@@ -570,15 +609,22 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
         csum += ct.c;
         if(store) {
 #pragma unroll
-            for(int i = 0; i < NX; i++) P.f[ILQG_F_X][((size_t)k * NX + i) * Bp + b] = ct.x[i];
+            for(int i = 0; i < NX; i++) px[i] = ct.x[i];
 #pragma unroll
-            for(int i = 0; i < NU; i++) P.f[ILQG_F_U][((size_t)k * NU + i) * Bp + b] = ct.u[i];
+            for(int i = 0; i < NU; i++) pu[i] = ct.u[i];
+            pk = k;
         }
         if(!cost_only) {
 #pragma unroll
             for(int i = 0; i < NX; i++) xc[i] = xnext[i];
         }
         cur = nxt;
+    }
+    if(store && pk >= 0) {
+#pragma unroll
+        for(int i = 0; i < NX; i++) P.f[ILQG_F_X][((size_t)pk * NX + i) * Bp + b] = px[i];
+#pragma unroll
+        for(int i = 0; i < NU; i++) P.f[ILQG_F_U][((size_t)pk * NU + i) * Bp + b] = pu[i];
     }
     if(ok) {
         trajFin_t cf;
