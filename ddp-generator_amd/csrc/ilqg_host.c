@@ -482,6 +482,10 @@ int ilqg_boxqp_batch(int device, int n, int count, const double *H, const double
     return ilqg_dev_boxqp_batch(device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);
 }
 
+int ilqg_sincos_batch(int device, int n, const double *x, double *s, double *c) {
+    return ilqg_dev_sincos_batch(device, n, x, s, c);
+}
+
 /* =========================================================================
  * drop-in single-trajectory entry points (batch of one on the device)
  * ========================================================================= */

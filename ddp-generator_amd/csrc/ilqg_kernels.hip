@@ -34,18 +34,66 @@
 #define PRNT(...) ((void)0)
 
 // The generated callbacks call sin(x) and cos(x) of the same few arguments many times, spread
-// over several functions (calcXUVariableAux, ddpf, bp_derivsL, ...).  Once those are inlined
-// into a kernel each call is a separate ~130-instruction body with its own argument
-// reduction, and the optimiser cannot merge bodies that contain branches.  Routing both
-// through ONE non-inlined, side-effect-free sincos keeps them as calls, which global value
-// numbering merges: one evaluation per distinct argument and kernel-loop iteration.
-// Values are those of the device math library (__ocml_sincos_f64).
+// over several functions (calcXUVariableAux, ddpf, bp_derivsL, ...).  The device math
+// library's sin/cos contain branches (huge-argument reduction), so once the callbacks are
+// inlined into a kernel every call is a separate ~130-instruction body the optimiser cannot
+// merge; and a non-inlined helper would stall on the function-call ABI's `s_waitcnt vmcnt(0)`.
+// ilqg_sincos below is STRAIGHT-LINE code for |x| < 8e5 (anything larger, NaN and Inf go to
+// the library through a rarely taken branch), so value numbering merges all evaluations of
+// the same argument: one argument reduction + one sine and one cosine polynomial per distinct
+// argument and loop iteration.
+//
+// Algorithm: Cody-Waite reduction with pi/2 split into three 33-bit pieces, always carried to
+// the third piece (the medium-size path of fdlibm's e_rem_pio2.c), then the minimax kernels of
+// fdlibm / FreeBSD msun k_sin.c and k_cos.c on [-pi/4, pi/4] with the reduction tail.  Error
+// below 1 ulp, the same class as the host libm and the device library (tests/test_gpu_parity.py
+// checks it against numpy).
 #ifndef ILQG_NO_SHARED_SINCOS
 struct ilqg_sc { double s, c; };
-__device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos(double x) {
+
+__device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_slow(double x) {
     ilqg_sc r;
-    sincos(x, &r.s, &r.c);  // HIP device overload: one argument reduction for both values
+    sincos(x, &r.s, &r.c);
     return r;
+}
+
+__device__ __forceinline__ static ilqg_sc ilqg_sincos(double x) {
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    // x - fn*(P1 + P2 + P3 + P3t) as y0 + y1; P1, P2, P3 have 33 significant bits each, so the
+    // products fn*Pi are exact for |fn| < 2^20; e1, e2 are the rounding errors of the two subtractions
+    const double a = x - fn * 1.57079632673412561417e+00;
+    const double b = fn * 6.07710050630396597660e-11;
+    const double r1 = a - b;
+    const double e1 = (a - r1) - b;
+    const double c3 = fn * 2.02226624871116645580e-21;
+    const double r2 = r1 - c3;
+    const double e2 = (r1 - r2) - c3;
+    const double w = (fn * 8.47842766036889956997e-32 - e2) - e1;
+    const double y0 = r2 - w;
+    const double y1 = (r2 - y0) - w;
+
+    const double z = y0 * y0;
+    const double zz = z * z;
+    // sine kernel with tail
+    const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * 2.75573137070700676789e-06) +
+                      z * zz * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10);
+    const double v = z * y0;
+    const double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+    // cosine kernel with tail
+    const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
+                      (zz * zz) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+    const double hz = 0.5 * z;
+    const double wc = 1.0 - hz;
+    const double kc = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+
+    const int q = ((int)fn) & 3;
+    ilqg_sc out;
+    out.s = (q & 1) ? kc : ks;
+    out.c = (q & 1) ? ks : kc;
+    if(q == 1 || q == 2) out.c = -out.c;
+    if(q >= 2) out.s = -out.s;
+    if(!(fabs(x) < 8.0e5)) out = ilqg_sincos_slow(x);  // huge arguments, NaN, Inf: device library
+    return out;
 }
 #define sin(x) (ilqg_sincos(x).s)
 #define cos(x) (ilqg_sincos(x).c)
@@ -751,6 +799,19 @@ __global__ void k_count_active(const int *status, int B, int *out) {
     if((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
 }
 
+// unit-test kernel for the shared sincos the generated callbacks are routed through
+__global__ void k_sincos_test(int n, const double *x, double *s, double *c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+#ifndef ILQG_NO_SHARED_SINCOS
+    const ilqg_sc r = ilqg_sincos(x[i]);
+    s[i] = r.s;
+    c[i] = r.c;
+#else
+    sincos(x[i], &s[i], &c[i]);
+#endif
+}
+
 // unit-test kernel for box_qp<M>, one problem per lane
 template <int M>
 __global__ __launch_bounds__(64, 1) void k_boxqp_test(int count, const double *H, const double *g, const double *lower, const double *upper,
@@ -1225,6 +1286,22 @@ int ilqg_dev_get_timing(ilqg_dev_t *d, int kernel, int *launches, double *total_
     if(drain_spans(d)) return 1;
     *launches = d->t_n[kernel];
     *total_ms = d->t_ms[kernel];
+    return 0;
+}
+
+int ilqg_dev_sincos_batch(int device, int n, const double *x, double *s, double *c) {
+    HIP_TRY(hipSetDevice(device));
+    double *dx, *ds, *dc;
+    HIP_TRY(hipMalloc((void **)&dx, n * 8));
+    HIP_TRY(hipMalloc((void **)&ds, n * 8));
+    HIP_TRY(hipMalloc((void **)&dc, n * 8));
+    HIP_TRY(hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_sincos_test, grid1(n, 256), dim3(256), 0, 0, n, dx, ds, dc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(s, ds, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c, dc, n * 8, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(ds); hipFree(dc);
     return 0;
 }
 

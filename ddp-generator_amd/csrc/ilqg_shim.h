@@ -147,6 +147,9 @@ const char *ilqg_dev_kernel_name(int kernel);
 int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
                          const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
 
+/* unit-test entry for the device sincos that the generated callbacks' sin()/cos() are routed through */
+int ilqg_dev_sincos_batch(int device, int n, const double *x, double *s, double *c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,7 @@ def load_library(problem="carparking", full_ddp=0, strict=False):
     lib.ilqg_batch_kernel_name.argtypes = [C.c_int]
     lib.ilqg_batch_get_timing.argtypes = [v, C.c_int, _ip, _dp]
     lib.ilqg_boxqp_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _ip]
+    lib.ilqg_sincos_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
     _libs[path] = lib
     return lib
 
@@ -289,6 +290,16 @@ def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, dev
     if r:
         raise IlqgError("ilqg_boxqp_batch failed")
     return dict(rc=rc, x=x, clamp=clamp, n_free=nfree, invH=invH)
+
+
+def sincos_batch(x, problem="carparking", full_ddp=0, device=0, strict=False):
+    """device sin/cos exactly as the generated callbacks get them; unit-test entry"""
+    lib = load_library(problem, full_ddp, strict)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    if lib.ilqg_sincos_batch(device, x.size, x, s, c):
+        raise IlqgError("ilqg_sincos_batch failed")
+    return s, c
 
 
 # CarParking demo parameters, reference examples/CarParking/testCar.m:2-11

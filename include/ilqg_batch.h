@@ -119,6 +119,9 @@ int ilqg_batch_get_timing(ilqg_batch_t *c, int kernel, int *launches, double *to
 int ilqg_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
                      const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
 
+/* device sin/cos as the generated callbacks see them, on n arguments (unit tests) */
+int ilqg_sincos_batch(int device, int n, const double *x, double *s, double *c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,25 @@ def test_boxqp_golden(ilqg, n, strict):
                 assert np.all(np.abs(r["x"][j] - g["qp_x"][i][:n]) <= 1e-7 * scale), (i, rc)
 
 
+def test_device_sincos_accuracy(ilqg):
+    """the straight-line sincos the callbacks' sin()/cos() are routed through: within 1 ulp of the host
+    libm over small, medium and large arguments, next to multiples of pi/2, and the library fallback
+    beyond 8e5 / for NaN and Inf"""
+    rng = np.random.default_rng(5)
+    parts = [rng.uniform(-s, s, 50000) for s in (1e-3, 1.0, 10.0, 1e3, 7.9e5, 1e12)]
+    k = rng.integers(-500000, 500000, 50000)
+    parts.append(k * (np.pi / 2) * (1 + rng.uniform(-4, 4, 50000) * 2.2e-16))
+    parts.append(np.array([0.0, -0.0, np.pi, np.pi / 2, 355.0, 8.0e5, -8.0e5, 1e300]))
+    x = np.concatenate(parts)
+    s, c = ilqg.sincos_batch(x)
+    for got, want in ((s, np.sin(x)), (c, np.cos(x))):
+        ulp = np.abs(got - want) / np.spacing(np.abs(want))
+        assert ulp.max() <= 2.0, ulp.max()
+        assert np.mean(ulp > 0) < 0.35
+    s, c = ilqg.sincos_batch(np.array([np.nan, np.inf, -np.inf]))
+    assert np.all(np.isnan(s)) and np.all(np.isnan(c))
+
+
 def test_boxqp_random_vs_oracle(ilqg, oracle_built):
     from oracle.harness import Kernels
     K = Kernels(lib_path("oracle"))
