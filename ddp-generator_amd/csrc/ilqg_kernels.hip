@@ -51,7 +51,7 @@
 #ifndef ILQG_NO_SHARED_SINCOS
 struct ilqg_sc { double s, c; };
 
-__device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_slow(double x) {
+__device__ __attribute__((noinline)) static ilqg_sc ilqg_sincos_slow(double x) {
     ilqg_sc r;
     sincos(x, &r.s, &r.c);
     return r;

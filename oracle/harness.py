@@ -28,6 +28,19 @@ CAR_X0 = [1.0, 1.0, 1.5 * np.pi, 0.0]  # testCar.m:16
 CAR_N = 500                              # testCar.m:14
 
 
+# state-dependent-limits test problem (problems/defs/hxtest.py)
+HX_PARAMS = dict(h=[0.05], cu=[0.02, 0.01], cx=[0.5, 0.05, 0.1], cf=[5.0, 1.0, 1.0], lim=[1.0, 0.8, 0.6, 0.7])
+HX_N = 120
+
+
+def hx_inputs(batch=1, first=0):
+    """x0 [batch,3], u0 [batch,HX_N,2]: starts that drive both state-dependent limits active"""
+    rng = np.random.default_rng(20261003 + first)
+    x0 = np.array([-1.5, 0.0, 2.0]) + 0.3 * rng.standard_normal((batch, 3))
+    u0 = 0.3 * rng.standard_normal((batch, HX_N, 2))
+    return x0, u0
+
+
 def lib_path(kind, problem="carparking", full_ddp=0):
     """kind: 'ref' (reference sources) or 'oracle' (CPU restatement)"""
     if kind == "ref":

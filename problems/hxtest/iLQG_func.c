@@ -1,0 +1,525 @@
+/* Problem functions for 'HxTest' emitted by tools/gen_problem.py. Do not edit.
+ * Function set, signatures and evaluation order: reference iLQG_func.tem:40-521. */
+#include "iLQG.h"
+#include "matMult.h"
+
+#define mcond(cond, a, dummy, b) ((cond)? a: b)
+#define sec(x) (1.0/cos(x))
+#define csc(x) (1.0/sin(x))
+
+int n_params= 5;
+
+tParamDesc p_name1= {"cf", 3, 0};
+tParamDesc p_name2= {"cu", 2, 0};
+tParamDesc p_name3= {"cx", 3, 0};
+tParamDesc p_name4= {"h", 1, 0};
+tParamDesc p_name5= {"lim", 4, 0};
+int n_vars= 0;
+
+tParamDesc *paramdesc[]= {&p_name1, &p_name2, &p_name3, &p_name4, &p_name5};
+
+#define aux_e t->e
+#define daux_de_x0 t->de_x0
+#define daux_de_x2 t->de_x2
+#define daux_de_x0x0 t->de_x0x0
+#define daux_de_x0x2 t->de_x0x2
+#define daux_de_x2x2 t->de_x2x2
+
+static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o);
+static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o);
+static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o);
+static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o);
+static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o);
+static int bp_derivsL(trajEl_t *t, int k, double **p);
+static int bp_derivsF(trajFin_t *t, int k, double **p);
+
+static int ddpL(trajEl_t *t, int k, tOptSet *o) {
+    const double *x= t->x;
+    const double *u= t->u;
+    double **p= o->p;
+
+    t->c= (1.0/10.0)*(aux_e*aux_e) + p[1][0]*(u[0]*u[0]) + p[1][1]*(u[1]*u[1]) + p[2][0]*(sqrt((x[0]*x[0]) + 1.0) - 1.0) + p[2][1]*(x[1]*x[1]) + p[2][2]*(x[2]*x[2]);
+    if(isNANorINF(t->c)) { PRNT("    @k %d: t->c in line %d is nan or inf: %g\n", k, __LINE__-1, t->c); return 0; }
+
+    return 1;
+}
+
+static int ddpF(trajFin_t *t, tOptSet *o) {
+    const double *x= t->x;
+    const int k= o->n_hor;
+    double **p= o->p;
+
+    t->c= p[0][0]*(x[0]*x[0]) + p[0][1]*(x[1]*x[1]) + p[0][2]*(x[2]*x[2]);
+    if(isNANorINF(t->c)) { PRNT("    @k %d: t->c in line %d is nan or inf: %g\n", k, __LINE__-1, t->c); return 0; }
+
+    return 1;
+}
+
+static int ddpf(double x_next[], trajEl_t *t, int k, double **p, int N) {
+    const double *x= t->x;
+    const double *u= t->u;
+
+    x_next[0]= p[3][0]*x[1] + x[0];
+    if(isNANorINF(x_next[0])) { PRNT("    @k %d: x_next[0] in line %d is nan or inf: %g\n", k, __LINE__-1, x_next[0]); return 0; }
+    x_next[1]= p[3][0]*(-aux_e*p[4][3] + u[0]) + x[1];
+    if(isNANorINF(x_next[1])) { PRNT("    @k %d: x_next[1] in line %d is nan or inf: %g\n", k, __LINE__-1, x_next[1]); return 0; }
+    x_next[2]= p[3][0]*(u[1] + (1.0/4.0)*x[0]*x[1] - 1.0/2.0*x[2]) + x[2];
+    if(isNANorINF(x_next[2])) { PRNT("    @k %d: x_next[2] in line %d is nan or inf: %g\n", k, __LINE__-1, x_next[2]); return 0; }
+    return 1;
+}
+
+void clampU(double *u, trajEl_t *t, int k, double **p, int N) {
+    double limit;
+    const double *x= t->x;
+
+    // constraint h[1]= a - lim[0] - v/2
+    limit= p[4][0] + (1.0/2.0)*x[1];
+    if(u[0]>limit) u[0]= limit;
+
+    // constraint h[2]= -a - lim[0]
+    limit= -p[4][0];
+    if(u[0]<limit) u[0]= limit;
+
+    // constraint h[3]= -lim[1] + w
+    limit= p[4][1];
+    if(u[1]>limit) u[1]= limit;
+
+    // constraint h[4]= -lim[2] - p**2/5 - w
+    limit= -p[4][2] - 1.0/5.0*(x[0]*x[0]);
+    if(u[1]<limit) u[1]= limit;
+
+}
+
+static void limitsU(trajEl_t *t, int k, double **p, int N) {
+    int i, j;
+    int lower_idx[N_U], upper_idx[N_U], *idx_;
+    double limit;
+    const double *x= t->x;
+    double *hx_, *h_sign;
+
+    for(i= 0; i<N_U; i++) {
+        lower_idx[i]= -1;
+        upper_idx[i]= -1;
+        t->lower[i]= -INF;
+        t->upper[i]= INF;
+    }
+
+    // constraint h[1]= a - lim[0] - v/2
+    limit= p[4][0] + (1.0/2.0)*x[1];
+    if(t->upper[0]>limit) { t->upper[0]= limit; upper_idx[0]= 0; }
+
+    // constraint h[2]= -a - lim[0]
+    limit= -p[4][0];
+    if(t->lower[0]<limit) { t->lower[0]= limit; lower_idx[0]= 1; }
+
+    // constraint h[3]= -lim[1] + w
+    limit= p[4][1];
+    if(t->upper[1]>limit) { t->upper[1]= limit; upper_idx[1]= 2; }
+
+    // constraint h[4]= -lim[2] - p**2/5 - w
+    limit= -p[4][2] - 1.0/5.0*(x[0]*x[0]);
+    if(t->lower[1]<limit) { t->lower[1]= limit; lower_idx[1]= 3; }
+
+    for(i= 0; i<N_U; i++) {
+        t->lower[i]-= t->u[i];
+        t->upper[i]-= t->u[i];
+    }
+
+    for(j= 0; j<2; j++) {
+        if(j==0) {
+            idx_= lower_idx;
+            hx_= t->lower_hx;
+            h_sign= t->lower_sign;
+        } else {
+            idx_= upper_idx;
+            hx_= t->upper_hx;
+            h_sign= t->upper_sign;
+        }
+        for(i= 0; i<N_U; i++, hx_+= N_X, h_sign++) {
+            switch(idx_[i]) {
+                case -1:
+                    h_sign[0]= 0.0;
+                    break;
+                case 0:
+                    hx_[0]= 0.0;
+                    hx_[1]= -1.0/2.0;
+                    hx_[2]= 0.0;
+                    h_sign[0]= 1.0;
+                    break;
+                case 1:
+                    hx_[0]= 0.0;
+                    hx_[1]= 0.0;
+                    hx_[2]= 0.0;
+                    h_sign[0]= -1.0;
+                    break;
+                case 2:
+                    hx_[0]= 0.0;
+                    hx_[1]= 0.0;
+                    hx_[2]= 0.0;
+                    h_sign[0]= 1.0;
+                    break;
+                case 3:
+                    hx_[0]= -2.0/5.0*x[0];
+                    hx_[1]= 0.0;
+                    hx_[2]= 0.0;
+                    h_sign[0]= -1.0;
+                    break;
+            }
+        }
+    }
+}
+
+int forward_pass(traj_t *c, tOptSet *o, double alpha, double *csum, int cost_only) {
+    int i, k, j;
+    double dx;
+    double *x0= o->x0;
+    int N= o->n_hor;
+    double **params= o->p;
+
+    trajEl_t *t= o->nominal->t;
+    trajEl_t *ct= c->t;
+    trajFin_t *cf= &c->f;
+
+    multipliersEl_t *m= o->multipliers.t;
+    multipliersFin_t *mf= &o->multipliers.f;
+
+    double *x_next;
+
+    csum[0]= 0.0;
+
+    if(!cost_only)
+        for(i= 0; i<N_X; i++) ct->x[i]= x0[i];
+
+    for(k= 0; k<N; k++, t++, ct++, m++) {
+        if(!cost_only) {
+            if(alpha) {
+                /* u = u_nom + alpha*l + L*(x - x_nom), accumulated state by state */
+                for(j= 0; j<N_U; j++)
+                    ct->u[j]= t->u[j] + t->l[j]*alpha;
+                for(i= 0; i<N_X; i++) {
+                    dx= ct->x[i] - t->x[i];
+                    for(j= 0; j<N_U; j++)
+                        ct->u[j]+= t->L[MAT_IDX(j, i, N_U)]*dx;
+                }
+            } else {
+                for(j= 0; j<N_U; j++)
+                    ct->u[j]= t->u[j];
+            }
+        }
+        if(!calcXVariableAux(ct, m, k, o)) return 0;
+
+        if(!cost_only)
+            clampU(ct->u, ct, k, params, N);
+        if(!calcXUVariableAux(ct, m, k, o)) return 0;
+
+        if(!cost_only) {
+            x_next= (k>=N-1)? cf->x: (ct+1)->x;
+            if(!ddpf(x_next, ct, k, params, N)) return 0;
+        }
+
+        if(!ddpL(ct, k, o)) return 0;
+        csum[0]+= ct->c;
+    }
+
+    if(!calcFVariableAux(cf, mf, o)) return 0;
+    if(!ddpF(cf, o)) return 0;
+    csum[0]+= cf->c;
+
+    return 1;
+}
+
+int calc_derivs(tOptSet *o) {
+    int k;
+    int N= o->n_hor;
+
+    trajEl_t *t= o->nominal->t + N - 1;
+    trajFin_t *f= &o->nominal->f;
+
+    multipliersEl_t *m= o->multipliers.t + N - 1;
+    multipliersFin_t *mf= &o->multipliers.f;
+
+    if(!calcFAuxDeriv(f, mf, o)) return 0;
+    if(!bp_derivsF(f, N, o->p)) return 0;
+
+    for(k= N-1; k>=0; k--, t--, m--) {
+        if(!calcLAuxDeriv(t, m, k, o)) return 0;
+        if(!bp_derivsL(t, k, o->p)) return 0;
+
+        limitsU(t, k, o->p, N);
+    }
+    return 1;
+}
+
+static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
+    const double *x= t->x;
+    double **p= o->p;
+    const double w_pen= o->w_pen_l;
+
+    aux_e= exp(-1.0/4.0*(x[2]*x[2]))*sin(x[0]);
+    if(isNANorINF(aux_e)) { PRNT("    @k %d: aux_e in line %d is nan or inf: %g\n", k, __LINE__-1, aux_e); return 0; }
+    return 1;
+}
+
+static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
+    const double *x= t->x;
+    const double *u= t->u;
+    double **p= o->p;
+    const double w_pen= o->w_pen_l;
+
+    return 1;
+}
+
+static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
+    const double *x= t->x;
+    double **p= o->p;
+    const double w_pen= o->w_pen_f;
+    const int k= o->n_hor;
+
+    return 1;
+}
+
+static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
+    const double *x= t->x;
+    const double *u= t->u;
+    const double w_pen= o->w_pen_l;
+    double **p= o->p;
+
+    daux_de_x0= exp(-1.0/4.0*(x[2]*x[2]))*cos(x[0]);
+    if(isNANorINF(daux_de_x0)) { PRNT("    @k %d: daux_de_x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_de_x0); return 0; }
+    daux_de_x2= -1.0/2.0*x[2]*exp(-1.0/4.0*(x[2]*x[2]))*sin(x[0]);
+    if(isNANorINF(daux_de_x2)) { PRNT("    @k %d: daux_de_x2 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_de_x2); return 0; }
+    daux_de_x0x0= -exp(-1.0/4.0*(x[2]*x[2]))*sin(x[0]);
+    if(isNANorINF(daux_de_x0x0)) { PRNT("    @k %d: daux_de_x0x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_de_x0x0); return 0; }
+    daux_de_x0x2= -1.0/2.0*x[2]*exp(-1.0/4.0*(x[2]*x[2]))*cos(x[0]);
+    if(isNANorINF(daux_de_x0x2)) { PRNT("    @k %d: daux_de_x0x2 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_de_x0x2); return 0; }
+    daux_de_x2x2= (1.0/4.0)*((x[2]*x[2]) - 2.0)*exp(-1.0/4.0*(x[2]*x[2]))*sin(x[0]);
+    if(isNANorINF(daux_de_x2x2)) { PRNT("    @k %d: daux_de_x2x2 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_de_x2x2); return 0; }
+#if FULL_DDP
+#endif
+    return 1;
+}
+
+static int bp_derivsL(trajEl_t *t, int k, double **p) {
+    const double *x= t->x;
+    const double *u= t->u;
+
+// derivatives of f
+    t->fx[1]= -daux_de_x0*p[3][0]*p[4][3];
+    if(isNANorINF(t->fx[1])) { PRNT("    @k %d: t->fx[1] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fx[1]); return 0; }
+    t->fx[2]= (1.0/4.0)*p[3][0]*x[1];
+    if(isNANorINF(t->fx[2])) { PRNT("    @k %d: t->fx[2] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fx[2]); return 0; }
+    t->fx[5]= (1.0/4.0)*p[3][0]*x[0];
+    if(isNANorINF(t->fx[5])) { PRNT("    @k %d: t->fx[5] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fx[5]); return 0; }
+    t->fx[7]= -daux_de_x2*p[3][0]*p[4][3];
+    if(isNANorINF(t->fx[7])) { PRNT("    @k %d: t->fx[7] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fx[7]); return 0; }
+
+
+#if FULL_DDP
+    t->fxx[6]= -daux_de_x0x0*p[3][0]*p[4][3];
+    if(isNANorINF(t->fxx[6])) { PRNT("    @k %d: t->fxx[6] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fxx[6]); return 0; }
+    t->fxx[9]= -daux_de_x0x2*p[3][0]*p[4][3];
+    if(isNANorINF(t->fxx[9])) { PRNT("    @k %d: t->fxx[9] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fxx[9]); return 0; }
+    t->fxx[11]= -daux_de_x2x2*p[3][0]*p[4][3];
+    if(isNANorINF(t->fxx[11])) { PRNT("    @k %d: t->fxx[11] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fxx[11]); return 0; }
+
+#endif
+
+// derivatives of L
+    t->cx[0]= (1.0/5.0)*aux_e*daux_de_x0 + p[2][0]*x[0]/sqrt((x[0]*x[0]) + 1.0);
+    if(isNANorINF(t->cx[0])) { PRNT("    @k %d: t->cx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[0]); return 0; }
+    t->cx[1]= 2.0*p[2][1]*x[1];
+    if(isNANorINF(t->cx[1])) { PRNT("    @k %d: t->cx[1] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[1]); return 0; }
+    t->cx[2]= (1.0/5.0)*aux_e*daux_de_x2 + 2.0*p[2][2]*x[2];
+    if(isNANorINF(t->cx[2])) { PRNT("    @k %d: t->cx[2] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[2]); return 0; }
+
+    t->cxx[0]= (1.0/5.0)*aux_e*daux_de_x0x0 + (1.0/5.0)*(daux_de_x0*daux_de_x0) - p[2][0]*(x[0]*x[0])/(((x[0]*x[0]) + 1.0)*sqrt((x[0]*x[0]) + 1.0)) + p[2][0]/sqrt((x[0]*x[0]) + 1.0);
+    if(isNANorINF(t->cxx[0])) { PRNT("    @k %d: t->cxx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxx[0]); return 0; }
+    t->cxx[3]= (1.0/5.0)*aux_e*daux_de_x0x2 + (1.0/5.0)*daux_de_x0*daux_de_x2;
+    if(isNANorINF(t->cxx[3])) { PRNT("    @k %d: t->cxx[3] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxx[3]); return 0; }
+    t->cxx[5]= (1.0/5.0)*aux_e*daux_de_x2x2 + (1.0/5.0)*(daux_de_x2*daux_de_x2) + 2.0*p[2][2];
+    if(isNANorINF(t->cxx[5])) { PRNT("    @k %d: t->cxx[5] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxx[5]); return 0; }
+
+    t->cu[0]= 2.0*p[1][0]*u[0];
+    if(isNANorINF(t->cu[0])) { PRNT("    @k %d: t->cu[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cu[0]); return 0; }
+    t->cu[1]= 2.0*p[1][1]*u[1];
+    if(isNANorINF(t->cu[1])) { PRNT("    @k %d: t->cu[1] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cu[1]); return 0; }
+
+
+
+    return 1;
+}
+
+static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
+    const double *x= t->x;
+    const double w_pen= o->w_pen_f;
+    double **p= o->p;
+    const int k= o->n_hor;
+
+    return 1;
+}
+
+static int bp_derivsF(trajFin_t *t, int k, double **p) {
+    const double *x= t->x;
+
+    t->cx[0]= 2.0*p[0][0]*x[0];
+    if(isNANorINF(t->cx[0])) { PRNT("    @k %d: t->cx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[0]); return 0; }
+    t->cx[1]= 2.0*p[0][1]*x[1];
+    if(isNANorINF(t->cx[1])) { PRNT("    @k %d: t->cx[1] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[1]); return 0; }
+    t->cx[2]= 2.0*p[0][2]*x[2];
+    if(isNANorINF(t->cx[2])) { PRNT("    @k %d: t->cx[2] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[2]); return 0; }
+
+    return 1;
+}
+
+static int init_running(trajEl_t *t, tOptSet *o) {
+    int k;
+    double **p= o->p;
+
+    for(k= 0; k<o->n_hor; k++, t++) {
+#if FULL_DDP
+#endif
+
+// derivatives of L
+
+        t->cxx[1]= 0.0;
+        t->cxx[2]= 2.0*p[2][1];
+        if(isNANorINF(t->cxx[2])) { PRNT("    @k %d: t->cxx[2] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxx[2]); return 0; }
+        t->cxx[4]= 0.0;
+
+
+        t->cuu[0]= 2.0*p[1][0];
+        if(isNANorINF(t->cuu[0])) { PRNT("    @k %d: t->cuu[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cuu[0]); return 0; }
+        t->cuu[1]= 0.0;
+        t->cuu[2]= 2.0*p[1][1];
+        if(isNANorINF(t->cuu[2])) { PRNT("    @k %d: t->cuu[2] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cuu[2]); return 0; }
+
+        t->cxu[0]= 0.0;
+        t->cxu[1]= 0.0;
+        t->cxu[2]= 0.0;
+        t->cxu[3]= 0.0;
+        t->cxu[4]= 0.0;
+        t->cxu[5]= 0.0;
+
+// derivatives of f
+        t->fx[0]= 1.0;
+        t->fx[3]= p[3][0];
+        if(isNANorINF(t->fx[3])) { PRNT("    @k %d: t->fx[3] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fx[3]); return 0; }
+        t->fx[4]= 1.0;
+        t->fx[6]= 0.0;
+        t->fx[8]= 1.0 - 1.0/2.0*p[3][0];
+        if(isNANorINF(t->fx[8])) { PRNT("    @k %d: t->fx[8] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fx[8]); return 0; }
+
+        t->fu[0]= 0.0;
+        t->fu[1]= p[3][0];
+        if(isNANorINF(t->fu[1])) { PRNT("    @k %d: t->fu[1] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fu[1]); return 0; }
+        t->fu[2]= 0.0;
+        t->fu[3]= 0.0;
+        t->fu[4]= 0.0;
+        t->fu[5]= p[3][0];
+        if(isNANorINF(t->fu[5])) { PRNT("    @k %d: t->fu[5] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fu[5]); return 0; }
+
+#if FULL_DDP
+        t->fxx[0]= 0.0;
+        t->fxx[1]= 0.0;
+        t->fxx[2]= 0.0;
+        t->fxx[3]= 0.0;
+        t->fxx[4]= 0.0;
+        t->fxx[5]= 0.0;
+        t->fxx[7]= 0.0;
+        t->fxx[8]= 0.0;
+        t->fxx[10]= 0.0;
+        t->fxx[12]= 0.0;
+        t->fxx[13]= (1.0/4.0)*p[3][0];
+        if(isNANorINF(t->fxx[13])) { PRNT("    @k %d: t->fxx[13] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fxx[13]); return 0; }
+        t->fxx[14]= 0.0;
+        t->fxx[15]= 0.0;
+        t->fxx[16]= 0.0;
+        t->fxx[17]= 0.0;
+
+        { int i_; for(i_= 0; i_<N_X*sizeofQuu; i_++) t->fuu[i_]= 0.0; }
+
+        { int i_; for(i_= 0; i_<N_X*sizeofQxu; i_++) t->fxu[i_]= 0.0; }
+
+#endif
+    }
+
+    return 1;
+}
+
+static int init_final(trajFin_t *t, tOptSet *o) {
+    double **p= o->p;
+    const int k= o->n_hor;
+
+
+    t->cxx[0]= 2.0*p[0][0];
+    if(isNANorINF(t->cxx[0])) { PRNT("    @k %d: t->cxx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxx[0]); return 0; }
+    t->cxx[1]= 0.0;
+    t->cxx[2]= 2.0*p[0][1];
+    if(isNANorINF(t->cxx[2])) { PRNT("    @k %d: t->cxx[2] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxx[2]); return 0; }
+    t->cxx[3]= 0.0;
+    t->cxx[4]= 0.0;
+    t->cxx[5]= 2.0*p[0][2];
+    if(isNANorINF(t->cxx[5])) { PRNT("    @k %d: t->cxx[5] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxx[5]); return 0; }
+
+    return 1;
+}
+
+int init_trajectory(traj_t *t, tOptSet *o) {
+    if(!init_running(t->t, o)) return 0;
+    if(!init_final(&t->f, o)) return 0;
+
+    return 1;
+}
+
+static int init_multipliers_running(tOptSet *o) {
+    return 1;
+}
+
+static int init_multipliers_final(tOptSet *o) {
+    return 1;
+}
+
+int init_multipliers(tOptSet *o) {
+    if(!init_multipliers_running(o)) return 0;
+    if(!init_multipliers_final(o)) return 0;
+
+    return 1;
+}
+
+int init_opt(tOptSet *o) {
+    int i;
+
+    for(i= 0; i<NUMBER_OF_THREADS+1; i++)
+        if(!init_trajectory(&o->trajectories[i], o)) return 0;
+
+    o->nominal= &o->trajectories[0];
+    for(i= 1; i<NUMBER_OF_THREADS+1; i++)
+        o->candidates[i-1]= &o->trajectories[i];
+
+    if(!init_multipliers(o)) return 0;
+
+    return 1;
+}
+
+static int update_multipliers_running(tOptSet *o, int init) {
+    return 1;
+}
+
+static int update_multipliers_final(tOptSet *o, int init) {
+    return 1;
+}
+
+int update_multipliers(tOptSet *o, int init) {
+    if(!update_multipliers_running(o, init)) return 0;
+    if(!update_multipliers_final(o, init)) return 0;
+
+    return 1;
+}
+
+int get_g_size() {
+    return(0);
+}
+
+int calcG(double g[], trajEl_t *t, int k, double **p) {
+    return(1);
+}

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from oracle.harness import CAR_PARAMS, Driver, Kernels, lib_path
+from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, Driver, Kernels, lib_path
 
 
 @pytest.fixture(scope="module")
@@ -106,6 +106,46 @@ def test_full_solves(oracle_built, fd):
         n = int(g["tr_len"][b])
         for k in ("lambda", "cost", "new_cost", "alpha_idx", "bp_calls"):
             assert np.array_equal(t[k], g["tr_" + k][b][:n]), k
+        d.close()
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_state_dependent_limits_problem(oracle_built, fd):
+    """problems/hxtest: the constraint-gradient terms of the gains (back_pass.c:186-199)"""
+    g = golden("hxtest_fd%d.npz" % fd)
+    for tag, pre in (("", 0), ("it3_", 3)):
+        d = Driver(lib_path("oracle", "hxtest", fd), HX_N, HX_PARAMS, dict(max_iter=max(pre, 1)))
+        assert d.init(g["x0"][0], g["u0"][0]) == 1
+        if pre:
+            d.solve()
+        assert d.calc_derivs() == 1
+        rec, fin = d.derivs()
+        assert np.array_equal(rec, g[tag + "rec"]) and np.array_equal(fin, g[tag + "fin"])
+        d.set_lambda(float(g[tag + "lam"]))
+        assert d.back_pass() == int(g[tag + "bp_rc"])
+        l, L = d.gains()
+        assert np.array_equal(l, g[tag + "l"]) and np.array_equal(L, g[tag + "L"])
+        assert d.line_search(0) == int(g[tag + "ls_accept"]) and d.log_linesearch(0) == int(g[tag + "ls_index"])
+        xc, uc = d.traj(1)
+        assert np.array_equal(xc, g[tag + "x_cand"]) and np.array_equal(uc, g[tag + "u_cand"])
+        d.close()
+    for b in range(len(g["solve_rc"])):
+        d = Driver(lib_path("oracle", "hxtest", fd), HX_N, HX_PARAMS, dict(max_iter=100))
+        assert d.init(g["x0"][b], g["u0"][b]) == 1
+        assert d.solve() == g["solve_rc"][b]
+        assert d.scalars()["cost"] == g["solve_cost"][b] and np.array_equal(d.traj(0)[0], g["solve_x"][b])
+        d.close()
+
+
+def test_regtype2_literal(oracle_built):
+    g = golden("car_regtype2.npz")
+    for fd in (0, 1):
+        d = Driver(lib_path("oracle", full_ddp=fd), 500, CAR_PARAMS, dict(regType=2))
+        assert d.init(g["x0"], g["u0"]) == 1 and d.calc_derivs() == 1
+        d.set_lambda(1.0)
+        assert d.back_pass() == int(g["fd%d_rc" % fd])
+        l, L = d.gains()
+        assert np.array_equal(l, g["fd%d_l" % fd]) and np.array_equal(L, g["fd%d_L" % fd])
         d.close()
 
 
