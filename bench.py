@@ -99,7 +99,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resweep", type=int, default=-1, help="-1: library default (off without multipliers)")
     ap.add_argument("--fuse-derivs", type=int, default=1)
-    ap.add_argument("--ls-split", type=int, default=3)
+    ap.add_argument("--ls-split", type=int, default=4)
+    ap.add_argument("--no-unfused", action="store_true", help="skip the secondary run with materialised derivative records")
     args = ap.parse_args()
 
     import torch
@@ -149,6 +150,22 @@ def main():
 
     times = s.kernel_times()
     active = s.active()
+
+    # secondary, untimed for `value`: the same iterations with the derivative records materialised in
+    # HBM (k_derivs + k_backward<0>), the two kernels the HBM roofline of SURVEY 8(d) was written for
+    unfused = {}
+    if rank == 0 and args.fuse_derivs and not args.no_unfused:
+        s.set_option("fuse_derivs", 0)
+        s.init(x0, u0)
+        s.timing(True)
+        s.iterate(5)
+        s.sync()
+        for kname, (n, ms) in s.kernel_times().items():
+            if n and kname in ("k_derivs", "k_backward"):
+                b_alg = ALG_BYTES[kname] * N_HOR * B
+                unfused[kname] = {"avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": b_alg,
+                                  "achieved_GBs": b_alg / (ms / n * 1e-3) / 1e9,
+                                  "frac_of_peak": b_alg / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS}
     cost = gathered.cpu().numpy() if world > 1 and rank == 0 else s.scalar("cost")
 
     if rank == 0:
@@ -158,6 +175,13 @@ def main():
         avg_ms = total_ms / n_launch
         alg_bytes = ALG_BYTES[dominant] * N_HOR * B
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (tools/collect_traffic.sh), if committed
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and B == 65536:
+            key = dominant
+            if dominant == "k_rollout[search]":  # the profiler sees one k_rollout; its modes differ by grid size
+                key = "k_rollout[grid=%d]" % (B * (args.ls_split if 0 < args.ls_split < 8 else 8))
+            traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
         iter_bytes = ITERATION_BYTES * N_HOR * B
         out = {
             "metric": "iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)",
@@ -179,9 +203,16 @@ def main():
                        "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split, "resweep": args.resweep,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_launch,
-                         "note": "achieved = algorithmic bytes (SURVEY 8(d), unfused figures) / HIP-event time"},
+                         "note": "achieved = ALGORITHMIC bytes of SURVEY 8(d) / HIP-event time. For "
+                                 "k_backward[fused derivs] that is the figure of the two kernels it replaces "
+                                 "(k_derivs 488 B + k_backward 536 B per step and trajectory), as SURVEY 8(d) "
+                                 "prescribes; the fused kernel itself moves 128 B per step and trajectory and is "
+                                 "bound by fp64 VALU issue, so frac can exceed 1. See unfused_kernels for the "
+                                 "HBM-bound kernels measured in the same run.",
+                         "moved_bytes_per_launch": (FUSED_MOVED_BYTES * N_HOR * B) if "fused" in dominant else alg_bytes},
+            "unfused_kernels": unfused,
             "iteration_roofline": {"algorithmic_bytes_per_iteration": iter_bytes,
                                    "achieved_GBs": iter_bytes * (K / dt) / 1e9 / world * 1.0,
                                    "frac_of_peak": iter_bytes * (K / dt) / world / 1e9 / HBM_PEAK_GBS},

@@ -14,9 +14,20 @@ def short(n):
     n = n.replace("(anonymous namespace)::", "")
     return n.split("(")[0]
 
+KERNEL_LABELS = {  # (kernel, grid) -> bench.py's kernel label; rollout modes differ by grid size only
+    "k_derivs": "k_derivs",
+    "void k_backward<0>": "k_backward",
+    "void k_backward<2>": "k_backward[fused derivs]",
+}
+
+
 def main():
+    argv = sys.argv[1:]
+    traffic_json = None
+    if argv and argv[0] == "--traffic-json":
+        traffic_json, argv = argv[1], argv[2:]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for d in sys.argv[1:]:
+    for d in argv:
         per_dispatch = collections.defaultdict(dict)
         for r in load(d):
             key = (r["Dispatch_Id"], short(r["Kernel_Name"]), r.get("Grid_Size", ""))
@@ -31,6 +42,26 @@ def main():
         for c in sorted(acc[(k, g)]):
             v = acc[(k, g)][c]
             print("    %-32s n=%3d mean=%.6g" % (c, len(v), sum(v) / len(v)))
+
+    if traffic_json:
+        import json
+        out = {}
+        for (k, g), cs in acc.items():
+            if "FETCH_SIZE" not in cs and "WRITE_SIZE" not in cs:
+                continue
+            label = KERNEL_LABELS.get(k)
+            if k == "k_rollout":
+                label = "k_rollout[grid=%s]" % g
+            if not label:
+                continue
+            f = sum(cs.get("FETCH_SIZE", [0])) / max(1, len(cs.get("FETCH_SIZE", [0])))
+            w = sum(cs.get("WRITE_SIZE", [0])) / max(1, len(cs.get("WRITE_SIZE", [0])))
+            out[label] = {"fetch_size_KiB_raw": f, "write_size_KiB_raw": w,
+                          "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024,
+                          "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), both KiB -> bytes"}
+        json.dump(out, open(traffic_json, "w"), indent=1, sort_keys=True)
+        print("wrote", traffic_json)
+
 
 if __name__ == "__main__":
     main()
