@@ -127,7 +127,8 @@ def main():
         s.iterate(W)
         s.sync()
         s.init(x0, u0)  # back to iteration 0: the timed window is always iterations 1..K
-    cost_view = pkg.dist.device_view(s.cost_device_ptr(), B, dev)  # zero-copy view of the solver's cost vector
+    # zero-copy view of the solver's cost vector (device memory) for the collective
+    cost_view = pkg.dist.device_view(s.cost_device_ptr(), B, dev, fallback=lambda: s.scalar("cost"))
 
     def barrier():
         if world > 1:
@@ -150,6 +151,7 @@ def main():
 
     times = s.kernel_times()
     active = s.active()
+    cost = gathered.cpu().numpy() if world > 1 and rank == 0 else s.scalar("cost")
 
     # secondary, untimed for `value`: the same iterations with the derivative records materialised in
     # HBM (k_derivs + k_backward<0>), the two kernels the HBM roofline of SURVEY 8(d) was written for
@@ -166,8 +168,6 @@ def main():
                 unfused[kname] = {"avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": b_alg,
                                   "achieved_GBs": b_alg / (ms / n * 1e-3) / 1e9,
                                   "frac_of_peak": b_alg / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    cost = gathered.cpu().numpy() if world > 1 and rank == 0 else s.scalar("cost")
-
     if rank == 0:
         per_iter = {k: v[1] / max(1, K) for k, v in times.items() if v[0]}
         dominant = max((k for k in per_iter if k in ALG_BYTES), key=lambda k: per_iter[k])

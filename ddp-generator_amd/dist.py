@@ -39,11 +39,17 @@ def gather_costs(cost, rank, world, dst=0):
     return out
 
 
-def device_view(ptr, n, device):
-    """zero-copy torch view of `n` doubles of device memory owned by the solver"""
+def device_view(ptr, n, device, fallback=None):
+    """zero-copy torch view of `n` doubles of device memory owned by the solver; if the array-interface
+    import is unavailable in this torch build, `fallback()` must return the values as a numpy array"""
     import torch
 
     class _Arr:
         __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
-    return torch.as_tensor(_Arr(), device=device)
+    try:
+        return torch.as_tensor(_Arr(), device=device)
+    except Exception:
+        if fallback is None:
+            raise
+        return torch.from_numpy(fallback()).to(device)
