@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resweep", type=int, default=-1, help="-1: library default (off without multipliers)")
     ap.add_argument("--fuse-derivs", type=int, default=1)
-    ap.add_argument("--ls-split", type=int, default=4)
+    ap.add_argument("--ls-split", type=int, default=5)
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary run with materialised derivative records")
     args = ap.parse_args()
 

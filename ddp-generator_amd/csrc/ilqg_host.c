@@ -236,7 +236,7 @@ ilqg_batch_t *ilqg_batch_create(int device, int batch, int n_hor) {
      * gets bit-identical costs from it, so it is skipped unless asked for */
     c->resweep = (sizeof(multipliersEl_t) > 0 || sizeof(multipliersFin_t) > 0) ? 1 : 0;
     c->fuse_derivs = 1;
-    c->ls_split = 3;
+    c->ls_split = 5;
     standard_parameters(&c->opt);
     if(ilqg_dev_create(&c->dev, device, batch, n_hor)) {
         snprintf(g_create_err, sizeof(g_create_err), "ilqg_batch_create: %s", ilqg_dev_error());

@@ -53,6 +53,7 @@ class Problem:
         self.L = None
         self.F = None
         self.h = []       # input constraints h_i < 0
+        self.fast = False # True: skip sympy.simplify (large generated problems)
 
     def states(self, names):
         self.x = list(sp.symbols(names, real=True))
@@ -174,10 +175,15 @@ class Deriver:
         if key in self.dcache:
             return self.dcache[key]
         # canonical name: aux name + sorted variable tags
-        d = sp.simplify(self.total_diff(self.defs[s], z))
+        d = self.total_diff(self.defs[s], z)
+        if not self.prob.fast:
+            d = sp.simplify(d)
         if d == 0:
             self.dcache[key] = sp.Integer(0)
             return self.dcache[key]
+        if d.is_number:  # constant derivative: use the number itself, no struct member
+            self.dcache[key] = d
+            return d
         root, tags = self._root_tags(s)
         tags = sorted(tags + [self.base_name[z]])
         name = "d%s_%s" % (root, "".join(tags))
@@ -264,7 +270,7 @@ class Emitter:
             raise ValueError("F may not depend on u")  # genenerator_main.mac:127-128
         self.Fx = [td(p.F, x[r]) for r in range(n)]
         self.Fxx = [[td(self.Fx[r], x[c]) for c in range(n)] for r in range(n)]
-        simp = lambda e: sp.simplify(e) if e != 0 else e
+        simp = (lambda e: e) if p.fast else (lambda e: sp.simplify(e) if e != 0 else e)
         for name in ("fx", "fu", "Lxx", "Luu", "Lxu", "Fxx"):
             setattr(self, name, [[simp(e) for e in row] for row in getattr(self, name)])
         for name in ("fxx", "fuu", "fxu"):
@@ -281,7 +287,7 @@ class Emitter:
                 raise ValueError("constraint %d must depend on one input with coefficient +-1" % (i + 1))
             j = nz[0]
             sign = int(hu[j])
-            lim = sp.simplify(h - sign * u[j])
+            lim = sp.expand(h - sign * u[j])
             if sign > 0:
                 lim = -lim
             hx = [td(h, xx) for xx in x]
