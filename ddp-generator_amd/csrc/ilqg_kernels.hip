@@ -95,8 +95,17 @@ __device__ __forceinline__ static ilqg_sc ilqg_sincos(double x) {
     if(!(fabs(x) < 8.0e5)) out = ilqg_sincos_slow(x);  // huge arguments, NaN, Inf: device library
     return out;
 }
+#if defined(ILQG_SINCOS_CALL)
+// Large generated files (thousands of sin/cos call sites, e.g. the tensors of an n = 16 problem): keep
+// every evaluation a CALL to a side-effect-free function.  Calls with equal arguments are merged before
+// anything is inlined, which also keeps the compile time bounded.
+__device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_call(double x) { return ilqg_sincos(x); }
+#define sin(x) (ilqg_sincos_call(x).s)
+#define cos(x) (ilqg_sincos_call(x).c)
+#else
 #define sin(x) (ilqg_sincos(x).s)
 #define cos(x) (ilqg_sincos(x).c)
+#endif
 #endif
 
 extern "C" {
@@ -111,7 +120,15 @@ extern "C" {
 #undef sin
 #undef cos
 
+// Mapping: lane mapping (one lane per trajectory, everything in registers) for small problems,
+// wave mapping (one wavefront per trajectory, matrices in LDS) when a lane's registers cannot
+// hold the matrices.  -DILQG_WAVE_MAP=1 forces the wave mapping for a small problem.
+#ifndef ILQG_WAVE_MAP
+#define ILQG_WAVE_MAP (N_X > 8)
+#endif
+
 #include "ilqg_device.hpp"
+#include "ilqg_wave.hpp"
 #include "ilqg_param_layout.h"  // generated at build time from the problem's paramdesc[]
 #include "ilqg_shim.h"
 
@@ -130,6 +147,7 @@ using RL = RecLayout<NX, NU, FULL, HX>;
 constexpr int SXX = RL::SXX, SUU = RL::SUU, NXU = RL::NXU, REC = RL::SIZE, REC_HOST = RL::HOST_SIZE;
 constexpr int FIN = NX + SXX;
 constexpr int WAVE = 64;
+constexpr bool WAVE_MAP = ILQG_WAVE_MAP;
 
 thread_local std::string g_err;
 
@@ -149,9 +167,16 @@ struct DevPtrs {
     int *pending;        // trajectories that go to the second line-search stage
     int *n_pending;      // their count (read by the second stage)
     int *n_pending_next; // counter the first-stage selection appends with (same word as n_pending)
+    trajEl_t *work;      // wave mapping: derivative records of one chunk of trajectories, [chunk][N]
     double **p;
     int B, Bp, N;
 };
+
+// element (step k, component i of W) of trajectory b in a per-step field of `steps` steps:
+// lane mapping [k][i][b] (batch-innermost), wave mapping [b][k][i] (trajectory-major)
+__device__ __forceinline__ size_t ix(const DevPtrs &P, int W, int steps, int k, int i, int b) {
+    return WAVE_MAP ? ((size_t)b * steps + k) * W + i : ((size_t)k * W + i) * (size_t)P.Bp + b;
+}
 
 // Per-lane snapshot of the problem parameters.  The generated callbacks read parameters as
 // p[i][j] through a `double **`; read from global memory, every such value would have to be
@@ -220,6 +245,7 @@ __global__ void k_to_aos(const double *__restrict__ soa, double *__restrict__ ao
     aos[i] = (fcol < wd) ? soa[((size_t)k * wd + fcol) * Bp + b] : 0.0;
 }
 
+#if !ILQG_WAVE_MAP
 // ---------------------------------------------------------------------------
 // calc_derivs: one lane per (trajectory, time step); step N is the final record
 // ---------------------------------------------------------------------------
@@ -539,6 +565,142 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
     P.i[ILQG_I_BP_RC][b] = rc;
 }
 
+#else  // ILQG_WAVE_MAP
+// ---------------------------------------------------------------------------
+// wave mapping: calc_derivs straight into the device trajEl_t records, one lane per
+// (trajectory of the chunk, time step); step N is the final record
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, int chunk_first, int chunk_count,
+                                                    int init_consts) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int bw = (int)(tid / (P.N + 1));
+    const int k = (int)(tid % (P.N + 1));
+    const int b = chunk_first + bw;
+    if(bw >= chunk_count || b >= P.B) return;
+    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
+    tOptSet o;
+    ParamValues pval;
+    ParamTable ptab;
+    make_optset(o, P, O, pval, ptab);
+    int ok = 1;
+    if(k < P.N) {
+        trajEl_t *t = P.work + (size_t)bw * P.N + k;
+        if(init_consts) {  // constant entries, once per buffer (init_opt, iLQG_func.tem:402-415)
+            tOptSet o1 = o;
+            o1.n_hor = 1;
+            init_running(t, &o1);
+        }
+        for(int i = 0; i < NX; i++) t->x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, k, i, b)];
+        for(int i = 0; i < NU; i++) t->u[i] = P.f[ILQG_F_U][ix(P, NU, P.N, k, i, b)];
+        ok &= calcXVariableAux(t, nullptr, k, &o);
+        ok &= calcXUVariableAux(t, nullptr, k, &o);
+        ok &= calcLAuxDeriv(t, nullptr, k, &o);
+        ok &= bp_derivsL(t, k, o.p);
+        limitsU(t, k, o.p, P.N);
+    } else {
+        trajFin_t fin;
+        init_final(&fin, &o);
+        for(int i = 0; i < NX; i++) fin.x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, P.N, i, b)];
+        ok &= calcFVariableAux(&fin, nullptr, &o);
+        ok &= calcFAuxDeriv(&fin, nullptr, &o);
+        ok &= bp_derivsF(&fin, P.N, o.p);
+        double *out = P.f[ILQG_F_FIN] + (size_t)b * FIN;
+        for(int i = 0; i < NX; i++) out[i] = fin.cx[i];
+        for(int i = 0; i < SXX; i++) out[NX + i] = fin.cxx[i];
+    }
+    if(!ok) P.derivs_failed[b] = 1;
+}
+
+// one sweep of one trajectory on one wave; returns 0 ok, 1 box-QP failed (wave-uniform)
+__device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const DevPtrs &P, int b, int bw, double lambda,
+                                                   int regType, double &dV0, double &dV1, double &g_norm) {
+    const int lane = threadIdx.x & 63;
+    const int N = P.N;
+    const double *fin = P.f[ILQG_F_FIN] + (size_t)b * FIN;
+    for(int i = lane; i < NX; i += 64) S.Vx[i] = fin[i];
+    for(int i = lane; i < SXX; i += 64) S.Vxx[i] = fin[NX + i];
+    for(int i = lane; i < NU; i += 64) S.l[i] = 0.0;
+    __syncthreads();
+    dV0 = 0.0;
+    dV1 = 0.0;
+    double gsum = 0.0;
+    for(int k = N - 1; k >= 0; k--) {
+        const trajEl_t *t = P.work + (size_t)bw * N + k;
+        StepFields<NX, NU> F;
+        F.cx = t->cx; F.cxx = t->cxx; F.cu = t->cu; F.cuu = t->cuu; F.cxu = t->cxu;
+        F.fx = t->fx; F.fu = t->fu; F.lower = t->lower; F.upper = t->upper;
+#if FULL_DDP
+        F.fxx = t->fxx; F.fuu = t->fuu; F.fxu = t->fxu;
+#else
+        F.fxx = F.fuu = F.fxu = nullptr;
+#endif
+        F.lower_sign = t->lower_sign; F.upper_sign = t->upper_sign;
+        F.lower_hx = t->lower_hx; F.upper_hx = t->upper_hx;
+        F.u = P.f[ILQG_F_U] + ix(P, NU, N, k, 0, b);
+        const int rc = back_step_wave<NX, NU, FULL, HX>(S, F, P.f[ILQG_F_LG] + ix(P, NU, N, k, 0, b),
+                                                        P.f[ILQG_F_KG] + ix(P, NXU, N, k, 0, b), lambda, regType, dV0,
+                                                        dV1, gsum);
+        if(rc < 1) return 1;
+    }
+    g_norm = gsum / ((double)(N - 1));
+    return 0;
+}
+
+// back_pass + retry loop, one wavefront (= one block) per trajectory of the chunk.  single_sweep: 1 = the
+// drop-in back_pass() (caller owns the retry loop)
+__global__ __launch_bounds__(64, 1) void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep,
+                                                         int chunk_first, int chunk_count) {
+    __shared__ WaveLds<NX, NU> S;
+    const int bw = blockIdx.x;
+    const int b = chunk_first + bw;
+    const int lane = threadIdx.x & 63;
+    if(bw >= chunk_count || b >= P.B) return;
+    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
+    if(P.derivs_failed[b]) {
+        if(lane == 0) {
+            P.i[ILQG_I_NEED_DERIVS][b] = 0;
+            P.i[ILQG_I_STATUS][b] = ILQG_ST_DERIVS_FAILED;
+        }
+        return;
+    }
+    double lambda = P.f[ILQG_F_LAMBDA][b], dlambda = P.f[ILQG_F_DLAMBDA][b];
+    double dV0 = 0.0, dV1 = 0.0, g_norm = P.f[ILQG_F_GNORM][b];
+    int calls = 0, rc, status = ILQG_ST_ACTIVE;
+    for(;;) {
+        rc = backward_sweep_wave(S, P, b, bw, lambda, O.regType, dV0, dV1, g_norm);
+        calls++;
+        if(single_sweep || rc != 1) break;
+        const double t1 = dlambda * O.lambdaFactor;
+        dlambda = (t1 > O.lambdaFactor) ? t1 : O.lambdaFactor;
+        const double t2 = lambda * dlambda;
+        lambda = (t2 > O.lambdaMin) ? t2 : O.lambdaMin;
+        if(lambda > O.lambdaMax) break;
+        __syncthreads();
+    }
+    if(!single_sweep) {
+        if(rc) {
+            status = ILQG_ST_NO_DESCENT;
+        } else if(g_norm < O.tolGrad && lambda < 1e-5) {
+            const double t1 = dlambda / O.lambdaFactor, t2 = 1.0 / O.lambdaFactor;
+            dlambda = (t1 < t2) ? t1 : t2;
+            lambda = lambda * dlambda * (lambda > O.lambdaMin);
+            status = ILQG_ST_CONVERGED_GRAD;
+        }
+    }
+    if(lane == 0) {
+        P.i[ILQG_I_NEED_DERIVS][b] = 0;
+        P.i[ILQG_I_STATUS][b] = status;
+        P.f[ILQG_F_LAMBDA][b] = lambda;
+        P.f[ILQG_F_DLAMBDA][b] = dlambda;
+        P.f[ILQG_F_DV0][b] = dV0;
+        P.f[ILQG_F_DV1][b] = dV1;
+        P.f[ILQG_F_GNORM][b] = g_norm;
+        P.i[ILQG_I_BP_CALLS][b] = calls;
+        P.i[ILQG_I_BP_RC][b] = rc;
+    }
+}
+#endif  // ILQG_WAVE_MAP
+
 // ---------------------------------------------------------------------------
 // forward_pass: one lane per (trajectory, step size)
 // ---------------------------------------------------------------------------
@@ -546,20 +708,22 @@ enum { ROLL_INIT = 0, ROLL_SEARCH = 1, ROLL_WINNER = 2, ROLL_COST = 3, ROLL_SEAR
 
 // nominal data of one step (what forward_pass reads of the nominal trajectory, iLQG_func.tem:145-155)
 struct NomStep {
-    double x[NX], u[NU], l[NU], K[NXU];
+    double x[NX], u[NU], l[NU];
+    double K[WAVE_MAP ? 1 : NXU];  // wave mapping: L is too large to prefetch, it is streamed (below)
 };
 
 __device__ __forceinline__ void load_nominal(NomStep &s, const DevPtrs &P, int k, int b, bool gains) {
-    const size_t Bp = P.Bp;
 #pragma unroll
-    for(int i = 0; i < NX; i++) s.x[i] = P.f[ILQG_F_X][((size_t)k * NX + i) * Bp + b];
+    for(int i = 0; i < NX; i++) s.x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, k, i, b)];
 #pragma unroll
-    for(int i = 0; i < NU; i++) s.u[i] = P.f[ILQG_F_U][((size_t)k * NU + i) * Bp + b];
+    for(int i = 0; i < NU; i++) s.u[i] = P.f[ILQG_F_U][ix(P, NU, P.N, k, i, b)];
     if(gains) {
 #pragma unroll
-        for(int i = 0; i < NU; i++) s.l[i] = P.f[ILQG_F_LG][((size_t)k * NU + i) * Bp + b];
+        for(int i = 0; i < NU; i++) s.l[i] = P.f[ILQG_F_LG][ix(P, NU, P.N, k, i, b)];
+        if(!WAVE_MAP) {
 #pragma unroll
-        for(int i = 0; i < NXU; i++) s.K[i] = P.f[ILQG_F_KG][((size_t)k * NXU + i) * Bp + b];
+            for(int i = 0; i < NXU; i++) s.K[i] = P.f[ILQG_F_KG][ix(P, NXU, P.N, k, i, b)];
+        }
     }
 }
 
@@ -579,7 +743,6 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
         b = P.pending[b];
     }
     if(b >= P.B) return;
-    const size_t Bp = P.Bp;
     const int N = P.N;
     double alpha = 0.0;
     if(mode == ROLL_SEARCH || mode == ROLL_SEARCH_LIST) {
@@ -606,7 +769,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
 
     double xc[NX];
 #pragma unroll
-    for(int i = 0; i < NX; i++) xc[i] = P.f[ILQG_F_X][(size_t)i * Bp + b];  // x0 (iLQG_func.tem:141-142)
+    for(int i = 0; i < NX; i++) xc[i] = P.f[ILQG_F_X][ix(P, NX, N + 1, 0, i, b)];  // x0 (iLQG_func.tem:141-142)
     double csum = 0.0;
     int ok = 1;
     NomStep cur;
@@ -617,9 +780,9 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
     for(int k = 0; k < N; k++) {
         if(store && pk >= 0) {
 #pragma unroll
-            for(int i = 0; i < NX; i++) P.f[ILQG_F_X][((size_t)pk * NX + i) * Bp + b] = px[i];
+            for(int i = 0; i < NX; i++) P.f[ILQG_F_X][ix(P, NX, N + 1, pk, i, b)] = px[i];
 #pragma unroll
-            for(int i = 0; i < NU; i++) P.f[ILQG_F_U][((size_t)pk * NU + i) * Bp + b] = pu[i];
+            for(int i = 0; i < NU; i++) P.f[ILQG_F_U][ix(P, NU, N, pk, i, b)] = pu[i];
         }
         NomStep nxt;
         if(k + 1 < N) load_nominal(nxt, P, k + 1, b, gains);  // in flight while this step computes
@@ -638,8 +801,14 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
 #pragma unroll
                 for(int i = 0; i < NX; i++) {
                     const double dx = ct.x[i] - cur.x[i];
+                    if(WAVE_MAP) {
+                        const double *Kk = P.f[ILQG_F_KG] + ix(P, NXU, N, k, i * NU, b);
 #pragma unroll
-                    for(int j = 0; j < NU; j++) ct.u[j] += cur.K[j + i * NU] * dx;
+                        for(int j = 0; j < NU; j++) ct.u[j] += Kk[j] * dx;
+                    } else {
+#pragma unroll
+                        for(int j = 0; j < NU; j++) ct.u[j] += cur.K[j + i * NU] * dx;
+                    }
                 }
             } else {
 #pragma unroll
@@ -670,16 +839,16 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
     }
     if(store && pk >= 0) {
 #pragma unroll
-        for(int i = 0; i < NX; i++) P.f[ILQG_F_X][((size_t)pk * NX + i) * Bp + b] = px[i];
+        for(int i = 0; i < NX; i++) P.f[ILQG_F_X][ix(P, NX, N + 1, pk, i, b)] = px[i];
 #pragma unroll
-        for(int i = 0; i < NU; i++) P.f[ILQG_F_U][((size_t)pk * NU + i) * Bp + b] = pu[i];
+        for(int i = 0; i < NU; i++) P.f[ILQG_F_U][ix(P, NU, N, pk, i, b)] = pu[i];
     }
     if(ok) {
         trajFin_t cf;
         init_final(&cf, &o);
         if(cost_only) {
 #pragma unroll
-            for(int i = 0; i < NX; i++) cf.x[i] = P.f[ILQG_F_X][((size_t)N * NX + i) * Bp + b];
+            for(int i = 0; i < NX; i++) cf.x[i] = P.f[ILQG_F_X][ix(P, NX, N + 1, N, i, b)];
         } else {
 #pragma unroll
             for(int i = 0; i < NX; i++) cf.x[i] = xc[i];
@@ -690,14 +859,14 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
             csum += cf.c;
             if(store) {
 #pragma unroll
-                for(int i = 0; i < NX; i++) P.f[ILQG_F_X][((size_t)N * NX + i) * Bp + b] = cf.x[i];
+                for(int i = 0; i < NX; i++) P.f[ILQG_F_X][ix(P, NX, N + 1, N, i, b)] = cf.x[i];
             }
         }
     }
 
     if(mode == ROLL_SEARCH || mode == ROLL_SEARCH_LIST) {
-        P.f[ILQG_F_ALPHA_COST][(size_t)ai * Bp + b] = csum;
-        P.i[ILQG_I_ALPHA_OK][(size_t)ai * Bp + b] = ok;
+        P.f[ILQG_F_ALPHA_COST][(size_t)ai * P.Bp + b] = csum;
+        P.i[ILQG_I_ALPHA_OK][(size_t)ai * P.Bp + b] = ok;
     } else if(mode == ROLL_WINNER) {
         P.f[ILQG_F_NEW_COST][b] = csum;
     } else if(mode == ROLL_COST) {
@@ -855,6 +1024,8 @@ struct ilqg_dev {
     double *staging;
     size_t staging_bytes;
     int *counter;
+    int chunk;            // wave mapping: trajectories whose derivative records fit the work buffer
+    bool work_consts;     // wave mapping: constant entries of the records written (init_running)
     bool timing;
     struct Span { int kernel; hipEvent_t a, b; };
     std::vector<Span> spans;
@@ -872,7 +1043,7 @@ FieldInfo field_info(int f) {
         case ILQG_F_U: return {0, NU, NU};
         case ILQG_F_LG: return {0, NU, NU};
         case ILQG_F_KG: return {0, NXU, NXU};
-        case ILQG_F_DER: return {0, REC, REC_HOST};
+        case ILQG_F_DER: return {0, WAVE_MAP ? REC_HOST : REC, REC_HOST};
         case ILQG_F_FIN: return {-1, FIN, FIN};
         case ILQG_F_ALPHA_COST: return {-1, ILQG_MAX_ALPHA, ILQG_MAX_ALPHA};
         default: return {-1, 1, 1};
@@ -952,6 +1123,7 @@ void ilqg_dev_dims(int *out) {
     out[4] = REC;
     out[5] = HX ? 1 : 0;
     out[6] = 0;
+    out[7] = WAVE_MAP ? 1 : 0;
 }
 
 const char *ilqg_dev_kernel_name(int k) {
@@ -990,7 +1162,23 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
     d->P.Bp = d->Bp;
     d->P.N = d->N;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    d->chunk = 0;
+    d->work_consts = false;
     for(int f = 0; f < ILQG_F_COUNT; f++) {
+        if(WAVE_MAP && f == ILQG_F_DER) {
+            // derivative records = device trajEl_t structs for as many trajectories as fit the budget
+            const char *e = getenv("ILQG_WORK_GB");
+            const double budget = (e ? atof(e) : 24.0) * 1e9;
+            const size_t per_traj = (size_t)d->N * sizeof(trajEl_t);
+            size_t c = (size_t)(budget / (double)per_traj);
+            if(c < 1) c = 1;
+            if(c > (size_t)d->B) c = d->B;
+            d->chunk = (int)c;
+            HIP_TRY(hipMalloc((void **)&d->P.work, c * per_traj));
+            HIP_TRY(hipMemsetAsync(d->P.work, 0, c * per_traj, d->stream));
+            d->P.f[f] = nullptr;
+            continue;
+        }
         const FieldInfo fi = field_info(f);
         const size_t bytes = (size_t)field_steps(d, f) * fi.wd * d->Bp * sizeof(double);
         HIP_TRY(hipMalloc((void **)&d->P.f[f], bytes));
@@ -1022,7 +1210,9 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
     }
-    for(int f = 0; f < ILQG_F_COUNT; f++) hipFree(d->P.f[f]);
+    for(int f = 0; f < ILQG_F_COUNT; f++)
+        if(d->P.f[f]) hipFree(d->P.f[f]);
+    if(d->P.work) hipFree(d->P.work);
     for(int f = 0; f < ILQG_I_COUNT; f++) hipFree(d->P.i[f]);
     hipFree(d->P.derivs_failed);
     hipFree(d->counter);
@@ -1053,6 +1243,7 @@ int ilqg_dev_set_params(ilqg_dev_t *d, int n_params, const int *sizes, const dou
     }
     HIP_TRY(hipMalloc((void **)&d->P.p, ptrs.size() * sizeof(double *)));
     HIP_TRY(hipMemcpy(d->P.p, ptrs.data(), ptrs.size() * sizeof(double *), hipMemcpyHostToDevice));
+    d->work_consts = false;  // constant record entries depend on the parameters
     return 0;
 }
 
@@ -1074,12 +1265,71 @@ int ilqg_dev_write(ilqg_dev_t *d, int field, const double *host) {
     return ilqg_dev_write_steps(d, field, host, field_steps(d, field));
 }
 
+// wave mapping: these fields are trajectory-major on the device, i.e. already in host layout
+static bool is_traj_major(int field) {
+    return WAVE_MAP && (field == ILQG_F_X || field == ILQG_F_U || field == ILQG_F_LG || field == ILQG_F_KG ||
+                        field == ILQG_F_FIN);
+}
+
+#if ILQG_WAVE_MAP
+// derivative records live in device trajEl_t structs: convert to/from the packed host record
+#define REC_FIELDS(OP)                                                                            \
+    OP(cx, NX) OP(cxx, SXX) OP(cu, NU) OP(cuu, SUU) OP(cxu, NXU) OP(fx, NX * NX) OP(fu, NXU)     \
+    OP(lower, NU) OP(upper, NU) REC_FIELDS_FULL(OP)                                               \
+    OP(lower_sign, NU) OP(upper_sign, NU) OP(lower_hx, NXU) OP(upper_hx, NXU)
+#if FULL_DDP
+#define REC_FIELDS_FULL(OP) OP(fxx, NX * SXX) OP(fuu, NX * SUU) OP(fxu, NX * NXU)
+#else
+#define REC_FIELDS_FULL(OP)
+#endif
+
+static int der_io(ilqg_dev *d, double *host_rw, const double *host_ro) {
+    if(d->B > d->chunk) {
+        g_err = "derivative records of the whole batch do not fit the work buffer (wave mapping): read/write them "
+                "with a batch <= the chunk size";
+        return 1;
+    }
+    const size_t n = (size_t)d->B * d->N;
+    std::vector<trajEl_t> tmp(n);
+    HIP_TRY(hipMemcpy(tmp.data(), d->P.work, n * sizeof(trajEl_t), hipMemcpyDeviceToHost));
+    for(size_t e = 0; e < n; e++) {
+        trajEl_t &t = tmp[e];
+        if(host_ro) {
+            const double *r = host_ro + e * REC_HOST;
+#define OP(field, cnt) memcpy(t.field, r, sizeof(double) * (cnt)); r += (cnt);
+            REC_FIELDS(OP)
+#undef OP
+        } else {
+            double *r = host_rw + e * REC_HOST;
+#define OP(field, cnt) memcpy(r, t.field, sizeof(double) * (cnt)); r += (cnt);
+            REC_FIELDS(OP)
+#undef OP
+        }
+    }
+    if(host_ro) HIP_TRY(hipMemcpy(d->P.work, tmp.data(), n * sizeof(trajEl_t), hipMemcpyHostToDevice));
+    return 0;
+}
+#endif
+
 int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps) {
     HIP_TRY(hipSetDevice(d->device));
     const FieldInfo fi = field_info(field);
     if(steps < 1 || steps > field_steps(d, field)) {
         g_err = "ilqg_dev_write_steps: bad step count";
         return 1;
+    }
+#if ILQG_WAVE_MAP
+    if(field == ILQG_F_DER) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        return der_io(d, nullptr, host);
+    }
+#endif
+    if(is_traj_major(field)) {
+        const size_t row = (size_t)steps * fi.wd * sizeof(double);
+        const size_t dpitch = (size_t)field_steps(d, field) * fi.wd * sizeof(double);
+        HIP_TRY(hipMemcpy2DAsync(d->P.f[field], dpitch, host, row, row, d->B, hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        return 0;
     }
     const size_t n = (size_t)d->B * steps * fi.wh;
     if(ensure_staging(d, n * sizeof(double))) return 1;
@@ -1100,6 +1350,17 @@ int ilqg_dev_read(ilqg_dev_t *d, int field, double *host) {
     const FieldInfo fi = field_info(field);
     const int steps = field_steps(d, field);
     const size_t n = (size_t)d->B * steps * fi.wh;
+#if ILQG_WAVE_MAP
+    if(field == ILQG_F_DER) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        return der_io(d, host, nullptr);
+    }
+#endif
+    if(is_traj_major(field)) {
+        HIP_TRY(hipMemcpyAsync(host, d->P.f[field], n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        return 0;
+    }
     if(ensure_staging(d, n * sizeof(double))) return 1;
     {
         Timed t(d, ILQG_K_TRANSPOSE);
@@ -1163,9 +1424,39 @@ int ilqg_dev_rollout_init(ilqg_dev_t *d) {
     return 0;
 }
 
+#if ILQG_WAVE_MAP
+// wave mapping: derivative records are evaluated chunk by chunk into the work buffer and consumed by
+// the backward kernel of the same chunk.  do_derivs = 0 uses the records already in the buffer.
+static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_backward) {
+    for(int c0 = 0; c0 < d->B; c0 += d->chunk) {
+        const int cnt = (d->B - c0 < d->chunk) ? d->B - c0 : d->chunk;
+        if(do_derivs) {
+            Timed t(d, ILQG_K_DERIVS);
+            const size_t total = (size_t)cnt * (d->N + 1);
+            hipLaunchKernelGGL(k_derivs_wave, grid1(total, 64), dim3(64), 0, d->stream, d->P, d->O, c0, cnt,
+                               d->work_consts ? 0 : 1);
+        }
+        if(do_backward) {
+            Timed t(d, ILQG_K_BACKWARD);
+            hipLaunchKernelGGL(k_backward_wave, dim3(cnt), dim3(64), 0, d->stream, d->P, d->O, single_sweep, c0, cnt);
+        }
+        if(do_derivs && cnt == d->chunk) d->work_consts = true;  // every element of the buffer has its constants now
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+#endif
+
 int ilqg_dev_derivs(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
+#if ILQG_WAVE_MAP
+    if(d->B > d->chunk) {
+        g_err = "ilqg_dev_derivs: the batch does not fit the work buffer; use ilqg_dev_backward(mode 2) / iterate";
+        return 1;
+    }
+    return wave_backward(d, 0, 1, 0);
+#else
     {
         Timed t(d, ILQG_K_DERIVS);
         const size_t total = (size_t)d->Bp * (d->N + 1);
@@ -1173,6 +1464,7 @@ int ilqg_dev_derivs(ilqg_dev_t *d) {
     }
     HIP_TRY(hipGetLastError());
     return 0;
+#endif
 }
 
 int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
@@ -1182,6 +1474,13 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
         return 1;
     }
     if(mode == 2) NEED_PARAMS(d);
+#if ILQG_WAVE_MAP
+    if(mode != 2 && d->B > d->chunk) {
+        g_err = "ilqg_dev_backward: stored records need the whole batch in the work buffer; use mode 2";
+        return 1;
+    }
+    return wave_backward(d, mode == 1, mode == 2, 1);
+#else
     {
         Timed t(d, mode == 2 ? ILQG_K_BACKWARD_FUSED : ILQG_K_BACKWARD);
         const dim3 grid(d->Bp / WAVE), block(WAVE);
@@ -1194,6 +1493,7 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
     }
     HIP_TRY(hipGetLastError());
     return 0;
+#endif
 }
 
 int ilqg_dev_search(ilqg_dev_t *d) {
@@ -1240,7 +1540,7 @@ int ilqg_dev_update(ilqg_dev_t *d) {
 
 int ilqg_dev_iterate(ilqg_dev_t *d, int n) {
     for(int it = 0; it < n; it++) {
-        if(d->O.fuse_derivs) {
+        if(d->O.fuse_derivs || WAVE_MAP) {  // wave mapping: derivatives + sweep chunk by chunk
             if(ilqg_dev_backward(d, 2)) return 1;
         } else {
             if(ilqg_dev_derivs(d)) return 1;

@@ -104,7 +104,8 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor);
 void ilqg_dev_destroy(ilqg_dev_t *d);
 
 /* compile-time facts of the problem this library was built for:
- * out[0..6] = N_X, N_U, FULL_DDP, host record size, device record size, state-dependent limits, n_params */
+ * out[0..7] = N_X, N_U, FULL_DDP, host record size, device record size, state-dependent limits, n_params,
+ * mapping (0 = one lane per trajectory, 1 = one wavefront per trajectory) */
 void ilqg_dev_dims(int *out);
 
 int ilqg_dev_set_params(ilqg_dev_t *d, int n_params, const int *sizes, const double *const *values);

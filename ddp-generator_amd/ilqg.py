@@ -34,8 +34,10 @@ class IlqgError(RuntimeError):
 
 
 def library_path(problem="carparking", full_ddp=0, strict=False):
-    """strict=True: the -ffp-contract=off build (bit-for-bit CPU parity of the backward pass; tests only)"""
-    return os.path.join(LIBDIR, "libilqg_%s_fd%d_hip%s.so" % (problem, int(full_ddp), "_strict" if strict else ""))
+    """strict=True: the -ffp-contract=off build (bit-for-bit CPU parity of the backward pass; tests only);
+    strict="wave": the build of a small problem forced into the one-wavefront-per-trajectory mapping"""
+    suffix = "_wave" if strict == "wave" else ("_strict" if strict else "")
+    return os.path.join(LIBDIR, "libilqg_%s_fd%d_hip%s.so" % (problem, int(full_ddp), suffix))
 
 
 _libs = {}
@@ -102,6 +104,7 @@ class Problem:
         d = np.zeros(8, dtype=np.int32)
         self.lib.ilqg_problem_dims(d)
         self.nx, self.nu, _, self.rec_host, self.rec_dev, self.state_dep_limits, self.n_params = [int(x) for x in d[:7]]
+        self.wave_mapping = bool(d[7])
         self.sxx = self.nx * (self.nx + 1) // 2
         self.suu = self.nu * (self.nu + 1) // 2
         self.params = [(self.lib.ilqg_problem_param_name(i).decode(), self.lib.ilqg_problem_param_size(i))

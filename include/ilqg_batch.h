@@ -30,9 +30,10 @@ extern "C" {
 
 typedef struct ilqg_batch ilqg_batch_t;
 
-/* problem facts of this build: out[0..6] = N_X, N_U, FULL_DDP, derivative
+/* problem facts of this build: out[0..7] = N_X, N_U, FULL_DDP, derivative
  * record size (host view), record size stored on the device, 1 if input limits
- * depend on the state, number of problem parameters */
+ * depend on the state, number of problem parameters, mapping (0 = one lane per
+ * trajectory, 1 = one wavefront per trajectory; chosen at build time from N_X) */
 void ilqg_problem_dims(int *out);
 /* problem parameters, as the generated paramdesc[] declares them (iLQG_func.tem:11-18);
  * size -1 = one value per time step (n_hor+1 values) */

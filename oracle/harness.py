@@ -46,6 +46,10 @@ SYN_PARAMS = dict(h=[0.05], c=[0.8], px=[0.1], ru=[0.05] * 8, qx=[0.02 + 0.01 * 
                   qf=[1.0 + 0.1 * i for i in range(16)], lim=[-1.0, 1.0])
 
 
+# the same with tight input limits, so that short-horizon test solves run on the limits
+SYN_PARAMS_TIGHT = dict(SYN_PARAMS, lim=[-0.25, 0.25])
+
+
 def syn_inputs(batch, n_hor, first=0, seed=20261003):
     """x0 ~ 0.5 U(-1,1)^16, u0 = 0.1 N(0,1), counter-based like the car inputs"""
     import importlib.util

@@ -26,7 +26,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, Driver, Kernels, hx_inputs, lib_path  # noqa: E402
+from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT as SYN_PARAMS, Driver, Kernels, hx_inputs, lib_path,  # noqa: E402
+                            syn_inputs)
 
 spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "ddp-generator_amd", "synth.py"))
 synth = importlib.util.module_from_spec(spec)
@@ -297,6 +298,50 @@ def hx_goldens(fd):
           (fd, out["it3_bp_rc"], out["it3_ls_index"], int(np.count_nonzero(hxcols)), rcs, its))
 
 
+def synth_goldens(fd, N=32):
+    """synthetic n=16, m=8 problem (BASELINE config 5) on a short horizon: single pass at the start and
+    after 3 iterations (inputs on their limits), line search, and full solves"""
+    x0s, u0s = syn_inputs(4, N)
+    out = dict(x0=x0s, u0=u0s, n_hor=N)
+    for tag, pre in (("", 0), ("it3_", 3)):
+        d = Driver(lib_path("ref", "synth16x8", fd), N, SYN_PARAMS, dict(max_iter=max(pre, 1)))
+        assert d.init(x0s[0], u0s[0]) == 1
+        if pre:
+            d.solve()
+        lam = d.scalars()["lambda"] if pre else 1.0
+        cost = d.scalars()["cost"]
+        xn, un = d.traj(0)
+        assert d.calc_derivs() == 1
+        rec, fin = d.derivs()
+        d.set_lambda(lam)
+        with quiet():
+            rc = d.back_pass()
+        l, L = d.gains()
+        s = d.scalars()
+        acc = d.line_search(0)
+        s2 = d.scalars()
+        xc, uc = d.traj(1)
+        out.update({tag + "x_nom": xn, tag + "u_nom": un, tag + "rec": rec, tag + "fin": fin, tag + "lam": lam,
+                    tag + "cost": cost, tag + "bp_rc": rc, tag + "l": l, tag + "L": L,
+                    tag + "dV": np.array([s["dV0"], s["dV1"]]), tag + "g_norm": s["g_norm"],
+                    tag + "ls_accept": acc, tag + "ls_index": d.log_linesearch(0), tag + "new_cost": s2["new_cost"],
+                    tag + "x_cand": xc, tag + "u_cand": uc})
+        d.close()
+    rcs, its, costs, xs = [], [], [], []
+    for b in range(len(x0s)):
+        d = Driver(lib_path("ref", "synth16x8", fd), N, SYN_PARAMS, dict(max_iter=100))
+        assert d.init(x0s[b], u0s[b]) == 1
+        with quiet():
+            rcs.append(d.solve())
+        sc = d.scalars(); its.append(int(sc["iterations"])); costs.append(sc["cost"]); xs.append(d.traj(0)[0])
+        d.close()
+    out.update(solve_rc=np.array(rcs), solve_iterations=np.array(its), solve_cost=np.array(costs), solve_x=np.array(xs))
+    np.savez_compressed(os.path.join(HERE, "synth16x8_fd%d.npz" % fd), **out)
+    clamped = int(np.sum(np.abs(np.abs(out["it3_u_nom"]) - 0.25) < 1e-12))
+    print("synth16x8 fd%d: rc %d/%d alpha idx %d/%d, inputs on a limit at it3: %d, solves %s iterations %s" %
+          (fd, out["bp_rc"], out["it3_bp_rc"], out["ls_index"], out["it3_ls_index"], clamped, rcs, its))
+
+
 def regtype2_goldens():
     """regType 2 (back_pass.c:136-155, reproduced literally incl. its index quirk)"""
     x0, u0 = synth.car_single()
@@ -327,6 +372,8 @@ def main():
     for fd in (0, 1):
         hx_goldens(fd)
     regtype2_goldens()
+    for fd in (0, 1):
+        synth_goldens(fd)
 
 
 if __name__ == "__main__":

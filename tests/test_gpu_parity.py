@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import golden, load_package
-from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, Driver, hx_inputs, lib_path
+from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver, hx_inputs, lib_path, syn_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -476,6 +476,98 @@ def test_regtype2_golden(ilqg, fd):
         assert close(l[0], g["fd%d_l" % fd]) and close(L[0], g["fd%d_L" % fd])
         assert close(s.scalar("dV0")[0], g["fd%d_dV" % fd][0]) and close(s.scalar("g_norm")[0], g["fd%d_g_norm" % fd])
     s.close()
+
+
+# ---------------------------------------------------------------------------
+# wave mapping (one wavefront per trajectory): n=16/m=8 synthetic problem, and CarParking forced into it
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("fd", [0, 1])
+def test_wave_mapping_synthetic_golden(ilqg, fd):
+    g = golden("synth16x8_fd%d.npz" % fd)
+    N = int(g["n_hor"])
+    s = ilqg.BatchSolver("synth16x8", fd, batch=1, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(ls_split=0))
+    assert s.problem.wave_mapping and (s.problem.nx, s.problem.nu) == (16, 8)
+    s.init(g["x0"][:1], g["u0"][:1])
+    assert close(s.scalar("cost")[0], g["cost"])
+    for tag in ("", "it3_"):
+        s.set_x(g[tag + "x_nom"][None]); s.set_u(g[tag + "u_nom"][None])
+        s.set_scalar("cost", float(g[tag + "cost"]))
+        s.calc_derivs()
+        rec, fin = s.derivs()
+        assert close(rec[0], g[tag + "rec"]), worst(rec[0], g[tag + "rec"])
+        assert close(fin[0], g[tag + "fin"])
+        s.set_scalar("lambda", float(g[tag + "lam"]))
+        s.back_pass(single_sweep=True)
+        assert s.ints("bp_rc")[0] == int(g[tag + "bp_rc"]) == 0
+        l, L = s.gains()
+        assert close(l[0], g[tag + "l"]), worst(l[0], g[tag + "l"])
+        assert close(L[0], g[tag + "L"]), worst(L[0], g[tag + "L"])
+        assert close(s.scalar("dV0")[0], g[tag + "dV"][0]) and close(s.scalar("dV1")[0], g[tag + "dV"][1])
+        assert close(s.scalar("g_norm")[0], g[tag + "g_norm"])
+        s.line_search()
+        assert s.ints("accepted")[0] == int(g[tag + "ls_accept"]) and s.ints("alpha_idx")[0] == int(g[tag + "ls_index"])
+        assert close(s.scalar("new_cost")[0], g[tag + "new_cost"], 1e-9)
+        assert close(s.x()[0], g[tag + "x_cand"], 1e-9) and close(s.u()[0], g[tag + "u_cand"], 1e-9)
+    s.close()
+    # lock-step batch (ragged size) against the oracle, derivative records chunked through the work buffer
+    B, iters = 5, 4
+    x0, u0 = syn_inputs(B, N, first=40)
+    s = ilqg.BatchSolver("synth16x8", fd, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters))
+    s.init(x0, u0)
+    s.iterate(iters)
+    cost, x = s.scalar("cost"), s.x()
+    for b in range(B):
+        d = Driver(lib_path("oracle", "synth16x8", fd), N, SYN_PARAMS_TIGHT, dict(max_iter=iters))
+        assert d.init(x0[b], u0[b]) == 1
+        d.solve()
+        assert close(cost[b], d.scalars()["cost"], 1e-9), (b, cost[b], d.scalars()["cost"])
+        assert np.abs(x[b] - d.traj(0)[0]).max() < 1e-7
+        d.close()
+    s.close()
+
+
+def test_wave_mapping_chunked_records(ilqg, monkeypatch):
+    """a work buffer smaller than the batch: derivative records are produced and consumed chunk by chunk"""
+    g = golden("synth16x8_fd0.npz")
+    N = int(g["n_hor"])
+    B, iters = 7, 3
+    x0, u0 = syn_inputs(B, N, first=80)
+    out = []
+    for gb in ("24", "0.002"):  # 0.002 GB ~ 6 trajectories of 32 steps x 9.5 KB -> two chunks
+        monkeypatch.setenv("ILQG_WORK_GB", gb)
+        s = ilqg.BatchSolver("synth16x8", 0, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters))
+        s.init(x0, u0)
+        s.iterate(iters)
+        out.append((s.scalar("cost"), s.x(), s.ints("alpha_idx")))
+        s.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_wave_mapping_carparking(ilqg, synth):
+    """CarParking in the one-wavefront-per-trajectory mapping (BASELINE config 2 wording): same gains as the
+    reference, same iterations as the lane mapping"""
+    g = golden("car_single_fd0.npz")
+    s = ilqg.BatchSolver("carparking", 0, batch=1, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(ls_split=0), strict="wave")
+    assert s.problem.wave_mapping
+    s.init(g["x0"][None], g["u0"][None])
+    s.calc_derivs()
+    s.back_pass(single_sweep=True)
+    l, L = s.gains()
+    assert close(l[0], g["l"]) and close(L[0], g["L"]), (worst(l[0], g["l"]), worst(L[0], g["L"]))
+    assert close(s.scalar("dV0")[0], g["dV"][0]) and close(s.scalar("g_norm")[0], g["g_norm"])
+    s.line_search()
+    assert s.ints("alpha_idx")[0] == int(g["ls_index"]) and close(s.scalar("new_cost")[0], g["new_cost"])
+    s.close()
+    B, iters = 70, 4
+    x0, u0 = synth.car_batch(B, first=2000)
+    res = []
+    for mode in (False, "wave"):
+        s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=iters), strict=mode)
+        s.init(x0, u0)
+        s.iterate(iters)
+        res.append((s.scalar("cost"), s.ints("alpha_idx"), s.x()))
+        s.close()
+    assert close(res[0][0], res[1][0], 1e-9) and np.array_equal(res[0][1], res[1][1]) and np.abs(res[0][2] - res[1][2]).max() < 1e-7
 
 
 # ---------------------------------------------------------------------------

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, Driver, Kernels, lib_path
+from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver, Kernels, lib_path
 
 
 @pytest.fixture(scope="module")
@@ -135,6 +135,33 @@ def test_state_dependent_limits_problem(oracle_built, fd):
         assert d.solve() == g["solve_rc"][b]
         assert d.scalars()["cost"] == g["solve_cost"][b] and np.array_equal(d.traj(0)[0], g["solve_x"][b])
         d.close()
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_synthetic_16x8_problem(oracle_built, fd):
+    """n=16, m=8 with dense second derivatives (BASELINE config 5), short horizon"""
+    g = golden("synth16x8_fd%d.npz" % fd)
+    N = int(g["n_hor"])
+    for tag, pre in (("", 0), ("it3_", 3)):
+        d = Driver(lib_path("oracle", "synth16x8", fd), N, SYN_PARAMS_TIGHT, dict(max_iter=max(pre, 1)))
+        assert d.init(g["x0"][0], g["u0"][0]) == 1
+        if pre:
+            d.solve()
+        assert d.calc_derivs() == 1
+        rec, fin = d.derivs()
+        assert np.array_equal(rec, g[tag + "rec"]) and np.array_equal(fin, g[tag + "fin"])
+        d.set_lambda(float(g[tag + "lam"]))
+        assert d.back_pass() == int(g[tag + "bp_rc"])
+        l, L = d.gains()
+        assert np.array_equal(l, g[tag + "l"]) and np.array_equal(L, g[tag + "L"])
+        assert d.line_search(0) == int(g[tag + "ls_accept"]) and d.log_linesearch(0) == int(g[tag + "ls_index"])
+        assert np.array_equal(d.traj(1)[0], g[tag + "x_cand"])
+        d.close()
+    b = 0
+    d = Driver(lib_path("oracle", "synth16x8", fd), N, SYN_PARAMS_TIGHT, dict(max_iter=100))
+    assert d.init(g["x0"][b], g["u0"][b]) == 1
+    assert d.solve() == g["solve_rc"][b] and d.scalars()["cost"] == g["solve_cost"][b]
+    d.close()
 
 
 def test_regtype2_literal(oracle_built):
