@@ -54,33 +54,32 @@ FUSED_MOVED_BYTES = (NX + NU + NU + NXU) * 8
 ITERATION_BYTES = 1200  # per step and trajectory, SURVEY.md §8(d)
 
 
-def cpu_baseline(batch_per_gpu, iters, budget_s=12.0):
+def cpu_baseline(batch_per_gpu, iters, problem, fd, params, n_hor, make_inputs, budget_s=12.0):
     """CPU checker on a bounded sample of the same workload, one pthread per host core, each solving
     its share of the sample exactly as independent runs of the reference would (oracle/driver.c,
     drv_solve_many).  Returns the JSON object for `cpu_baseline`."""
-    import __graft_entry__ as g
-    from oracle.harness import CAR_PARAMS, Driver, lib_path
-    synth = g.load_package().synth
-    ref = lib_path("ref", full_ddp=0)
+    from oracle.harness import Driver, lib_path
+    ref = lib_path("ref", problem, fd)
     kind = "reference" if os.path.exists(ref) else "port"
-    path = ref if kind == "reference" else lib_path("oracle", full_ddp=0)
+    path = ref if kind == "reference" else lib_path("oracle", problem, fd)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    d = Driver(path, N_HOR, CAR_PARAMS, dict(max_iter=iters))
-    # calibrate single-core speed on 8 trajectories, then size the sample to the time budget
-    x0, u0 = synth.car_batch(8)
+    d = Driver(path, n_hor, params, dict(max_iter=iters))
+    # calibrate single-core speed on a few trajectories, then size the sample to the time budget
+    ncal = 8 if problem == "carparking" else 1
+    x0, u0 = make_inputs(ncal, n_hor)
     t0 = time.perf_counter()
     d.solve_many(x0, u0, 1)
-    per_traj = max((time.perf_counter() - t0) / 8, 1e-5)
+    per_traj = max((time.perf_counter() - t0) / ncal, 1e-5)
     sample = int(max(cores, min(65536, budget_s / per_traj * cores)))
-    x0, u0 = synth.car_batch(sample)
+    x0, u0 = make_inputs(sample, n_hor)
     t0 = time.perf_counter()
     cost, its, rc = d.solve_many(x0, u0, cores)
     dt = time.perf_counter() - t0
     d.close()
     traj_iters_per_s = float(its.sum()) / dt
     return {
-        "value": traj_iters_per_s / batch_per_gpu,  # batched iterations/s of a 65 536-trajectory batch
-        "unit": "iterations/s (65536-trajectory batch equivalent)",
+        "value": traj_iters_per_s / batch_per_gpu,  # batched iterations/s of a whole-batch equivalent
+        "unit": "iterations/s (%d-trajectory batch equivalent)" % batch_per_gpu,
         "cores": cores,
         "kind": kind,
         "single_core_ms_per_trajectory_iteration": 1e3 * per_traj / iters,
@@ -94,8 +93,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
-    ap.add_argument("--full-ddp", type=int, default=0)
+    ap.add_argument("--workload", choices=("car", "synth"), default="car",
+                    help="car: BASELINE metric (CarParking n=4,m=2,N=500, 65 536 per GPU); synth: BASELINE config 5 "
+                         "(n=16,m=8,N=1000, FULL_DDP=1, 16 384 per GPU, one wavefront per trajectory)")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU")
+    ap.add_argument("--n-hor", type=int, default=None)
+    ap.add_argument("--full-ddp", type=int, default=None)
+    ap.add_argument("--mapping", choices=("auto", "wave"), default="auto",
+                    help="wave: CarParking in the one-wavefront-per-trajectory build (comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resweep", type=int, default=-1, help="-1: library default (off without multipliers)")
     ap.add_argument("--fuse-derivs", type=int, default=1)
@@ -116,10 +121,33 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    B, K, W = args.batch, args.steps, args.warmup
-    x0, u0 = synth.car_batch(B, N_HOR, first=pkg.dist.shard_first(rank, B))
-    s = ilqg.BatchSolver("carparking", args.full_ddp, batch=B, n_hor=N_HOR, device=local, params=ilqg.CAR_PARAMS,
-                         opts=dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_split=args.ls_split))
+    global N_HOR, NX, NU, SXX, SUU, NXU, ALG_BYTES, FUSED_MOVED_BYTES, ITERATION_BYTES
+    car = args.workload == "car"
+    problem = "carparking" if car else "synth16x8"
+    fd = args.full_ddp if args.full_ddp is not None else (0 if car else 1)
+    B = args.batch if args.batch is not None else (65536 if car else 16384)
+    N_HOR = args.n_hor if args.n_hor is not None else (500 if car else 1000)
+    K, W = args.steps, args.warmup
+    if not car:
+        NX, NU = 16, 8
+        SXX, SUU, NXU = NX * (NX + 1) // 2, NU * (NU + 1) // 2, NX * NU
+    rec = NX + SXX + NU + SUU + NXU + NX * NX + NXU + 2 * NU + (NX * (SXX + SUU + NXU) if fd else 0)
+    ALG_BYTES = {  # SURVEY.md 8(d) formulas, doubles x 8 B per step and trajectory
+        "k_derivs": (NX + NU + rec) * 8,
+        "k_backward": (rec + NU + NU + NXU) * 8,
+        "k_rollout[search]": (NX + 2 * NU + NXU) * 8,
+        "k_rollout[winner]": (NX + NU) * 8,
+    }
+    ALG_BYTES["k_backward[fused derivs]"] = ALG_BYTES["k_derivs"] + ALG_BYTES["k_backward"]
+    FUSED_MOVED_BYTES = (NX + NU + NU + NXU) * 8
+    ITERATION_BYTES = sum(ALG_BYTES[k] for k in ("k_derivs", "k_backward", "k_rollout[search]", "k_rollout[winner]"))
+    first = pkg.dist.shard_first(rank, B)
+    x0, u0 = synth.car_batch(B, N_HOR, first=first) if car else synth.synth16_batch(B, N_HOR, first=first)
+    params = ilqg.CAR_PARAMS if car else synth.SYNTH16_PARAMS
+    s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=N_HOR, device=local, params=params,
+                         opts=dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_split=args.ls_split),
+                         strict=("wave" if args.mapping == "wave" else False))
+    args.full_ddp = fd
     if args.resweep >= 0:
         s.set_option("resweep", args.resweep)
     s.init(x0, u0)
@@ -156,7 +184,7 @@ def main():
     # secondary, untimed for `value`: the same iterations with the derivative records materialised in
     # HBM (k_derivs + k_backward<0>), the two kernels the HBM roofline of SURVEY 8(d) was written for
     unfused = {}
-    if rank == 0 and args.fuse_derivs and not args.no_unfused:
+    if rank == 0 and args.fuse_derivs and not args.no_unfused and not s.problem.wave_mapping:
         s.set_option("fuse_derivs", 0)
         s.init(x0, u0)
         s.timing(True)
@@ -173,18 +201,20 @@ def main():
         dominant = max((k for k in per_iter if k in ALG_BYTES), key=lambda k: per_iter[k])
         n_launch, total_ms = times[dominant]
         avg_ms = total_ms / n_launch
-        alg_bytes = ALG_BYTES[dominant] * N_HOR * B
+        # per launch; in the wave mapping a kernel is launched once per chunk of trajectories per iteration
+        alg_bytes = ALG_BYTES[dominant] * N_HOR * B * K / n_launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (tools/collect_traffic.sh), if committed
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and B == 65536:
+        if os.path.exists(tpath) and B == 65536 and car and not s.problem.wave_mapping:
             key = dominant
             if dominant == "k_rollout[search]":  # the profiler sees one k_rollout; its modes differ by grid size
                 key = "k_rollout[grid=%d]" % (B * (args.ls_split if 0 < args.ls_split < 8 else 8))
             traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
         iter_bytes = ITERATION_BYTES * N_HOR * B
         out = {
-            "metric": "iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)",
+            "metric": ("iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)" if car else
+                       "iLQG iterations/sec, batch %d synthetic problem (n=16,m=8,N=%d, FULL_DDP=%d)" % (B, N_HOR, fd)),
             "value": K / dt,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -196,10 +226,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "CarParking batch=%d per GPU x %d GPU, 8-alpha line search, FULL_DDP=%d, "
-                                   "first %d iterations after the initial roll-out" % (B, world, args.full_ddp, K),
+            "config": {"workload": "%s batch=%d per GPU x %d GPU, 8-alpha line search, FULL_DDP=%d, "
+                                   "first %d iterations after the initial roll-out" % ("CarParking" if car else "Synth16x8", B, world, args.full_ddp, K),
                        "batch_per_gpu": B, "n_hor": N_HOR, "n_x": NX, "n_u": NU, "full_ddp": args.full_ddp,
-                       "mapping": "one lane per trajectory (64 trajectories per wavefront)",
+                       "mapping": ("one wavefront per trajectory" if s.problem.wave_mapping else
+                                   "one lane per trajectory (64 trajectories per wavefront)"),
                        "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split, "resweep": args.resweep,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -221,7 +252,8 @@ def main():
             "cost_mean_after_window": float(cost.mean()),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, K)
+            out["cpu_baseline"] = cpu_baseline(B, K, problem, fd, params, N_HOR,
+                                               synth.car_batch if car else synth.synth16_batch)
         print(json.dumps(out))
     s.close()
     if world > 1:

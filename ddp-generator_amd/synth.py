@@ -57,3 +57,18 @@ def car_single(n_hor=500, seed=SEED):
     """the reference demo's fixed x0 (testCar.m:16) with seeded controls"""
     _, u0 = car_batch(1, n_hor, first=0, seed=seed)
     return np.array([1.0, 1.0, 1.5 * np.pi, 0.0]), u0[0]
+
+
+def synth16_batch(batch, n_hor, first=0, seed=SEED):
+    """x0 [batch,16] ~ 0.5 U(-1,1), u0 [batch,n_hor,8] = 0.1 N(0,1) for the synthetic n=16, m=8 problem
+    (SURVEY.md 8(d) config 5); same counter-based generator, separate streams from the car inputs"""
+    b = np.arange(first, first + batch, dtype=np.uint64)
+    x0 = 0.5 * (2.0 * uniform(b[:, None], n_hor + 1, np.arange(16)[None, :], seed + 1) - 1.0)
+    k = np.arange(n_hor, dtype=np.uint64)
+    u0 = 0.1 * normal(b[:, None, None], k[None, :, None], np.arange(8)[None, None, :], seed + 2)
+    return np.ascontiguousarray(x0), np.ascontiguousarray(u0)
+
+
+# parameters of the synthetic problem (problems/defs/synth16x8.py)
+SYNTH16_PARAMS = dict(h=[0.05], c=[0.8], px=[0.1], ru=[0.05] * 8, qx=[0.02 + 0.01 * i for i in range(16)],
+                      qf=[1.0 + 0.1 * i for i in range(16)], lim=[-1.0, 1.0])

@@ -51,16 +51,12 @@ SYN_PARAMS_TIGHT = dict(SYN_PARAMS, lim=[-0.25, 0.25])
 
 
 def syn_inputs(batch, n_hor, first=0, seed=20261003):
-    """x0 ~ 0.5 U(-1,1)^16, u0 = 0.1 N(0,1), counter-based like the car inputs"""
+    """x0 ~ 0.5 U(-1,1)^16, u0 = 0.1 N(0,1): the package's generator"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("ilqg_synth_inputs", os.path.join(os.path.dirname(HERE), "ddp-generator_amd", "synth.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    b = np.arange(first, first + batch, dtype=np.uint64)
-    x0 = 0.5 * (2.0 * m.uniform(b[:, None], n_hor + 1, np.arange(16)[None, :] % 16, seed + 1) - 1.0)
-    k = np.arange(n_hor, dtype=np.uint64)
-    u0 = 0.1 * m.normal(b[:, None, None], k[None, :, None], np.arange(8)[None, None, :], seed + 2)
-    return np.ascontiguousarray(x0), np.ascontiguousarray(u0)
+    return m.synth16_batch(batch, n_hor, first, seed)
 
 
 def lib_path(kind, problem="carparking", full_ddp=0):
