@@ -66,11 +66,13 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     for(int c = lane; c < NU + NX; c += 64) {
         if(c < NU) {
             double acc = F.cu[c];
+            #pragma unroll
             for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fu[r + c * NX];
             S.Qu[c] = acc;
         } else {
             const int cc = c - NU;
             double acc = F.cx[cc];
+            #pragma unroll
             for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fx[r + cc * NX];
             S.Qx[cc] = acc;
         }
@@ -82,6 +84,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         const int r = oo % NX, q = oo / NX;
         const double *A = second ? S.fx : S.fu;
         double acc = 0.0;
+        #pragma unroll
         for(int s = 0; s < NX; s++) acc += S.Vxx[sy(r, s)] * A[s + q * NX];
         (second ? S.T1 : S.T2)[oo] = acc;
     }
@@ -91,10 +94,12 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     for(int j = lane; j < NXU; j += 64) {
         const int r = j % NX, q = j / NX;
         double d = 0.0;
+        #pragma unroll
         for(int s = 0; s < NX; s++) d += S.fx[s + r * NX] * S.T2[s + q * NX];
         double v = F.cxu[j] + d;
         if(FULL) {
             double d1 = 0.0;
+            #pragma unroll
             for(int i = 0; i < NX; i++) d1 += S.Vx[i] * F.fxu[j + i * NXU];
             v += d1;
         }
@@ -109,8 +114,10 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         const double *A = isxx ? S.fx : S.fu;
         const double *T = isxx ? S.T1 : S.T2;
         double acc = 0.0;
+        #pragma unroll
         for(int s = 0; s < NX; s++) acc += A[s + r * NX] * T[s + c * NX];
         if(r != c) {
+            #pragma unroll
             for(int s = 0; s < NX; s++) acc += A[s + c * NX] * T[s + r * NX];
             acc *= 0.5;
         }
@@ -119,6 +126,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             const double *ten = isxx ? F.fxx : F.fuu;
             const int stride = isxx ? SXX : SUU;
             double d1 = 0.0;
+            #pragma unroll
             for(int i = 0; i < NX; i++) d1 += S.Vx[i] * ten[e + i * stride];
             v += d1;
         }
@@ -133,6 +141,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         double v = S.Quu[e];
         if(regType == 2) {
             double acc = 0.0;
+            #pragma unroll
             for(int q = 0; q < NU; q++) acc += S.fu[sy(q, r)] * S.fu[sy(q, c)];
             v += acc * lambda;
         }
@@ -144,6 +153,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         if(regType == 2) {
             const int i = j % NX, q = j / NX;
             double acc = 0.0;
+            #pragma unroll
             for(int s = 0; s < NX; s++) acc += S.fx[s + i * NX] * S.fu[s + q * NU];
             v += acc * lambda;
         }
@@ -158,7 +168,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         int cl[NU], nf;
 #pragma unroll
         for(int i = 0; i < SUU; i++) H[i] = S.QuuF[i];
-#pragma unroll
+        #pragma unroll
         for(int i = 0; i < NU; i++) {
             g[i] = S.Qu[i];
             lo[i] = F.lower[i];
@@ -168,7 +178,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         rc = box_qp<NU>(H, g, lo, up, x, cl, nf, inv);
         __syncthreads();
         if(lane == 0) {
-#pragma unroll
+            #pragma unroll
             for(int i = 0; i < NU; i++) {
                 S.l[i] = x[i];
                 S.clamp[i] = cl[i];
@@ -191,11 +201,13 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
                 v -= sg * hx;
             }
         } else {
+            #pragma unroll
             for(int j = 0; j < NU; j++) {
                 if(!S.clamp[j]) {
                     v -= S.invH[sy(i, j)] * S.Qxur[q + j * NX];
                 } else if(HX) {
                     double w = 0.0;
+                    #pragma unroll
                     for(int s = 0; s < NU; s++)
                         if(!S.clamp[s]) w -= S.invH[sy(i, s)] * S.QuuF[sy(s, j)];
                     const double sg = (S.clamp[j] == 1) ? F.lower_sign[j] : F.upper_sign[j];
@@ -211,9 +223,12 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     __syncthreads();
 
     // expected cost change, redundantly on every lane (back_pass.c:205-214)
+    #pragma unroll
     for(int i = 0; i < NU; i++) dV0 += S.Qu[i] * S.l[i];
+    #pragma unroll
     for(int i = 0; i < NU; i++) {
         double acc = 0.0;
+        #pragma unroll
         for(int j = 0; j < NU; j++) acc += S.l[j] * S.Quu[sy(j, i)];
         dV1 += 0.5 * S.l[i] * acc;
     }
@@ -222,11 +237,13 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     for(int o = lane; o < NU + NXU; o += 64) {
         if(o < NU) {
             double acc = 0.0;
+            #pragma unroll
             for(int s = 0; s < NU; s++) acc += S.Quu[sy(o, s)] * S.l[s];
             S.bc[o] = acc;
         } else {
             const int oo = o - NU, r = oo % NU, c = oo / NU;
             double acc = 0.0;
+            #pragma unroll
             for(int s = 0; s < NU; s++) acc += S.Quu[sy(r, s)] * S.K[s + c * NU];
             S.ba[oo] = acc;
         }
@@ -238,9 +255,12 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         if(o < NX) {
             const int i = o;
             double d = 0.0;
+            #pragma unroll
             for(int s = 0; s < NU; s++) d += S.K[s + i * NU] * S.bc[s];
             double v = S.Qx[i] + d;
+            #pragma unroll
             for(int j = 0; j < NU; j++) v += S.K[j + i * NU] * S.Qu[j];
+            #pragma unroll
             for(int j = 0; j < NU; j++) v += S.Qxu[i + j * NX] * S.l[j];
             S.Vx[i] = v;
         } else {
@@ -248,17 +268,22 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             int r, c;
             tri_rc(e, r, c);
             double acc = 0.0;
+            #pragma unroll
             for(int s = 0; s < NU; s++) acc += S.K[s + r * NU] * S.ba[s + c * NU];
             if(r != c) {
+                #pragma unroll
                 for(int s = 0; s < NU; s++) acc += S.K[s + c * NU] * S.ba[s + r * NU];
                 acc *= 0.5;
             }
             double v = S.Qxx[e] + acc;
             // the reference's i-major loop touches packed entry (r,c) first as (i=r,j=c), then as (i=c,j=r)
             if(r == c) {
+                #pragma unroll
                 for(int q = 0; q < NU; q++) v += (S.K[q + r * NU] * S.Qxu[r + q * NX]) * 2.0;
             } else {
+                #pragma unroll
                 for(int q = 0; q < NU; q++) v += S.K[q + r * NU] * S.Qxu[c + q * NX];
+                #pragma unroll
                 for(int q = 0; q < NU; q++) v += S.K[q + c * NU] * S.Qxu[r + q * NX];
             }
             S.Vxx[e] = v;
@@ -267,6 +292,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
 
     // gradient-norm summand (back_pass.c:246-251)
     double gmax = 0.0;
+    #pragma unroll
     for(int i = 0; i < NU; i++) {
         const double gi = fabs(S.l[i]) / (fabs(F.u[i]) + 1.0);
         if(gi > gmax) gmax = gi;
