@@ -27,16 +27,21 @@ __device__ __forceinline__ void tri_rc(int e, int &r, int &c) {
     r = e - c * (c + 1) / 2;
 }
 
+// Column-major matrices that are read one COLUMN per lane (a'b-type products) are stored with the
+// leading dimension padded by one double: a stride of 16 doubles (128 B) would put every lane of such
+// a read on the same two LDS banks (8-way conflict, measured 6 700 conflict cycles per step); with 17
+// (resp. 9) doubles the 16 column starts fall on distinct bank pairs.
 template <int NX, int NU>
 struct WaveLds {
     static constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
+    static constexpr int LDX = NX + 1, LDU = NU + 1;
     double Vx[NX], Vxx[SXX];
-    double fx[NX * NX], fu[NXU];
-    double T1[NX * NX], T2[NXU];   // Vxx*fx, Vxx*fu
+    double fx[LDX * NX], fu[LDX * NU];   // NX x NX, NX x NU, leading dimension LDX
+    double T1[LDX * NX], T2[LDX * NU];   // Vxx*fx, Vxx*fu, leading dimension LDX
     double Qx[NX], Qu[NU], Qxx[SXX], Qxu[NXU], Quu[SUU];
     double QuuF[SUU], Qxur[NXU];
-    double K[NXU], l[NU], invH[SUU];
-    double ba[NXU], bc[NU];        // Quu*K, Quu*l
+    double K[LDU * NX], l[NU], invH[SUU]; // NU x NX, leading dimension LDU
+    double ba[LDU * NX], bc[NU];          // Quu*K (leading dimension LDU), Quu*l
     int clamp[NU];
 };
 
@@ -55,11 +60,12 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
                                               double *Kout, const double lambda, const int regType, double &dV0,
                                               double &dV1, double &gsum) {
     constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
+    constexpr int LDX = NX + 1, LDU = NU + 1;  // padded leading dimensions of the LDS copies
     const int lane = threadIdx.x & 63;
 
     // stage fx, fu (read NX resp. NU times each) in LDS
-    for(int i = lane; i < NX * NX; i += 64) S.fx[i] = F.fx[i];
-    for(int i = lane; i < NXU; i += 64) S.fu[i] = F.fu[i];
+    for(int i = lane; i < NX * NX; i += 64) S.fx[(i % NX) + (i / NX) * LDX] = F.fx[i];
+    for(int i = lane; i < NXU; i += 64) S.fu[(i % NX) + (i / NX) * LDX] = F.fu[i];
     __syncthreads();
 
     // Qu = cu + fu'Vx ; Qx = cx + fx'Vx   (addMulVec, matMult.c:3-12)
@@ -67,13 +73,13 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         if(c < NU) {
             double acc = F.cu[c];
             #pragma unroll
-            for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fu[r + c * NX];
+            for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fu[r + c * LDX];
             S.Qu[c] = acc;
         } else {
             const int cc = c - NU;
             double acc = F.cx[cc];
             #pragma unroll
-            for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fx[r + cc * NX];
+            for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fx[r + cc * LDX];
             S.Qx[cc] = acc;
         }
     }
@@ -85,8 +91,8 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         const double *A = second ? S.fx : S.fu;
         double acc = 0.0;
         #pragma unroll
-        for(int s = 0; s < NX; s++) acc += S.Vxx[sy(r, s)] * A[s + q * NX];
-        (second ? S.T1 : S.T2)[oo] = acc;
+        for(int s = 0; s < NX; s++) acc += S.Vxx[sy(r, s)] * A[s + q * LDX];
+        (second ? S.T1 : S.T2)[r + q * LDX] = acc;
     }
     __syncthreads();
 
@@ -95,7 +101,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         const int r = j % NX, q = j / NX;
         double d = 0.0;
         #pragma unroll
-        for(int s = 0; s < NX; s++) d += S.fx[s + r * NX] * S.T2[s + q * NX];
+        for(int s = 0; s < NX; s++) d += S.fx[s + r * LDX] * S.T2[s + q * LDX];
         double v = F.cxu[j] + d;
         if(FULL) {
             double d1 = 0.0;
@@ -115,10 +121,10 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         const double *T = isxx ? S.T1 : S.T2;
         double acc = 0.0;
         #pragma unroll
-        for(int s = 0; s < NX; s++) acc += A[s + r * NX] * T[s + c * NX];
+        for(int s = 0; s < NX; s++) acc += A[s + r * LDX] * T[s + c * LDX];
         if(r != c) {
             #pragma unroll
-            for(int s = 0; s < NX; s++) acc += A[s + c * NX] * T[s + r * NX];
+            for(int s = 0; s < NX; s++) acc += A[s + c * LDX] * T[s + r * LDX];
             acc *= 0.5;
         }
         double v = (isxx ? F.cxx[e] : F.cuu[e]) + acc;
@@ -142,7 +148,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         if(regType == 2) {
             double acc = 0.0;
             #pragma unroll
-            for(int q = 0; q < NU; q++) acc += S.fu[sy(q, r)] * S.fu[sy(q, c)];
+            for(int q = 0; q < NU; q++) acc += S.fu[(sy(q, r) % NX) + (sy(q, r) / NX) * LDX] * S.fu[(sy(q, c) % NX) + (sy(q, c) / NX) * LDX];
             v += acc * lambda;
         }
         if(regType == 1 && r == c) v += lambda;
@@ -154,7 +160,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             const int i = j % NX, q = j / NX;
             double acc = 0.0;
             #pragma unroll
-            for(int s = 0; s < NX; s++) acc += S.fx[s + i * NX] * S.fu[s + q * NU];
+            for(int s = 0; s < NX; s++) acc += S.fx[s + i * LDX] * S.fu[((s + q * NU) % NX) + ((s + q * NU) / NX) * LDX];
             v += acc * lambda;
         }
         S.Qxur[j] = v;
@@ -216,7 +222,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
                 }
             }
         }
-        S.K[o] = v;
+        S.K[i + q * LDU] = v;
         Kout[o] = v;
     }
     for(int i = lane; i < NU; i += 64) lout[i] = S.l[i];
@@ -244,8 +250,8 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             const int oo = o - NU, r = oo % NU, c = oo / NU;
             double acc = 0.0;
             #pragma unroll
-            for(int s = 0; s < NU; s++) acc += S.Quu[sy(r, s)] * S.K[s + c * NU];
-            S.ba[oo] = acc;
+            for(int s = 0; s < NU; s++) acc += S.Quu[sy(r, s)] * S.K[s + c * LDU];
+            S.ba[r + c * LDU] = acc;
         }
     }
     __syncthreads();
@@ -256,10 +262,10 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             const int i = o;
             double d = 0.0;
             #pragma unroll
-            for(int s = 0; s < NU; s++) d += S.K[s + i * NU] * S.bc[s];
+            for(int s = 0; s < NU; s++) d += S.K[s + i * LDU] * S.bc[s];
             double v = S.Qx[i] + d;
             #pragma unroll
-            for(int j = 0; j < NU; j++) v += S.K[j + i * NU] * S.Qu[j];
+            for(int j = 0; j < NU; j++) v += S.K[j + i * LDU] * S.Qu[j];
             #pragma unroll
             for(int j = 0; j < NU; j++) v += S.Qxu[i + j * NX] * S.l[j];
             S.Vx[i] = v;
@@ -269,22 +275,22 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             tri_rc(e, r, c);
             double acc = 0.0;
             #pragma unroll
-            for(int s = 0; s < NU; s++) acc += S.K[s + r * NU] * S.ba[s + c * NU];
+            for(int s = 0; s < NU; s++) acc += S.K[s + r * LDU] * S.ba[s + c * LDU];
             if(r != c) {
                 #pragma unroll
-                for(int s = 0; s < NU; s++) acc += S.K[s + c * NU] * S.ba[s + r * NU];
+                for(int s = 0; s < NU; s++) acc += S.K[s + c * LDU] * S.ba[s + r * LDU];
                 acc *= 0.5;
             }
             double v = S.Qxx[e] + acc;
             // the reference's i-major loop touches packed entry (r,c) first as (i=r,j=c), then as (i=c,j=r)
             if(r == c) {
                 #pragma unroll
-                for(int q = 0; q < NU; q++) v += (S.K[q + r * NU] * S.Qxu[r + q * NX]) * 2.0;
+                for(int q = 0; q < NU; q++) v += (S.K[q + r * LDU] * S.Qxu[r + q * NX]) * 2.0;
             } else {
                 #pragma unroll
-                for(int q = 0; q < NU; q++) v += S.K[q + r * NU] * S.Qxu[c + q * NX];
+                for(int q = 0; q < NU; q++) v += S.K[q + r * LDU] * S.Qxu[c + q * NX];
                 #pragma unroll
-                for(int q = 0; q < NU; q++) v += S.K[q + c * NU] * S.Qxu[r + q * NX];
+                for(int q = 0; q < NU; q++) v += S.K[q + c * LDU] * S.Qxu[r + q * NX];
             }
             S.Vxx[e] = v;
         }
