@@ -1167,8 +1167,11 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
     for(int f = 0; f < ILQG_F_COUNT; f++) {
         if(WAVE_MAP && f == ILQG_F_DER) {
             // derivative records = device trajEl_t structs for as many trajectories as fit the budget
+            // budget: ILQG_WORK_GB if set, else half of the free device memory
             const char *e = getenv("ILQG_WORK_GB");
-            const double budget = (e ? atof(e) : 24.0) * 1e9;
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const double budget = e ? atof(e) * 1e9 : 0.5 * (double)free_b;
             const size_t per_traj = (size_t)d->N * sizeof(trajEl_t);
             size_t c = (size_t)(budget / (double)per_traj);
             if(c < 1) c = 1;
