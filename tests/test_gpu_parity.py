@@ -623,3 +623,86 @@ def test_properties_at_benchmark_size(ilqg, synth):
     assert np.array_equal(small.x(), s.x()[pick])
     # the closed loop is consistent: re-rolling with alpha = 0 reproduces the stored cost exactly
     s.close(); small.close()
+
+
+# ---------------------------------------------------------------------------
+# edge cases: failures, exits, degenerate sizes
+# ---------------------------------------------------------------------------
+def test_failure_paths_are_per_trajectory(ilqg, synth):
+    """NaN in one trajectory's inputs fails THAT trajectory (status 7, as iLQG_mex.c:116-118 reports a failed
+    initial roll-out) and leaves its neighbours in the same wavefront untouched"""
+    B, iters = 66, 3
+    x0, u0 = synth.car_batch(B, first=4000)
+    clean = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=iters))
+    clean.init(x0, u0)
+    clean.iterate(iters)
+    u_bad = u0.copy()
+    u_bad[5, 100, 0] = np.nan
+    x_bad = x0.copy()
+    x_bad[64, 3] = np.inf
+    s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=iters))
+    s.init(x_bad, u_bad)
+    st = s.ints("status")
+    assert st[5] == 7 and st[64] == 7 and np.all(np.delete(st, [5, 64]) == 0)
+    s.iterate(iters)
+    ok = np.ones(B, dtype=bool); ok[[5, 64]] = False
+    assert np.array_equal(s.scalar("cost")[ok], clean.scalar("cost")[ok])
+    assert np.array_equal(s.x()[ok], clean.x()[ok])
+    assert np.all(s.ints("status")[~ok] == 7) and np.all(s.success()[~ok] == 0)
+    s.close(); clean.close()
+
+
+@pytest.mark.parametrize("opts", [dict(max_iter=0), dict(max_iter=30, lambdaMax=0.5), dict(max_iter=40, lambdaInit=1e9, lambdaMax=1e10),
+                                  dict(max_iter=25, tolFun=0.5), dict(max_iter=8, alpha=[1.0, 0.5]), dict(max_iter=8, zMin=0.6)])
+def test_exit_conditions_match_oracle(ilqg, synth, oracle_built, opts):
+    """every way out of the outer loop (iLQG.c:365-378): iteration counts, return values and costs as the oracle's"""
+    B = 12
+    x0, u0 = synth.car_batch(B, first=6000)
+    s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=opts)
+    s.init(x0, u0)
+    s.solve()
+    assert s.active() == 0
+    its, succ, cost = s.ints("iterations"), s.success(), s.scalar("cost")
+    for b in range(B):
+        d = Driver(lib_path("oracle", full_ddp=0), 500, CAR_PARAMS, opts)
+        assert d.init(x0[b], u0[b]) == 1
+        rc = d.solve()
+        sc = d.scalars()
+        assert (int(its[b]), int(succ[b])) == (int(sc["iterations"]), rc), (opts, b, s.ints("status")[b])
+        assert close(cost[b], sc["cost"], 1e-8), (opts, b)
+        d.close()
+    s.close()
+
+
+def test_short_horizon_and_single_trajectory(ilqg, synth, oracle_built):
+    """n_hor = 2 (the smallest the solver accepts: g_norm divides by n_hor - 1) and B = 1"""
+    x0, u0 = synth.car_batch(1, n_hor=2, first=9)
+    s = ilqg.BatchSolver("carparking", 0, batch=1, n_hor=2, params=ilqg.CAR_PARAMS, opts=dict(max_iter=5))
+    s.init(x0, u0)
+    s.solve()
+    d = Driver(lib_path("oracle", full_ddp=0), 2, CAR_PARAMS, dict(max_iter=5))
+    assert d.init(x0[0], u0[0]) == 1
+    d.solve()
+    assert close(s.scalar("cost")[0], d.scalars()["cost"], 1e-12) and close(s.x()[0], d.traj(0)[0], 1e-12)
+    with pytest.raises(ilqg.IlqgError):
+        ilqg.BatchSolver("carparking", 0, batch=1, n_hor=1, params=ilqg.CAR_PARAMS)
+    with pytest.raises(ilqg.IlqgError):
+        ilqg.BatchSolver("carparking", 0, batch=0, n_hor=10, params=ilqg.CAR_PARAMS)
+    s.close()
+
+
+def test_option_and_parameter_errors(ilqg):
+    s = ilqg.BatchSolver("carparking", 0, batch=2, n_hor=10)
+    with pytest.raises(ilqg.IlqgError, match="parameter must be positive"):
+        s.set_option("tolFun", 0.0)
+    with pytest.raises(ilqg.IlqgError, match="no such parameter"):
+        s.set_option("w_pen_init", 1.0)
+    with pytest.raises(ilqg.IlqgError, match="monotonically"):
+        s.set_option("alpha", [1.0, 0.5, 0.5])
+    with pytest.raises(ilqg.IlqgError, match="not a parameter"):
+        s.set_param("nope", [1.0])
+    with pytest.raises(ilqg.IlqgError, match="vector length 4"):
+        s.set_param("cf", [1.0, 2.0])
+    with pytest.raises(ilqg.IlqgError, match="parameters not set"):
+        s.init(np.zeros((2, 4)), np.zeros((2, 10, 2)))  # parameters were never given
+    s.close()
