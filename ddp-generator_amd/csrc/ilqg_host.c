@@ -44,6 +44,7 @@ struct ilqg_batch {
     double alpha_store[ILQG_MAX_ALPHA];
     int resweep, fuse_derivs, ls_split;
     double **p;                      /* owned copies of the problem parameters */
+    char *p_given;                   /* which of them the caller has set */
     int params_pushed;
     char err[512];
 };
@@ -244,6 +245,7 @@ ilqg_batch_t *ilqg_batch_create(int device, int batch, int n_hor) {
         return NULL;
     }
     c->p = (double **)calloc(n_params > 0 ? n_params : 1, sizeof(double *));
+    c->p_given = (char *)calloc(n_params > 0 ? n_params : 1, 1);
     for(i = 0; i < n_params; i++) c->p[i] = (double *)calloc(param_len(c, i), sizeof(double));
     return c;
 }
@@ -254,6 +256,7 @@ void ilqg_batch_destroy(ilqg_batch_t *c) {
     ilqg_dev_destroy(c->dev);
     for(i = 0; i < n_params; i++) free(c->p[i]);
     free(c->p);
+    free(c->p_given);
     free(c);
 }
 
@@ -297,6 +300,7 @@ int ilqg_batch_set_param(ilqg_batch_t *c, const char *name, const double *value,
             return 1;
         }
         memcpy(c->p[i], value, sizeof(double) * n);
+        c->p_given[i] = 1;
         c->params_pushed = 0;
         return 0;
     }
@@ -326,6 +330,11 @@ static int push_config(ilqg_batch_t *c) {
     if(ilqg_dev_set_opts(c->dev, &d)) return fail(c, "options");
     if(!c->params_pushed) {
         int sizes[64];
+        for(i = 0; i < n_params; i++)  /* every parameter must be given, as in iLQG_mex.c:73-76 */
+            if(!c->p_given[i]) {
+                snprintf(c->err, sizeof(c->err), "Parameter name '%s' was not set.", paramdesc[i]->name);
+                return 1;
+            }
         if(n_params > 64) return fail_msg(c, "more than 64 problem parameters");
         for(i = 0; i < n_params; i++) sizes[i] = paramdesc[i]->size;
         if(ilqg_dev_set_params(c->dev, n_params, sizes, (const double *const *)c->p)) return fail(c, "parameters");
@@ -517,8 +526,9 @@ static ilqg_batch_t *backend_of(tOptSet *o, const char *who) {
     c->opt.w_pen_max_l = o->w_pen_max_l; c->opt.w_pen_max_f = o->w_pen_max_f;
     c->opt.w_pen_fact1 = o->w_pen_fact1; c->opt.w_pen_fact2 = o->w_pen_fact2;
     for(i = 0; i < n_params; i++) {
-        if(memcmp(c->p[i], o->p[i], sizeof(double) * param_len(c, i)) != 0) {
+        if(!c->p_given[i] || memcmp(c->p[i], o->p[i], sizeof(double) * param_len(c, i)) != 0) {
             memcpy(c->p[i], o->p[i], sizeof(double) * param_len(c, i));
+            c->p_given[i] = 1;
             c->params_pushed = 0;
         }
     }
