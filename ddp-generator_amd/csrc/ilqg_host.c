@@ -698,6 +698,55 @@ int boxQP(double *H, const double *g, const double *lower, const double *upper, 
     return rc;
 }
 
+/* ---- the reference's small dense helpers, executed on the device (matMult.h:11-14, cholesky.h:4-6) ---- */
+#include "cholesky.h"
+
+static void dense_call(const char *who, int op, int shape, const double *in0, int n0, const double *in1, int n1,
+                       const double *in2, int n2, double *out, int nout, int *flag) {
+    if(ilqg_dev_dense(env_device(), op, shape, in0, n0, in1, n1, in2, n2, out, nout, flag))
+        fatal_no_device(who, ilqg_dev_error());
+    if(*flag == -1) {
+        fprintf(stderr, "ilqg: %s: this size is not built into the device library of this problem\n", who);
+        abort();
+    }
+}
+
+#define TRI(n) (((n) * ((n) + 1)) / 2)
+
+void addMulVec(double base[], const double a[], const double b[], const int n_r, const int n_c) {
+    int flag, shape = (n_r == N_X && n_c == N_U) ? 0 : (n_r == N_X && n_c == N_X) ? 1 : -1;
+    if(shape < 0) { fprintf(stderr, "ilqg: addMulVec: sizes (%d,%d) not built\n", n_r, n_c); abort(); }
+    dense_call("addMulVec()", 0, shape, a, n_r, b, n_r * n_c, NULL, 0, base, n_c, &flag);
+}
+
+void addSquareTri(double base[], const double b[], const double a[], const int n_r, const int n_c, double ba[]) {
+    int flag, shape = (n_r == N_X && n_c == N_U) ? 0 : (n_r == N_X && n_c == N_X) ? 1 : (n_r == N_U && n_c == N_X) ? 2 : -1;
+    (void)ba;
+    if(shape < 0) { fprintf(stderr, "ilqg: addSquareTri: sizes (%d,%d) not built\n", n_r, n_c); abort(); }
+    dense_call("addSquareTri()", 1, shape, b, TRI(n_r), a, n_r * n_c, NULL, 0, base, TRI(n_c), &flag);
+}
+
+void addMul2Tri(double base[], const double b[], const double a[], const int n_ra, const int n_ca, const double c[],
+                const int n_rc, const int n_cc, double bc[]) {
+    int flag, shape = (n_ra == N_X && n_ca == N_X && n_rc == N_X && n_cc == N_U) ? 0
+                    : (n_ra == N_U && n_ca == N_X && n_rc == N_U && n_cc == 1) ? 2 : -1;
+    (void)bc;
+    if(shape < 0) { fprintf(stderr, "ilqg: addMul2Tri: sizes not built\n"); abort(); }
+    dense_call("addMul2Tri()", 2, shape, b, TRI(n_ra), a, n_ra * n_ca, c, n_rc * n_cc, base, n_ca * n_cc, &flag);
+}
+
+int cholesky_tri(const double *A, int n, double *L) {
+    int flag;
+    dense_call("cholesky_tri()", 3, n, A, TRI(n), NULL, 0, NULL, 0, L, TRI(n), &flag);
+    return flag;
+}
+
+void cholesky_tri_inv(const double *L_, double *invA, const int n, double *x) {
+    int flag;
+    (void)x;
+    dense_call("cholesky_tri_inv()", 4, n, L_, TRI(n), NULL, 0, NULL, 0, invA, TRI(n), &flag);
+}
+
 static void lambda_increase(tOptSet *o, double *dlambda) {
     *dlambda = max(*dlambda * o->lambdaFactor, o->lambdaFactor);
     o->lambda = max(o->lambda * *dlambda, o->lambdaMin);

@@ -981,6 +981,59 @@ __global__ void k_sincos_test(int n, const double *x, double *s, double *c) {
 #endif
 }
 
+// The reference's small dense helpers as callable entry points (matMult.h:11-14, cholesky.h:4-6), executed by
+// the same device templates the lane-mapped kernels use.  One problem on one lane; sizes are those of this
+// build's problem (matMult) resp. 1, 2, 3, 8 and N_U (Cholesky).
+enum { DENSE_MULVEC = 0, DENSE_SQUARETRI = 1, DENSE_MUL2TRI = 2, DENSE_CHOL = 3, DENSE_CHOLINV = 4 };
+
+template <int M>
+__device__ void dense_chol(int op, const double *in, double *out, int *flag) {
+    constexpr int T = tri(M);
+    double A[T], U[T];
+#pragma unroll
+    for(int i = 0; i < T; i++) A[i] = in[i];
+    if(op == DENSE_CHOL) {
+        *flag = chol_factor<M>(A, U) ? 1 : 0;  // on failure the content of L is unspecified (as in the reference)
+#pragma unroll
+        for(int i = 0; i < T; i++) out[i] = U[i];
+    } else {
+        chol_inverse<M>(A, U);
+#pragma unroll
+        for(int i = 0; i < T; i++) out[i] = U[i];
+    }
+}
+
+__global__ void k_dense_test(int op, int v0, int v1, int v2, const double *in0, const double *in1, const double *in2,
+                             double *out, int *flag) {
+    if(blockIdx.x || threadIdx.x) return;
+    *flag = 1;
+    if(op == DENSE_CHOL || op == DENSE_CHOLINV) {
+        switch(v0) {
+            case 1: dense_chol<1>(op, in0, out, flag); break;
+            case 2: dense_chol<2>(op, in0, out, flag); break;
+            case 3: dense_chol<3>(op, in0, out, flag); break;
+            case 8: dense_chol<8>(op, in0, out, flag); break;
+            default:
+                if(v0 == NU) dense_chol<NU>(op, in0, out, flag); else *flag = -1;
+        }
+        return;
+    }
+#if !ILQG_WAVE_MAP
+    // v0 selects the shape: 0 = (N_X, N_U), 1 = (N_X, N_X), 2 = (N_U, N_X) / (N_U, N_X, 1)
+    if(op == DENSE_MULVEC) {
+        if(v0 == 0) add_mul_vec<NX, NU>(out, in0, in1); else add_mul_vec<NX, NX>(out, in0, in1);
+    } else if(op == DENSE_SQUARETRI) {
+        if(v0 == 0) add_square_tri<NX, NU>(out, in0, in1);
+        else if(v0 == 1) add_square_tri<NX, NX>(out, in0, in1);
+        else add_square_tri<NU, NX>(out, in0, in1);
+    } else if(op == DENSE_MUL2TRI) {
+        if(v0 == 0) add_mul2_tri<NX, NX, NU>(out, in0, in1, in2); else add_mul2_tri<NU, NX, 1>(out, in0, in1, in2);
+    }
+#else
+    *flag = -1;
+#endif
+}
+
 // unit-test kernel for box_qp<M>, one problem per lane
 template <int M>
 __global__ __launch_bounds__(64, 1) void k_boxqp_test(int count, const double *H, const double *g, const double *lower, const double *upper,
@@ -1589,6 +1642,30 @@ int ilqg_dev_get_timing(ilqg_dev_t *d, int kernel, int *launches, double *total_
     if(drain_spans(d)) return 1;
     *launches = d->t_n[kernel];
     *total_ms = d->t_ms[kernel];
+    return 0;
+}
+
+// op / shape as in k_dense_test; in*/out are host arrays of n_in0/n_in1/n_in2/n_out doubles (out is in/out)
+int ilqg_dev_dense(int device, int op, int shape, const double *in0, int n_in0, const double *in1, int n_in1,
+                   const double *in2, int n_in2, double *out, int n_out, int *flag) {
+    HIP_TRY(hipSetDevice(device));
+    double *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *dout = nullptr;
+    int *dflag = nullptr;
+    HIP_TRY(hipMalloc((void **)&d0, (n_in0 > 0 ? n_in0 : 1) * 8));
+    HIP_TRY(hipMalloc((void **)&d1, (n_in1 > 0 ? n_in1 : 1) * 8));
+    HIP_TRY(hipMalloc((void **)&d2, (n_in2 > 0 ? n_in2 : 1) * 8));
+    HIP_TRY(hipMalloc((void **)&dout, (n_out > 0 ? n_out : 1) * 8));
+    HIP_TRY(hipMalloc((void **)&dflag, 4));
+    if(n_in0 > 0) HIP_TRY(hipMemcpy(d0, in0, n_in0 * 8, hipMemcpyHostToDevice));
+    if(n_in1 > 0) HIP_TRY(hipMemcpy(d1, in1, n_in1 * 8, hipMemcpyHostToDevice));
+    if(n_in2 > 0) HIP_TRY(hipMemcpy(d2, in2, n_in2 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dout, out, n_out * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dense_test, dim3(1), dim3(64), 0, 0, op, shape, 0, 0, d0, d1, d2, dout, dflag);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, n_out * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(flag, dflag, 4, hipMemcpyDeviceToHost));
+    hipFree(d0); hipFree(d1); hipFree(d2); hipFree(dout); hipFree(dflag);
     return 0;
 }
 

@@ -33,7 +33,8 @@ def test_library_exports_declared_symbols(built, fd):
     # (forward_pass, calc_derivs, init_opt, ...) is exported by the linked problem file
     wanted |= {"iLQG", "standard_parameters", "setOptParam", "makeCandidateNominal", "printParams", "back_pass",
                "line_search", "boxQP", "forward_pass", "calc_derivs", "init_opt", "update_multipliers",
-               "ilqg_release", "printVec", "printTri", "printMat"}
+               "ilqg_release", "printVec", "printTri", "printMat", "addMulVec", "addSquareTri", "addMul2Tri",
+               "cholesky_tri", "cholesky_tri_inv"}
     assert len(wanted) > 40
     missing = [n for n in sorted(wanted) if not hasattr(lib, n)]
     assert not missing, missing

@@ -127,6 +127,35 @@ def test_device_sincos_accuracy(ilqg):
     assert np.all(np.isnan(s)) and np.all(np.isnan(c))
 
 
+def test_dropin_dense_helpers_golden(ilqg):
+    """the reference's matMult / Cholesky symbols exported by the product library run the device templates"""
+    import os
+    from conftest import ROOT
+    from oracle.harness import Kernels
+    g = golden("kernels.npz")
+    K = Kernels(ilqg.library_path("carparking", 0))
+    p = lambda k: g["mm_car_" + k]
+    assert close(K.add_mul_vec(p("base_u"), p("vx"), p("fu"), 4, 2), p("mulvec"), 1e-13)
+    assert close(K.add_square_tri(p("base_uu"), p("V"), p("fu"), 4, 2), p("sq_uu"), 1e-13)
+    assert close(K.add_square_tri(p("base_xx"), p("V"), p("fx"), 4, 4), p("sq_xx"), 1e-13)
+    assert close(K.add_mul2_tri(p("base_xu"), p("V"), p("fx"), 4, 4, p("fu"), 4, 2), p("mul2"), 1e-13)
+    for n, A, ok, U, inv in zip(g["chol_n"], g["chol_A"], g["chol_ok"], g["chol_U"], g["chol_inv"]):
+        t = tri(int(n))
+        ok2, U2 = K.cholesky(A[:t].copy(), int(n))
+        assert ok2 == ok
+        if ok:
+            assert close(U2, U[:t], 1e-13)
+            assert close(K.cholesky_inv(U[:t].copy(), int(n)), inv[:t], 1e-11)
+    # boxQP through the reference's own signature (free-block numbering of invHfree)
+    sel = np.nonzero((g["qp_n"] == 2) & (g["qp_rc"] == 5))[0][:3]
+    for i in sel:
+        r = K.boxqp(g["qp_H"][i][:3], g["qp_g"][i][:2], g["qp_lo"][i][:2], g["qp_hi"][i][:2], g["qp_x0"][i][:2])
+        assert r["rc"] == 5 and np.array_equal(r["clamp"], g["qp_clamp"][i][:2])
+        nf = r["n_free"]
+        scale = max(1.0, np.abs(g["qp_invH"][i][:tri(nf)]).max())
+        assert np.all(np.abs(r["invH"][:tri(nf)] - g["qp_invH"][i][:tri(nf)]) <= 1e-9 * scale)
+
+
 def test_boxqp_random_vs_oracle(ilqg, oracle_built):
     from oracle.harness import Kernels
     K = Kernels(lib_path("oracle"))
