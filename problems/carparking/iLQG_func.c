@@ -296,12 +296,12 @@ static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
 
     daux_ds_x3= p[4][0]*(p[4][0]*x[3]*(sin(u[0])*sin(u[0]))/sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0]))) + cos(u[0]));
     if(isNANorINF(daux_ds_x3)) { PRNT("    @k %d: daux_ds_x3 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_ds_x3); return 0; }
-    daux_ds_u0= p[4][0]*x[3]*((1.0/2.0)*sqrt(2.0)*p[4][0]*x[3]*sin(2.0*u[0])/sqrt(2.0*(p[3][0]*p[3][0]) + (p[4][0]*p[4][0])*(x[3]*x[3])*cos(2.0*u[0]) - (p[4][0]*p[4][0])*(x[3]*x[3])) - sin(u[0]));
+    daux_ds_u0= p[4][0]*x[3]*(sqrt(2.0)*p[4][0]*x[3]*sin(u[0])*cos(u[0])/sqrt(2.0*(p[3][0]*p[3][0]) + (p[4][0]*p[4][0])*(x[3]*x[3])*(2.0*(cos(u[0])*cos(u[0])) - 1.0) - (p[4][0]*p[4][0])*(x[3]*x[3])) - sin(u[0]));
     if(isNANorINF(daux_ds_u0)) { PRNT("    @k %d: daux_ds_u0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_ds_u0); return 0; }
 #if FULL_DDP
     daux_ds_x3x3= (p[3][0]*p[3][0])*(p[4][0]*p[4][0])*(sin(u[0])*sin(u[0]))/(((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0])))*sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0]))));
     if(isNANorINF(daux_ds_x3x3)) { PRNT("    @k %d: daux_ds_x3x3 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_ds_x3x3); return 0; }
-    daux_ds_u0u0= (1.0/4.0)*(p[4][0]*p[4][0]*p[4][0]*p[4][0])*(x[3]*x[3]*x[3]*x[3])*(sin(2.0*u[0])*sin(2.0*u[0]))/(((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0])))*sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0])))) + (p[4][0]*p[4][0])*(x[3]*x[3])*cos(2.0*u[0])/sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0]))) - p[4][0]*x[3]*cos(u[0]);
+    daux_ds_u0u0= (1.0/4.0)*p[4][0]*x[3]*((1.0/4.0)*sqrt(2.0)*(p[4][0]*p[4][0]*p[4][0])*(x[3]*x[3]*x[3])*(-8.0*(cos(u[0])*cos(u[0])*cos(u[0])*cos(u[0])) + 8.0*(cos(u[0])*cos(u[0])))*sqrt(2.0*(p[3][0]*p[3][0]) + (p[4][0]*p[4][0])*(x[3]*x[3])*(2.0*(cos(u[0])*cos(u[0])) - 1.0) - (p[4][0]*p[4][0])*(x[3]*x[3])) + 4.0*p[4][0]*x[3]*(((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0])))*sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0]))))*(2.0*(cos(u[0])*cos(u[0])) - 1.0) - 4.0*(((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0])))*((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0]))))*cos(u[0]))/(((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0])))*((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0]))));
     if(isNANorINF(daux_ds_u0u0)) { PRNT("    @k %d: daux_ds_u0u0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_ds_u0u0); return 0; }
     daux_ds_u0x3= (p[4][0]*p[4][0]*p[4][0]*p[4][0])*(x[3]*x[3]*x[3])*(sin(u[0])*sin(u[0])*sin(u[0]))*cos(u[0])/(((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0])))*sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0])))) + 2.0*(p[4][0]*p[4][0])*x[3]*sin(u[0])*cos(u[0])/sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(sin(u[0])*sin(u[0]))) - p[4][0]*sin(u[0]);
     if(isNANorINF(daux_ds_u0x3)) { PRNT("    @k %d: daux_ds_u0x3 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_ds_u0x3); return 0; }

@@ -125,6 +125,16 @@ def cexpr(e):
     return _printer.doprint(e)
 
 
+def _tidy(e):
+    """simplify, then undo the multiple-angle forms simplify likes to introduce (sin(2w), cos(2w)):
+    every distinct trig argument costs a separate argument reduction at run time"""
+    e = sp.simplify(e)
+    if any(isinstance(a, (sp.sin, sp.cos)) and a.args[0].is_Mul and a.args[0].as_coeff_Mul()[0] != 1
+           for a in e.atoms(sp.sin, sp.cos)):
+        e = sp.expand_trig(e)
+    return e
+
+
 def utri(r, c):
     return c * (c + 1) // 2 + r
 
@@ -177,7 +187,7 @@ class Deriver:
         # canonical name: aux name + sorted variable tags
         d = self.total_diff(self.defs[s], z)
         if not self.prob.fast:
-            d = sp.simplify(d)
+            d = _tidy(d)
         if d == 0:
             self.dcache[key] = sp.Integer(0)
             return self.dcache[key]
@@ -270,7 +280,7 @@ class Emitter:
             raise ValueError("F may not depend on u")  # genenerator_main.mac:127-128
         self.Fx = [td(p.F, x[r]) for r in range(n)]
         self.Fxx = [[td(self.Fx[r], x[c]) for c in range(n)] for r in range(n)]
-        simp = (lambda e: e) if p.fast else (lambda e: sp.simplify(e) if e != 0 else e)
+        simp = (lambda e: e) if p.fast else (lambda e: _tidy(e) if e != 0 else e)
         for name in ("fx", "fu", "Lxx", "Luu", "Lxu", "Fxx"):
             setattr(self, name, [[simp(e) for e in row] for row in getattr(self, name)])
         for name in ("fxx", "fuu", "fxu"):
