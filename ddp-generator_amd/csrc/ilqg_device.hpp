@@ -302,7 +302,7 @@ struct RecLayout {
 // r: derivative record of this step (registers), uk: nominal control,
 // Vx/Vxx: value function of step k+1 in, of step k out, l: warm start in /
 // feed-forward out, K: feedback gains out (NU x NX column-major).
-// Returns the box-QP code (< 1 means the sweep must be abandoned).
+// Returns the box-QP code (< 1 means the sweep must be abandoned: the outputs are then meaningless).
 template <int NX, int NU, bool FULL, bool HX>
 ILQG_DEV int back_step(const double *r, const double *uk, double *Vx, double *Vxx, double *l, double *K,
                        const double lambda, const int regType, double &dV0, double &dV1, double &gsum) {
@@ -394,7 +394,10 @@ ILQG_DEV int back_step(const double *r, const double *uk, double *Vx, double *Vx
     int clamp[NU], n_free;
     double invH[SUU];
     const int rc = box_qp<NU>(QuuF, Qu, lower, upper, l, clamp, n_free, invH);
-    if(rc < 1) return rc;
+    // No early return on rc < 1 (back_pass.c:168-171 abandons the sweep there): the rest of the step is
+    // evaluated for every lane and the CALLER drops the lanes with rc < 1 afterwards.  A divergent return
+    // here would put everything below under its own exec-mask region, cut off from the code the caller
+    // places behind this step (the derivative evaluation of the next step, which overlaps with it).
 
     // feedback gains (back_pass.c:175-201)
 #pragma unroll

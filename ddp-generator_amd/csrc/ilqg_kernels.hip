@@ -33,15 +33,60 @@
 // NaN/Inf guards in generated code still `return 0`; their printing is dropped on the device
 #define PRNT(...) ((void)0)
 
+// ---------------------------------------------------------------------------
+// Hooks of the generated code on the device.
+//
+// Every non-constant assignment of a generated callback is followed by
+//     if(isNANorINF(v)) { PRNT(...); return 0; }              (genenerator_main.mac:193-198)
+// with isNANorINF(v) = (mxIsNaN(v) || mxIsInf(v))               (iLQG_problem.tem:11).
+// Compiled literally that is one branch per assignment (52 in the CarParking file): the inlined
+// callbacks fall apart into dozens of small basic blocks, each a VALU->SALU round trip, and the
+// scheduler cannot overlap anything across them.  mex.h is ours, so on the device mxIsNaN()
+// RECORDS a non-finite value in a per-lane sticky flag and evaluates to 0: the callbacks become
+// straight-line code that always returns 1, and the caller tests the flag once per time step.
+// The flag is a double that stays 0.0 until the first NaN/Inf is folded in (v*0.0 is NaN for
+// both), i.e. exactly "some guarded value was NaN or Inf" — the condition under which the
+// reference's callback returns 0.  What differs is only that the remaining assignments of a failed
+// step are still evaluated (their results are discarded with the step).
+//
+// The flag has to be reachable from inside the generated functions without changing them: every
+// guard sits in a function that has the parameter table `double **p` in scope
+// (iLQG_func.tem:43-467), and on the device that table is a private array owned by the kernel,
+// so the slots in front of it, p[-1], p[-2], p[-3], carry pointers to the lane's hook variables.
+// After inlining and SROA they are plain registers.
+// ---------------------------------------------------------------------------
+struct ilqg_hooks {
+    double nonfinite;  // p[-1]: 0.0, or NaN once a guarded value was NaN/Inf
+    double huge;       // p[-2]: != 0 once sin/cos saw an argument the straight-line path cannot reduce
+    double slow;       // p[-3]: != 0: sin/cos go to the device library (the rarely taken re-evaluation)
+};
+#include "ilqg_param_layout.h"  // generated at build time from the problem's paramdesc[]: ILQG_NP, sizes, offsets
+#define ILQG_HOOK_SLOTS 3
+#define ILQG_HOOK_NONFINITE (ILQG_NP)
+#define ILQG_HOOK_HUGE (ILQG_NP + 1)
+#define ILQG_HOOK_SLOW (ILQG_NP + 2)
+
+__device__ __forceinline__ int ilqg_note_nonfinite(double **p, double v) {
+    double *f = p[ILQG_HOOK_NONFINITE];
+    *f = v * 0.0 + *f;
+    return 0;
+}
+#undef mxIsNaN
+#undef mxIsInf
+#define mxIsNaN(v) ilqg_note_nonfinite(p, (v))
+#define mxIsInf(v) 0
+
 // The generated callbacks call sin(x) and cos(x) of the same few arguments many times, spread
 // over several functions (calcXUVariableAux, ddpf, bp_derivsL, ...).  The device math
 // library's sin/cos contain branches (huge-argument reduction), so once the callbacks are
 // inlined into a kernel every call is a separate ~130-instruction body the optimiser cannot
 // merge; and a non-inlined helper would stall on the function-call ABI's `s_waitcnt vmcnt(0)`.
-// ilqg_sincos below is STRAIGHT-LINE code for |x| < 8e5 (anything larger, NaN and Inf go to
-// the library through a rarely taken branch), so value numbering merges all evaluations of
-// the same argument: one argument reduction + one sine and one cosine polynomial per distinct
-// argument and loop iteration.
+// ilqg_sincos below is STRAIGHT-LINE code, exact to < 1 ulp for |x| < 8e5, so value numbering
+// merges all evaluations of the same argument: one argument reduction + one sine and one cosine
+// polynomial per distinct argument and loop iteration.  Anything it cannot reduce (|x| >= 8e5;
+// NaN and Inf give NaN here as in the library) raises the lane's `huge` hook; the kernel then
+// evaluates that time step again with the `slow` hook set, which routes every sin/cos of the
+// step to the device library.
 //
 // Algorithm: Cody-Waite reduction with pi/2 split into three 33-bit pieces, always carried to
 // the third piece (the medium-size path of fdlibm's e_rem_pio2.c), then the minimax kernels of
@@ -57,7 +102,7 @@ __device__ __attribute__((noinline)) static ilqg_sc ilqg_sincos_slow(double x) {
     return r;
 }
 
-__device__ __forceinline__ static ilqg_sc ilqg_sincos(double x) {
+__device__ __forceinline__ static ilqg_sc ilqg_sincos_fast(double x) {
     const double fn = rint(x * 6.36619772367581382433e-01);
     // x - fn*(P1 + P2 + P3 + P3t) as y0 + y1; P1, P2, P3 have 33 significant bits each, so the
     // products fn*Pi are exact for |fn| < 2^20; e1, e2 are the rounding errors of the two subtractions
@@ -92,8 +137,22 @@ __device__ __forceinline__ static ilqg_sc ilqg_sincos(double x) {
     out.c = (q & 1) ? ks : kc;
     if(q == 1 || q == 2) out.c = -out.c;
     if(q >= 2) out.s = -out.s;
-    if(!(fabs(x) < 8.0e5)) out = ilqg_sincos_slow(x);  // huge arguments, NaN, Inf: device library
     return out;
+}
+
+// stand-alone form (unit test, large generated files): library for what the fast path cannot reduce
+__device__ __forceinline__ static ilqg_sc ilqg_sincos(double x) {
+    ilqg_sc out = ilqg_sincos_fast(x);
+    if(!(fabs(x) < 8.0e5)) out = ilqg_sincos_slow(x);
+    return out;
+}
+
+// form used by the generated code of small problems: no branch, hooks instead (see above)
+__device__ __forceinline__ static ilqg_sc ilqg_sincos_hooked(double **p, double x) {
+    if(*p[ILQG_HOOK_SLOW] != 0.0) return ilqg_sincos_slow(x);  // compile-time constant per copy of the step
+    double *h = p[ILQG_HOOK_HUGE];
+    *h = (fabs(x) < 8.0e5) ? *h : 1.0;
+    return ilqg_sincos_fast(x);
 }
 #if defined(ILQG_SINCOS_CALL)
 // Large generated files (thousands of sin/cos call sites, e.g. the tensors of an n = 16 problem): keep
@@ -103,8 +162,8 @@ __device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_call(doub
 #define sin(x) (ilqg_sincos_call(x).s)
 #define cos(x) (ilqg_sincos_call(x).c)
 #else
-#define sin(x) (ilqg_sincos(x).s)
-#define cos(x) (ilqg_sincos(x).c)
+#define sin(x) (ilqg_sincos_hooked(p, (x)).s)
+#define cos(x) (ilqg_sincos_hooked(p, (x)).c)
 #endif
 #endif
 
@@ -129,7 +188,6 @@ extern "C" {
 
 #include "ilqg_device.hpp"
 #include "ilqg_wave.hpp"
-#include "ilqg_param_layout.h"  // generated at build time from the problem's paramdesc[]
 #include "ilqg_shim.h"
 
 namespace {
@@ -172,43 +230,80 @@ struct DevPtrs {
     int B, Bp, N;
 };
 
-// element (step k, component i of W) of trajectory b in a per-step field of `steps` steps:
-// lane mapping [k][i][b] (batch-innermost), wave mapping [b][k][i] (trajectory-major)
+// Nothing may be in flight when a prefetching loop is entered: the compiler's wait-count pass
+// merges the state of the loop entry with that of the back edge, and a load still pending from
+// before the loop makes it wait for EVERYTHING (vmcnt(0)) at the first use inside the loop, i.e.
+// right behind the prefetch of the next step, which would then never overlap with the arithmetic.
+__device__ __forceinline__ void drain_memory_ops() { __builtin_amdgcn_s_waitcnt(0); }
+
+// "this value is needed HERE": keeps the optimiser from sinking its computation into a later block
+__device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
+
+// Layout of a per-step field of width W (doubles per step and trajectory) with `steps` time steps.
+//   lane mapping: [step][tile of 64 trajectories][component][trajectory in tile] — the 64 lanes of a
+//                 wavefront read one component as 512 contiguous bytes, the components of a step sit
+//                 at FIXED distances of 512 bytes (instruction immediates), and one pointer per field,
+//                 advanced by W*Bp doubles per step, addresses everything a lane touches;
+//   wave mapping: [trajectory][step][component] (trajectory-major, = the host layout).
+constexpr int SI = WAVE_MAP ? 1 : WAVE;  // distance between components
+__device__ __forceinline__ size_t step_stride(const DevPtrs &P, int W) { return WAVE_MAP ? (size_t)W : (size_t)W * P.Bp; }
+__device__ __forceinline__ size_t traj_off(const DevPtrs &P, int W, int steps, int b) {
+    return WAVE_MAP ? (size_t)b * steps * W : (size_t)(b >> 6) * (W * WAVE) + (b & 63);
+}
+// component i of a width-W, single-step field that is tiled in BOTH mappings (per-step-size costs)
+__device__ __forceinline__ size_t tile_ix(int W, int i, int b) { return (size_t)(b >> 6) * (W * WAVE) + (size_t)i * WAVE + (b & 63); }
+// element (step k, component i of W) of trajectory b
 __device__ __forceinline__ size_t ix(const DevPtrs &P, int W, int steps, int k, int i, int b) {
-    return WAVE_MAP ? ((size_t)b * steps + k) * W + i : ((size_t)k * W + i) * (size_t)P.Bp + b;
+    return traj_off(P, W, steps, b) + (size_t)k * step_stride(P, W) + (size_t)i * SI;
 }
 
 // Per-lane snapshot of the problem parameters.  The generated callbacks read parameters as
 // p[i][j] through a `double **`; read from global memory, every such value would have to be
 // re-loaded after each store of the kernel (the compiler cannot prove that the parameter
 // arrays do not alias the output arrays), which costs two dependent memory round trips per
-// use.  Fixed-size parameters are therefore copied once into a private array that the
-// optimiser keeps in registers; per-time-step parameters (size -1) stay in global memory.
+// use.  Fixed-size parameters are therefore passed BY VALUE as a kernel argument (ParamValues)
+// and copied into a private array: after SROA every p[i][j] is a wave-uniform value that was
+// loaded once from the kernel-argument segment by a scalar load, i.e. it lives in an SGPR and
+// costs no vector register.  Per-time-step parameters (size -1) stay in global memory.
 struct ParamValues {
     double v[ILQG_PTOTAL];
 };
 struct ParamTable {
-    double *ptr[ILQG_NP > 0 ? ILQG_NP : 1];
+    double *ptr[ILQG_NP + ILQG_HOOK_SLOTS];  // the problem's parameters, then the hooks (see ilqg_hooks)
 };
-__device__ __forceinline__ void load_params(ParamValues &V, ParamTable &T, double **p) {
+__device__ __forceinline__ void load_params(ParamValues &V, ParamTable &T, ilqg_hooks &H, const ParamValues &A,
+                                            double **p) {
     constexpr int sizes[ILQG_NP > 0 ? ILQG_NP : 1] = ILQG_PSIZES;
     constexpr int offs[ILQG_NP > 0 ? ILQG_NP : 1] = ILQG_POFFSETS;
 #pragma unroll
     for(int i = 0; i < ILQG_NP; i++) {
-        double *src = p[i];
         if(sizes[i] > 0) {
 #pragma unroll
-            for(int j = 0; j < sizes[i]; j++) V.v[offs[i] + j] = src[j];
+            for(int j = 0; j < sizes[i]; j++) V.v[offs[i] + j] = A.v[offs[i] + j];
             T.ptr[i] = &V.v[offs[i]];
         } else {
-            T.ptr[i] = src;
+            T.ptr[i] = p[i];
         }
     }
+    H.nonfinite = 0.0;
+    H.huge = 0.0;
+    H.slow = 0.0;
+    T.ptr[ILQG_HOOK_NONFINITE] = &H.nonfinite;
+    T.ptr[ILQG_HOOK_HUGE] = &H.huge;
+    T.ptr[ILQG_HOOK_SLOW] = &H.slow;
 }
 
-__device__ __forceinline__ void make_optset(tOptSet &o, const DevPtrs &P, const ilqg_dev_opts_t &O,
-                                            ParamValues &V, ParamTable &T) {
-    load_params(V, T, P.p);
+// What a kernel needs to call the generated callbacks.  Four separate private objects, each pointing
+// only at the next (o -> table -> values, hooks): the optimiser dissolves them one level at a time into
+// registers; a single struct holding pointers into itself would stay in scratch memory.
+struct Callbacks {
+    tOptSet o;   // what the callbacks see as `o` (p, n_hor, penalty weights)
+    tOptSet o1;  // the same with n_hor = 1: init_running loops over n_hor elements
+};
+__device__ __forceinline__ void make_callbacks(Callbacks &C, ParamTable &T, ParamValues &V, ilqg_hooks &H,
+                                               const DevPtrs &P, const ilqg_dev_opts_t &O, const ParamValues &A) {
+    load_params(V, T, H, A, P.p);
+    tOptSet &o = C.o;
     o.p = T.ptr;
     o.n_hor = P.N;
     o.w_pen_l = O.w_pen_init_l;
@@ -218,12 +313,22 @@ __device__ __forceinline__ void make_optset(tOptSet &o, const DevPtrs &P, const 
     o.w_pen_fact2 = O.w_pen_fact2;
     o.w_pen_max_l = O.w_pen_max_l;
     o.w_pen_max_f = O.w_pen_max_f;
+    C.o1 = o;
+    C.o1.n_hor = 1;
 }
+// declares the callback context C and the lane's hooks H of a kernel with arguments (P, O, A)
+#define ILQG_CALLBACKS(C, H) \
+    ParamValues C##_values;  \
+    ParamTable C##_table;    \
+    ilqg_hooks H;            \
+    Callbacks C;             \
+    make_callbacks(C, C##_table, C##_values, H, P, O, A)
 
 // ---------------------------------------------------------------------------
-// host layout [b][k][f]  <->  device layout [k][f][b]
+// host layout [b][k][f]  <->  device layout [k][b/64][f][b%64] of the lane mapping (the wave mapping's
+// trajectory-major fields are copied without a kernel)
 // ---------------------------------------------------------------------------
-__global__ void k_to_soa(const double *__restrict__ aos, double *__restrict__ soa, int B, int Bp, int steps, int wh,
+__global__ void k_to_dev(const double *__restrict__ host, double *__restrict__ dev, int B, int Bp, int steps, int wh,
                          int wd) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)B * steps * wd;
@@ -231,175 +336,209 @@ __global__ void k_to_soa(const double *__restrict__ aos, double *__restrict__ so
     const int fcol = (int)(i % wd);
     const int k = (int)((i / wd) % steps);
     const int b = (int)(i / ((size_t)wd * steps));
-    soa[((size_t)k * wd + fcol) * Bp + b] = aos[((size_t)b * steps + k) * wh + fcol];
+    dev[(size_t)k * wd * Bp + (size_t)(b >> 6) * (wd * WAVE) + (size_t)fcol * WAVE + (b & 63)] =
+        host[((size_t)b * steps + k) * wh + fcol];
 }
 
-__global__ void k_to_aos(const double *__restrict__ soa, double *__restrict__ aos, int B, int Bp, int steps, int wh,
-                         int wd) {
+__global__ void k_from_dev(const double *__restrict__ dev, double *__restrict__ host, int B, int Bp, int steps, int wh,
+                           int wd) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)B * steps * wh;
     if(i >= total) return;
     const int fcol = (int)(i % wh);
     const int k = (int)((i / wh) % steps);
     const int b = (int)(i / ((size_t)wh * steps));
-    aos[i] = (fcol < wd) ? soa[((size_t)k * wd + fcol) * Bp + b] : 0.0;
+    host[i] = (fcol < wd) ? dev[(size_t)k * wd * Bp + (size_t)(b >> 6) * (wd * WAVE) + (size_t)fcol * WAVE + (b & 63)] : 0.0;
 }
 
 #if !ILQG_WAVE_MAP
 // ---------------------------------------------------------------------------
+// The reference's calc_derivs body for one time step (iLQG_func.tem:207-211), from (x_k, u_k) in t.
+// Auxiliaries are not kept in HBM: they are recomputed from (x,u) exactly as forward_pass did
+// (iLQG_func.tem:160-164).  Straight-line code (see ilqg_hooks); evaluated a second time through the
+// device library's sin/cos in the rare case that an argument was beyond the fast reduction.
+// ---------------------------------------------------------------------------
+// `overlapped` is called between the evaluation and the test for the rare second evaluation: a caller
+// that has independent work in flight pins its results there, so that both share one basic block.
+template <class F>
+__device__ __forceinline__ int derivs_step(trajEl_t &t, Callbacks &C, ilqg_hooks &H, int k, int N, F &&overlapped) {
+    double x[NX], u[NU];
+#pragma unroll
+    for(int i = 0; i < NX; i++) x[i] = t.x[i];
+#pragma unroll
+    for(int i = 0; i < NU; i++) u[i] = t.u[i];
+    const double nf0 = H.nonfinite;
+    H.huge = 0.0;
+    int ok = 1;
+    auto body = [&]() {
+        ok = calcXVariableAux(&t, nullptr, k, &C.o);
+        ok &= calcXUVariableAux(&t, nullptr, k, &C.o);
+        ok &= calcLAuxDeriv(&t, nullptr, k, &C.o);
+        ok &= bp_derivsL(&t, k, C.o.p);
+        limitsU(&t, k, C.o.p, N);
+    };
+    body();
+    overlapped();
+    if(H.huge != 0.0) {
+#pragma unroll
+        for(int i = 0; i < NX; i++) t.x[i] = x[i];
+#pragma unroll
+        for(int i = 0; i < NU; i++) t.u[i] = u[i];
+        H.nonfinite = nf0;
+        H.slow = 1.0;
+        body();
+        H.slow = 0.0;
+    }
+    return ok;
+}
+
+__device__ __forceinline__ int derivs_final(trajFin_t &fin, Callbacks &C, ilqg_hooks &H, int N) {
+    double x[NX];
+#pragma unroll
+    for(int i = 0; i < NX; i++) x[i] = fin.x[i];
+    const double nf0 = H.nonfinite;
+    H.huge = 0.0;
+    int ok = 1;
+    auto body = [&]() {
+        ok = calcFVariableAux(&fin, nullptr, &C.o);
+        ok &= calcFAuxDeriv(&fin, nullptr, &C.o);
+        ok &= bp_derivsF(&fin, N, C.o.p);
+    };
+    body();
+    if(H.huge != 0.0) {
+#pragma unroll
+        for(int i = 0; i < NX; i++) fin.x[i] = x[i];
+        H.nonfinite = nf0;
+        H.slow = 1.0;
+        body();
+        H.slow = 0.0;
+    }
+    return ok;
+}
+
+// record of one step in the order of RecLayout
+#define REC_COPY(OP, t)                                                                                 \
+    OP(RL::CX, (t).cx, NX) OP(RL::CXX, (t).cxx, SXX) OP(RL::CU, (t).cu, NU) OP(RL::CUU, (t).cuu, SUU)  \
+    OP(RL::CXU, (t).cxu, NXU) OP(RL::FX, (t).fx, NX * NX) OP(RL::FU, (t).fu, NXU)                      \
+    OP(RL::LOWER, (t).lower, NU) OP(RL::UPPER, (t).upper, NU) REC_COPY_FULL(OP, t)                      \
+    if(HX) {                                                                                            \
+        OP(RL::LSIGN, (t).lower_sign, NU) OP(RL::USIGN, (t).upper_sign, NU)                             \
+        OP(RL::LHX, (t).lower_hx, NXU) OP(RL::UHX, (t).upper_hx, NXU)                                   \
+    }
+#if FULL_DDP
+#define REC_COPY_FULL(OP, t) OP(RL::FXX, (t).fxx, NX * SXX) OP(RL::FUU, (t).fuu, NX * SUU) OP(RL::FXU, (t).fxu, NX * NXU)
+#else
+#define REC_COPY_FULL(OP, t)
+#endif
+
+// ---------------------------------------------------------------------------
 // calc_derivs: one lane per (trajectory, time step); step N is the final record
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O) {
+__global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O, ParamValues A) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = (int)(tid % P.Bp);
     const int k = (int)(tid / P.Bp);
     if(k > P.N || b >= P.B) return;
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_NEED_DERIVS][b]) return;
-    const size_t Bp = P.Bp;
 
-    tOptSet o;
-    ParamValues pval;
-    ParamTable ptab;
-    make_optset(o, P, O, pval, ptab);
+    ILQG_CALLBACKS(C, H);
     int ok = 1;
     if(k < P.N) {
-        tOptSet o1 = o;
-        o1.n_hor = 1;  // init_running loops over n_hor elements: write this element's constants only
         trajEl_t t;
-        init_running(&t, &o1);
+        init_running(&t, &C.o1);
+        const double *xs = P.f[ILQG_F_X] + ix(P, NX, P.N + 1, k, 0, b);
+        const double *us = P.f[ILQG_F_U] + ix(P, NU, P.N, k, 0, b);
 #pragma unroll
-        for(int i = 0; i < NX; i++) t.x[i] = P.f[ILQG_F_X][((size_t)k * NX + i) * Bp + b];
+        for(int i = 0; i < NX; i++) t.x[i] = xs[i * SI];
 #pragma unroll
-        for(int i = 0; i < NU; i++) t.u[i] = P.f[ILQG_F_U][((size_t)k * NU + i) * Bp + b];
-        // auxiliaries are not kept in HBM: recompute them from the stored (x,u) exactly as
-        // forward_pass did (iLQG_func.tem:160-164), then the reference's calc_derivs body
-        ok &= calcXVariableAux(&t, nullptr, k, &o);
-        ok &= calcXUVariableAux(&t, nullptr, k, &o);
-        ok &= calcLAuxDeriv(&t, nullptr, k, &o);
-        ok &= bp_derivsL(&t, k, o.p);
-        limitsU(&t, k, o.p, P.N);
-
-        double *out = P.f[ILQG_F_DER] + (size_t)k * REC * Bp + b;
-#define PUT(off, arr, cnt) \
-    _Pragma("unroll") for(int i = 0; i < (cnt); i++) out[(size_t)((off) + i) * Bp] = (arr)[i];
-        PUT(RL::CX, t.cx, NX)
-        PUT(RL::CXX, t.cxx, SXX)
-        PUT(RL::CU, t.cu, NU)
-        PUT(RL::CUU, t.cuu, SUU)
-        PUT(RL::CXU, t.cxu, NXU)
-        PUT(RL::FX, t.fx, NX * NX)
-        PUT(RL::FU, t.fu, NXU)
-        PUT(RL::LOWER, t.lower, NU)
-        PUT(RL::UPPER, t.upper, NU)
-#if FULL_DDP
-        PUT(RL::FXX, t.fxx, NX * SXX)
-        PUT(RL::FUU, t.fuu, NX * SUU)
-        PUT(RL::FXU, t.fxu, NX * NXU)
-#endif
-        if(HX) {
-            PUT(RL::LSIGN, t.lower_sign, NU)
-            PUT(RL::USIGN, t.upper_sign, NU)
-            PUT(RL::LHX, t.lower_hx, NXU)
-            PUT(RL::UHX, t.upper_hx, NXU)
-        }
+        for(int i = 0; i < NU; i++) t.u[i] = us[i * SI];
+        ok = derivs_step(t, C, H, k, P.N, [] {});
+        double *out = P.f[ILQG_F_DER] + ix(P, REC, P.N, k, 0, b);
+#define PUT(off, arr, cnt) _Pragma("unroll") for(int i = 0; i < (cnt); i++) out[((off) + i) * SI] = (arr)[i];
+        REC_COPY(PUT, t)
     } else {
         trajFin_t fin;
-        init_final(&fin, &o);
+        init_final(&fin, &C.o);
+        const double *xs = P.f[ILQG_F_X] + ix(P, NX, P.N + 1, P.N, 0, b);
 #pragma unroll
-        for(int i = 0; i < NX; i++) fin.x[i] = P.f[ILQG_F_X][((size_t)P.N * NX + i) * Bp + b];
-        ok &= calcFVariableAux(&fin, nullptr, &o);
-        ok &= calcFAuxDeriv(&fin, nullptr, &o);
-        ok &= bp_derivsF(&fin, P.N, o.p);
-        double *out = P.f[ILQG_F_FIN] + b;
+        for(int i = 0; i < NX; i++) fin.x[i] = xs[i * SI];
+        ok = derivs_final(fin, C, H, P.N);
+        double *out = P.f[ILQG_F_FIN] + ix(P, FIN, 1, 0, 0, b);
         PUT(0, fin.cx, NX)
         PUT(NX, fin.cxx, SXX)
 #undef PUT
     }
-    if(!ok) P.derivs_failed[b] = 1;
+    if(!ok || H.nonfinite != 0.0) P.derivs_failed[b] = 1;
 }
 
 // ---------------------------------------------------------------------------
 // back_pass: one lane per trajectory, sequential in time, next record prefetched
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void load_record(double *dst, double *udst, const DevPtrs &P, int k, int b) {
-    const size_t Bp = P.Bp;
-    const double *src = P.f[ILQG_F_DER] + (size_t)k * REC * Bp + b;
+__device__ __forceinline__ void load_record(double *dst, double *udst, const double *src, const double *us) {
 #pragma unroll
-    for(int i = 0; i < REC; i++) dst[i] = src[(size_t)i * Bp];
-    const double *us = P.f[ILQG_F_U] + (size_t)k * NU * Bp + b;
+    for(int i = 0; i < REC; i++) dst[i] = src[i * SI];
 #pragma unroll
-    for(int i = 0; i < NU; i++) udst[i] = us[(size_t)i * Bp];
+    for(int i = 0; i < NU; i++) udst[i] = us[i * SI];
 }
 
-// Gains of one step, kept in registers for one more loop iteration: stores are issued at the
-// TOP of the next iteration, ahead of that iteration's prefetch loads.  The memory counter
-// (vmcnt) retires loads and stores in issue order, and the compiler waits with vmcnt(0) at
-// the loop head; with this order everything outstanding at that wait is a full step old.
-struct PendingGains {
-    double l[NU], K[NXU];
-    int k;
-    bool valid;
-};
-
-__device__ __forceinline__ void flush_gains(const DevPtrs &P, int b, const PendingGains &g) {
-    if(!g.valid) return;
-    const size_t Bp = P.Bp;
-    double *lo = P.f[ILQG_F_LG] + (size_t)g.k * NU * Bp + b;
+// The gains of a step are stored right behind its arithmetic, i.e. BEHIND the prefetch of the next step's inputs
+// in issue order: the memory counter retires in issue order, so the wait for the prefetched values (vmcnt = number
+// of younger operations) leaves the stores in flight.  They are stored for every lane, also for one whose box QP
+// has just failed (back_pass.c:168-171 returns before writing L): that lane leaves the sweep right after, and a
+// retry rewrites all gains.
+__device__ __forceinline__ void store_gains(const double *l, const double *K, double *lo, double *ko) {
 #pragma unroll
-    for(int i = 0; i < NU; i++) lo[(size_t)i * Bp] = g.l[i];
-    double *ko = P.f[ILQG_F_KG] + (size_t)g.k * NXU * Bp + b;
+    for(int i = 0; i < NU; i++) lo[i * SI] = l[i];
 #pragma unroll
-    for(int i = 0; i < NXU; i++) ko[(size_t)i * Bp] = g.K[i];
-}
-
-__device__ __forceinline__ void hold_gains(PendingGains &g, const double *l, const double *K, int k) {
-#pragma unroll
-    for(int i = 0; i < NU; i++) g.l[i] = l[i];
-#pragma unroll
-    for(int i = 0; i < NXU; i++) g.K[i] = K[i];
-    g.k = k;
-    g.valid = true;
+    for(int i = 0; i < NXU; i++) ko[i * SI] = K[i];
 }
 
 // one sweep k = N-1..0; returns 0 ok, 1 box-QP failed (back_pass.c:168-171)
 __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double lambda, int regType, double &dV0,
                                               double &dV1, double &g_norm) {
-    const size_t Bp = P.Bp;
     const int N = P.N;
     double Vx[NX], Vxx[SXX], l[NU], K[NXU];
+    const double *fin = P.f[ILQG_F_FIN] + ix(P, FIN, 1, 0, 0, b);
 #pragma unroll
-    for(int i = 0; i < NX; i++) Vx[i] = P.f[ILQG_F_FIN][(size_t)i * Bp + b];
+    for(int i = 0; i < NX; i++) Vx[i] = fin[i * SI];
 #pragma unroll
-    for(int i = 0; i < SXX; i++) Vxx[i] = P.f[ILQG_F_FIN][(size_t)(NX + i) * Bp + b];
+    for(int i = 0; i < SXX; i++) Vxx[i] = fin[(NX + i) * SI];
 #pragma unroll
     for(int i = 0; i < NU; i++) l[i] = 0.0;  // warm start of the last step (back_pass.c:163-164)
     dV0 = 0.0;
     dV1 = 0.0;
     double gsum = 0.0;
 
+    // pointers to step k of this lane's trajectory, walked backwards
+    const double *rp = P.f[ILQG_F_DER] + ix(P, REC, N, N - 1, 0, b);
+    const double *up = P.f[ILQG_F_U] + ix(P, NU, N, N - 1, 0, b);
+    double *lo = P.f[ILQG_F_LG] + ix(P, NU, N, N - 1, 0, b);
+    double *ko = P.f[ILQG_F_KG] + ix(P, NXU, N, N - 1, 0, b);
+    const size_t rs = step_stride(P, REC), us = step_stride(P, NU), ks = step_stride(P, NXU);
+
     double cur[REC], ucur[NU];
-    load_record(cur, ucur, P, N - 1, b);
+    load_record(cur, ucur, rp, up);
     int failed = 0;
-    PendingGains pend;
-    pend.valid = false;
+    drain_memory_ops();
     for(int k = N - 1; k >= 0; k--) {
-        flush_gains(P, b, pend);
-        pend.valid = false;
         double nxt[REC], unxt[NU];
-        if(k > 0) load_record(nxt, unxt, P, k - 1, b);  // in flight while this step computes
+        if(k > 0) load_record(nxt, unxt, rp - rs, up - us);  // in flight while this step computes
         // l still holds the solution of step k+1: the warm start (back_pass.c:165-166)
         const int rc = back_step<NX, NU, FULL, HX>(cur, ucur, Vx, Vxx, l, K, lambda, regType, dV0, dV1, gsum);
+        store_gains(l, K, lo, ko);
         if(rc < 1) {
             failed = 1;
             break;
         }
-        hold_gains(pend, l, K, k);
+        rp -= rs;
+        up -= us;
+        lo -= us;
+        ko -= ks;
 #pragma unroll
         for(int i = 0; i < REC; i++) cur[i] = nxt[i];
 #pragma unroll
         for(int i = 0; i < NU; i++) ucur[i] = unxt[i];
     }
-    flush_gains(P, b, pend);
     if(!failed) g_norm = gsum / ((double)(N - 1));  // N summands over N-1 (back_pass.c:254)
     return failed;
 }
@@ -409,106 +548,118 @@ __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double la
 // read and 10 written, instead of 57 + 10 (and k_derivs' 61 are not moved at all).  The values
 // are the ones k_derivs would have stored (same callbacks, same inputs).
 // Returns 0 ok, 1 box-QP failed, 2 NaN/Inf in the derivatives (iLQG.c:247-249).
-__device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, const ilqg_dev_opts_t &O, int b, double lambda,
+__device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks &C, ilqg_hooks &H, int b, double lambda, int regType,
                                                     double &dV0, double &dV1, double &g_norm) {
-    const size_t Bp = P.Bp;
     const int N = P.N;
-    tOptSet o;
-    ParamValues pval;
-    ParamTable ptab;
-    make_optset(o, P, O, pval, ptab);
-    tOptSet o1 = o;
-    o1.n_hor = 1;
+    H.nonfinite = 0.0;
+    const double *xp = P.f[ILQG_F_X] + ix(P, NX, N + 1, N, 0, b);
+    const double *up = P.f[ILQG_F_U] + ix(P, NU, N, N - 1, 0, b);
+    double *lo = P.f[ILQG_F_LG] + ix(P, NU, N, N - 1, 0, b);
+    double *ko = P.f[ILQG_F_KG] + ix(P, NXU, N, N - 1, 0, b);
+    const size_t xs = step_stride(P, NX), us = step_stride(P, NU), ks = step_stride(P, NXU);
 
     double Vx[NX], Vxx[SXX], l[NU], K[NXU];
     {
         trajFin_t fin;
-        init_final(&fin, &o);
+        init_final(&fin, &C.o);
 #pragma unroll
-        for(int i = 0; i < NX; i++) fin.x[i] = P.f[ILQG_F_X][((size_t)N * NX + i) * Bp + b];
-        int ok = calcFVariableAux(&fin, nullptr, &o);
-        ok &= calcFAuxDeriv(&fin, nullptr, &o);
-        ok &= bp_derivsF(&fin, N, o.p);
-        if(!ok) return 2;
+        for(int i = 0; i < NX; i++) fin.x[i] = xp[i * SI];
+        const int ok = derivs_final(fin, C, H, N);
+        if(!ok || H.nonfinite != 0.0) return 2;
 #pragma unroll
         for(int i = 0; i < NX; i++) Vx[i] = fin.cx[i];
 #pragma unroll
         for(int i = 0; i < SXX; i++) Vxx[i] = fin.cxx[i];
     }
+    xp -= xs;  // step N-1
 #pragma unroll
     for(int i = 0; i < NU; i++) l[i] = 0.0;
     dV0 = 0.0;
     dV1 = 0.0;
     double gsum = 0.0;
 
+    // Software pipeline: the record of step k-1 is evaluated in the same loop iteration as the Riccati
+    // update of step k, behind the box QP.  The two are independent chains of dependent fp64
+    // operations, so with ONE wavefront per SIMD (all that 65 536 trajectories give) the scheduler can
+    // fill the latency of one with the other.
     trajEl_t t;
-    init_running(&t, &o1);  // constant entries of the record (iLQG_func.tem:312-347)
-    double xk[NX], uk[NU];
+    init_running(&t, &C.o1);  // constant entries of the record (iLQG_func.tem:312-347)
+    double uk[NU];            // control of the step whose record is in `cur`
+    double cur[REC];
+#define GETF(off, arr, cnt) _Pragma("unroll") for(int i = 0; i < (cnt); i++) rec[(off) + i] = (arr)[i];
+    auto record_of = [&](const double *xv, const double *uv, int k, double *rec, auto &&overlapped) {
 #pragma unroll
-    for(int i = 0; i < NX; i++) xk[i] = P.f[ILQG_F_X][((size_t)(N - 1) * NX + i) * Bp + b];
+        for(int i = 0; i < NX; i++) t.x[i] = xv[i];
 #pragma unroll
-    for(int i = 0; i < NU; i++) uk[i] = P.f[ILQG_F_U][((size_t)(N - 1) * NU + i) * Bp + b];
+        for(int i = 0; i < NU; i++) t.u[i] = uv[i];
+        const int ok = derivs_step(t, C, H, k, N, overlapped);
+        REC_COPY(GETF, t)
+        return ok;
+    };
+    {
+        double xv[NX];
+#pragma unroll
+        for(int i = 0; i < NX; i++) xv[i] = xp[i * SI];
+#pragma unroll
+        for(int i = 0; i < NU; i++) uk[i] = up[i * SI];
+        const int ok = record_of(xv, uk, N - 1, cur, [] {});
+        if(!ok || H.nonfinite != 0.0) return 2;
+    }
+    // (x, u) of step k-1, loaded one iteration ahead of their use (N >= 2)
+    double xn[NX], un[NU];
+#pragma unroll
+    for(int i = 0; i < NX; i++) xn[i] = (xp - xs)[i * SI];
+#pragma unroll
+    for(int i = 0; i < NU; i++) un[i] = (up - us)[i * SI];
     int result = 0;
-    PendingGains pend;
-    pend.valid = false;
+    drain_memory_ops();
     for(int k = N - 1; k >= 0; k--) {
-        flush_gains(P, b, pend);
-        pend.valid = false;
-        double xn[NX], un[NU];
-        if(k > 0) {
+        // step k-2 (clamped at step 0, so that the pipeline below needs no special case at its end: the
+        // last iteration evaluates the record of step 0 once more and discards it)
+        double xnn[NX], unn[NU];
+        const int back = (k > 1) ? 2 : k;
 #pragma unroll
-            for(int i = 0; i < NX; i++) xn[i] = P.f[ILQG_F_X][((size_t)(k - 1) * NX + i) * Bp + b];
+        for(int i = 0; i < NX; i++) xnn[i] = (xp - back * xs)[i * SI];
 #pragma unroll
-            for(int i = 0; i < NU; i++) un[i] = P.f[ILQG_F_U][((size_t)(k - 1) * NU + i) * Bp + b];
-        }
+        for(int i = 0; i < NU; i++) unn[i] = (up - back * us)[i * SI];
+        const int rc = back_step<NX, NU, FULL, HX>(cur, uk, Vx, Vxx, l, K, lambda, regType, dV0, dV1, gsum);
+        double nxt[REC];
+        // The value-function update above is only needed by the next iteration, so the optimiser would
+        // sink it behind the exit tests below, into a block of its own, where it cannot overlap with
+        // the derivative evaluation.  Pinning its results right behind that evaluation keeps both in
+        // one block.
+        const int ok = record_of(xn, un, (k > 0) ? k - 1 : 0, nxt, [&] {
 #pragma unroll
-        for(int i = 0; i < NX; i++) t.x[i] = xk[i];
+            for(int i = 0; i < NX; i++) pin(Vx[i]);
 #pragma unroll
-        for(int i = 0; i < NU; i++) t.u[i] = uk[i];
-        int ok = calcXVariableAux(&t, nullptr, k, &o);
-        ok &= calcXUVariableAux(&t, nullptr, k, &o);
-        ok &= calcLAuxDeriv(&t, nullptr, k, &o);
-        ok &= bp_derivsL(&t, k, o.p);
-        limitsU(&t, k, o.p, N);
-        if(!ok) {
+            for(int i = 0; i < SXX; i++) pin(Vxx[i]);
+            pin(dV0);
+            pin(dV1);
+            pin(gsum);
+        });
+        if(!ok || H.nonfinite != 0.0) {
             result = 2;
             break;
         }
-        double cur[REC];
-#define GETF(off, arr, cnt) _Pragma("unroll") for(int i = 0; i < (cnt); i++) cur[(off) + i] = (arr)[i];
-        GETF(RL::CX, t.cx, NX)
-        GETF(RL::CXX, t.cxx, SXX)
-        GETF(RL::CU, t.cu, NU)
-        GETF(RL::CUU, t.cuu, SUU)
-        GETF(RL::CXU, t.cxu, NXU)
-        GETF(RL::FX, t.fx, NX * NX)
-        GETF(RL::FU, t.fu, NXU)
-        GETF(RL::LOWER, t.lower, NU)
-        GETF(RL::UPPER, t.upper, NU)
-#if FULL_DDP
-        GETF(RL::FXX, t.fxx, NX * SXX)
-        GETF(RL::FUU, t.fuu, NX * SUU)
-        GETF(RL::FXU, t.fxu, NX * NXU)
-#endif
-        if(HX) {
-            GETF(RL::LSIGN, t.lower_sign, NU)
-            GETF(RL::USIGN, t.upper_sign, NU)
-            GETF(RL::LHX, t.lower_hx, NXU)
-            GETF(RL::UHX, t.upper_hx, NXU)
-        }
-#undef GETF
-        const int rc = back_step<NX, NU, FULL, HX>(cur, uk, Vx, Vxx, l, K, lambda, O.regType, dV0, dV1, gsum);
+        store_gains(l, K, lo, ko);
         if(rc < 1) {
             result = 1;
             break;
         }
-        hold_gains(pend, l, K, k);
 #pragma unroll
-        for(int i = 0; i < NX; i++) xk[i] = xn[i];
+        for(int i = 0; i < REC; i++) cur[i] = nxt[i];
+        xp -= xs;
+        up -= us;
+        lo -= us;
+        ko -= ks;
 #pragma unroll
         for(int i = 0; i < NU; i++) uk[i] = un[i];
+#pragma unroll
+        for(int i = 0; i < NX; i++) xn[i] = xnn[i];
+#pragma unroll
+        for(int i = 0; i < NU; i++) un[i] = unn[i];
     }
-    flush_gains(P, b, pend);
+#undef GETF
     if(!result) g_norm = gsum / ((double)(N - 1));
     return result;
 }
@@ -517,7 +668,7 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, const ilqg
 //       1 = records from HBM, ONE sweep (the drop-in back_pass(): the caller owns the retry loop)
 //       2 = as 0 with the derivatives evaluated on the fly (k_derivs is not needed)
 template <int mode>
-__global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t O) {
+__global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t O, ParamValues A) {
     const int b = blockIdx.x * WAVE + threadIdx.x;
     if(b >= P.B) return;
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
@@ -527,12 +678,13 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
         P.i[ILQG_I_STATUS][b] = ILQG_ST_DERIVS_FAILED;
         return;
     }
+    ILQG_CALLBACKS(C, H);
     double lambda = P.f[ILQG_F_LAMBDA][b], dlambda = P.f[ILQG_F_DLAMBDA][b];
     double dV0 = 0.0, dV1 = 0.0, g_norm = P.f[ILQG_F_GNORM][b];
     int calls = 0, rc;
     for(;;) {
         if(mode == 2)
-            rc = backward_sweep_fused(P, O, b, lambda, dV0, dV1, g_norm);
+            rc = backward_sweep_fused(P, C, H, b, lambda, O.regType, dV0, dV1, g_norm);
         else
             rc = backward_sweep(P, b, lambda, O.regType, dV0, dV1, g_norm);
         calls++;
@@ -570,45 +722,55 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
 // wave mapping: calc_derivs straight into the device trajEl_t records, one lane per
 // (trajectory of the chunk, time step); step N is the final record
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, int chunk_first, int chunk_count,
-                                                    int init_consts) {
+__global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first,
+                                                    int chunk_count, int init_consts) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int bw = (int)(tid / (P.N + 1));
     const int k = (int)(tid % (P.N + 1));
     const int b = chunk_first + bw;
     if(bw >= chunk_count || b >= P.B) return;
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
-    tOptSet o;
-    ParamValues pval;
-    ParamTable ptab;
-    make_optset(o, P, O, pval, ptab);
+    ILQG_CALLBACKS(C, H);
+    tOptSet &o = C.o;
     int ok = 1;
     if(k < P.N) {
         trajEl_t *t = P.work + (size_t)bw * P.N + k;
-        if(init_consts) {  // constant entries, once per buffer (init_opt, iLQG_func.tem:402-415)
-            tOptSet o1 = o;
-            o1.n_hor = 1;
-            init_running(t, &o1);
+        if(init_consts) init_running(t, &C.o1);  // constant entries, once per buffer (init_opt, iLQG_func.tem:402-415)
+        auto body = [&]() {
+            for(int i = 0; i < NX; i++) t->x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, k, i, b)];
+            for(int i = 0; i < NU; i++) t->u[i] = P.f[ILQG_F_U][ix(P, NU, P.N, k, i, b)];
+            ok = calcXVariableAux(t, nullptr, k, &o);
+            ok &= calcXUVariableAux(t, nullptr, k, &o);
+            ok &= calcLAuxDeriv(t, nullptr, k, &o);
+            ok &= bp_derivsL(t, k, o.p);
+            limitsU(t, k, o.p, P.N);
+        };
+        body();
+        if(H.huge != 0.0) {  // an argument beyond the fast sin/cos reduction: once more through the library
+            H.nonfinite = 0.0;
+            H.slow = 1.0;
+            body();
         }
-        for(int i = 0; i < NX; i++) t->x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, k, i, b)];
-        for(int i = 0; i < NU; i++) t->u[i] = P.f[ILQG_F_U][ix(P, NU, P.N, k, i, b)];
-        ok &= calcXVariableAux(t, nullptr, k, &o);
-        ok &= calcXUVariableAux(t, nullptr, k, &o);
-        ok &= calcLAuxDeriv(t, nullptr, k, &o);
-        ok &= bp_derivsL(t, k, o.p);
-        limitsU(t, k, o.p, P.N);
     } else {
         trajFin_t fin;
         init_final(&fin, &o);
-        for(int i = 0; i < NX; i++) fin.x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, P.N, i, b)];
-        ok &= calcFVariableAux(&fin, nullptr, &o);
-        ok &= calcFAuxDeriv(&fin, nullptr, &o);
-        ok &= bp_derivsF(&fin, P.N, o.p);
+        auto body = [&]() {
+            for(int i = 0; i < NX; i++) fin.x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, P.N, i, b)];
+            ok = calcFVariableAux(&fin, nullptr, &o);
+            ok &= calcFAuxDeriv(&fin, nullptr, &o);
+            ok &= bp_derivsF(&fin, P.N, o.p);
+        };
+        body();
+        if(H.huge != 0.0) {
+            H.nonfinite = 0.0;
+            H.slow = 1.0;
+            body();
+        }
         double *out = P.f[ILQG_F_FIN] + (size_t)b * FIN;
         for(int i = 0; i < NX; i++) out[i] = fin.cx[i];
         for(int i = 0; i < SXX; i++) out[NX + i] = fin.cxx[i];
     }
-    if(!ok) P.derivs_failed[b] = 1;
+    if(!ok || H.nonfinite != 0.0) P.derivs_failed[b] = 1;
 }
 
 // one sweep of one trajectory on one wave; returns 0 ok, 1 box-QP failed (wave-uniform)
@@ -712,30 +874,52 @@ struct NomStep {
     double K[WAVE_MAP ? 1 : NXU];  // wave mapping: L is too large to prefetch, it is streamed (below)
 };
 
-__device__ __forceinline__ void load_nominal(NomStep &s, const DevPtrs &P, int k, int b, bool gains) {
+// pointers to the current step of one trajectory in X, U, l, L
+struct NomPtrs {
+    const double *x, *u, *l, *K;
+};
+
+template <bool GAINS>
+__device__ __forceinline__ void load_nominal(NomStep &s, const NomPtrs &q) {
 #pragma unroll
-    for(int i = 0; i < NX; i++) s.x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, k, i, b)];
+    for(int i = 0; i < NX; i++) s.x[i] = q.x[i * SI];
 #pragma unroll
-    for(int i = 0; i < NU; i++) s.u[i] = P.f[ILQG_F_U][ix(P, NU, P.N, k, i, b)];
-    if(gains) {
+    for(int i = 0; i < NU; i++) s.u[i] = q.u[i * SI];
+    if(GAINS) {
 #pragma unroll
-        for(int i = 0; i < NU; i++) s.l[i] = P.f[ILQG_F_LG][ix(P, NU, P.N, k, i, b)];
+        for(int i = 0; i < NU; i++) s.l[i] = q.l[i * SI];
         if(!WAVE_MAP) {
 #pragma unroll
-            for(int i = 0; i < NXU; i++) s.K[i] = P.f[ILQG_F_KG][ix(P, NXU, P.N, k, i, b)];
+            for(int i = 0; i < NXU; i++) s.K[i] = q.K[i * SI];
         }
     }
 }
 
-// `mode` is a run-time argument on purpose: the search passes and the winner pass
-// must execute the same machine code so that the re-rolled winner reproduces
-// the cost the selection was based on, bit for bit.
-//   ROLL_SEARCH       lane = (trajectory blockIdx.x*64+lane, step size a0 + blockIdx.y)
+// Three instantiations of the roll-out:
+//   RK_GENERAL  u = u_nom + alpha*l + L (x - x_nom): ROLL_SEARCH, ROLL_SEARCH_LIST and ROLL_WINNER.  These differ
+//               by the RUN-TIME argument `mode` only, on purpose: the search passes and the winner pass must
+//               execute the same machine code so that the re-rolled winner reproduces the cost its selection
+//               was based on, bit for bit.
+//   RK_INIT     alpha = 0: u = u_nom, no gains read (initial roll-out, iLQG_mex.c:116), stored in place
+//   RK_COST     cost of the stored trajectory (forward_pass with cost_only = 1, iLQG.c:338)
+// Lanes:
+//   ROLL_SEARCH       lane = (trajectory blockIdx.x*64+lane, step size a0 + blockIdx.y); only the cost is kept
 //   ROLL_SEARCH_LIST  as ROLL_SEARCH for the trajectories listed in P.pending (second stage)
-//   ROLL_WINNER       lane = trajectory, accepted step size, result stored in place
-//   ROLL_INIT         lane = trajectory, alpha = 0 (initial roll-out, iLQG_mex.c:116), stored
-//   ROLL_COST         lane = trajectory, cost of the stored trajectory (forward_pass cost_only = 1)
-__global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, int mode, int a0) {
+//   ROLL_WINNER       lane = trajectory, accepted step size, rolled out again and stored in place of the nominal
+//                     trajectory: accepted = overwritten, no candidate buffer and no swap (iLQG.c:381-386)
+//   ROLL_INIT / ROLL_COST  lane = trajectory
+// Keeping the candidates of the search instead of re-rolling the winner was measured and dropped: a whole-batch copy
+// of X and U per step size costs more HBM write time than the winner pass, and candidates of the compacted second
+// stage can only be written or copied back as scattered 8-byte pieces.
+// The time step itself is straight-line code: the generated callbacks' NaN/Inf guards and the
+// huge-argument case of sin/cos are hooks (see ilqg_hooks), tested once per step.
+enum { RK_GENERAL = 0, RK_INIT = 1, RK_COST = 2 };
+#ifndef ILQG_ROLLOUT_ATTR
+#define ILQG_ROLLOUT_ATTR
+#endif
+
+template <int KIND>
+__global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int mode, int a0) {
     int b = blockIdx.x * WAVE + threadIdx.x;
     const int ai = a0 + blockIdx.y;
     if(mode == ROLL_SEARCH_LIST) {
@@ -754,118 +938,155 @@ __global__ __launch_bounds__(WAVE) void k_rollout(DevPtrs P, ilqg_dev_opts_t O, 
     } else if(mode == ROLL_COST) {
         if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) return;
     }
-    const bool cost_only = (mode == ROLL_COST);
+    constexpr bool cost_only = (KIND == RK_COST);
+    constexpr bool gains = (KIND == RK_GENERAL);
     const bool store = (mode == ROLL_INIT || mode == ROLL_WINNER);
-    const bool gains = !cost_only && alpha != 0.0;
+    const bool feedback = (alpha != 0.0);  // alpha == 0.0: u = u_nom without feedback (iLQG_func.tem:156-158)
 
-    tOptSet o;
-    ParamValues pval;
-    ParamTable ptab;
-    make_optset(o, P, O, pval, ptab);
-    tOptSet o1 = o;
-    o1.n_hor = 1;
+    ILQG_CALLBACKS(C, H);
     trajEl_t ct;
-    init_running(&ct, &o1);  // constant auxiliaries of this problem (iLQG_func.tem:312-347)
+    init_running(&ct, &C.o1);  // constant auxiliaries of this problem (iLQG_func.tem:312-347)
+
+    // this trajectory's step 0 in every field; all of them advance by one step per iteration
+    NomPtrs q;
+    q.x = P.f[ILQG_F_X] + ix(P, NX, N + 1, 0, 0, b);
+    q.u = P.f[ILQG_F_U] + ix(P, NU, N, 0, 0, b);
+    // a stored roll-out (initial, winner) replaces the nominal trajectory in place
+    double *xo = const_cast<double *>(q.x), *uo = const_cast<double *>(q.u);
+    q.l = P.f[ILQG_F_LG] + ix(P, NU, N, 0, 0, b);
+    q.K = P.f[ILQG_F_KG] + ix(P, NXU, N, 0, 0, b);
+    const size_t xs = step_stride(P, NX), us = step_stride(P, NU), ks = step_stride(P, NXU);
 
     double xc[NX];
 #pragma unroll
-    for(int i = 0; i < NX; i++) xc[i] = P.f[ILQG_F_X][ix(P, NX, N + 1, 0, i, b)];  // x0 (iLQG_func.tem:141-142)
+    for(int i = 0; i < NX; i++) xc[i] = q.x[i * SI];  // x0 (iLQG_func.tem:141-142)
     double csum = 0.0;
-    int ok = 1;
+    int okc = 1;
     NomStep cur;
-    load_nominal(cur, P, 0, b, gains);
-    // stores of a step are issued at the top of the next iteration, ahead of its prefetch (see PendingGains)
-    double px[NX], pu[NU];
-    int pk = -1;
+    load_nominal<gains>(cur, q);
+    drain_memory_ops();
     for(int k = 0; k < N; k++) {
-        if(store && pk >= 0) {
-#pragma unroll
-            for(int i = 0; i < NX; i++) P.f[ILQG_F_X][ix(P, NX, N + 1, pk, i, b)] = px[i];
-#pragma unroll
-            for(int i = 0; i < NU; i++) P.f[ILQG_F_U][ix(P, NU, N, pk, i, b)] = pu[i];
-        }
+        NomPtrs qn;
+        qn.x = q.x + xs;
+        qn.u = q.u + us;
+        qn.l = q.l + us;
+        qn.K = q.K + ks;
         NomStep nxt;
-        if(k + 1 < N) load_nominal(nxt, P, k + 1, b, gains);  // in flight while this step computes
+        if(k + 1 < N) load_nominal<gains>(nxt, qn);  // in flight while this step computes
+
+        // inputs of the step
+        double xin[NX], uin[NU];
         if(cost_only) {
 #pragma unroll
-            for(int i = 0; i < NX; i++) ct.x[i] = cur.x[i];
+            for(int i = 0; i < NX; i++) xin[i] = cur.x[i];
 #pragma unroll
-            for(int i = 0; i < NU; i++) ct.u[i] = cur.u[i];
+            for(int i = 0; i < NU; i++) uin[i] = cur.u[i];
         } else {
 #pragma unroll
-            for(int i = 0; i < NX; i++) ct.x[i] = xc[i];
-            if(alpha) {
+            for(int i = 0; i < NX; i++) xin[i] = xc[i];
+            if(gains) {
                 // u = u_nom + alpha*l + L (x - x_nom), state by state (iLQG_func.tem:146-155)
+                double uf[NU];
 #pragma unroll
-                for(int j = 0; j < NU; j++) ct.u[j] = cur.u[j] + cur.l[j] * alpha;
+                for(int j = 0; j < NU; j++) uf[j] = cur.u[j] + cur.l[j] * alpha;
 #pragma unroll
                 for(int i = 0; i < NX; i++) {
-                    const double dx = ct.x[i] - cur.x[i];
+                    const double dx = xin[i] - cur.x[i];
                     if(WAVE_MAP) {
-                        const double *Kk = P.f[ILQG_F_KG] + ix(P, NXU, N, k, i * NU, b);
+                        const double *Kk = q.K + i * NU;
 #pragma unroll
-                        for(int j = 0; j < NU; j++) ct.u[j] += Kk[j] * dx;
+                        for(int j = 0; j < NU; j++) uf[j] += Kk[j] * dx;
                     } else {
 #pragma unroll
-                        for(int j = 0; j < NU; j++) ct.u[j] += cur.K[j + i * NU] * dx;
+                        for(int j = 0; j < NU; j++) uf[j] += cur.K[j + i * NU] * dx;
                     }
                 }
+#pragma unroll
+                for(int j = 0; j < NU; j++) uin[j] = feedback ? uf[j] : cur.u[j];
             } else {
 #pragma unroll
-                for(int j = 0; j < NU; j++) ct.u[j] = cur.u[j];
+                for(int j = 0; j < NU; j++) uin[j] = cur.u[j];
             }
         }
-        if(!calcXVariableAux(&ct, nullptr, k, &o)) { ok = 0; break; }
-        if(!cost_only) clampU(ct.u, &ct, k, o.p, N);
-        if(!calcXUVariableAux(&ct, nullptr, k, &o)) { ok = 0; break; }
+
+        // the step (iLQG_func.tem:160-176)
         double xnext[NX];
-        if(!cost_only) {
-            if(!ddpf(xnext, &ct, k, o.p, N)) { ok = 0; break; }
+        const double nf0 = H.nonfinite;
+        H.huge = 0.0;
+        auto step = [&]() {
+#pragma unroll
+            for(int i = 0; i < NX; i++) ct.x[i] = xin[i];
+#pragma unroll
+            for(int j = 0; j < NU; j++) ct.u[j] = uin[j];
+            int r = calcXVariableAux(&ct, nullptr, k, &C.o);
+            if(!cost_only) clampU(ct.u, &ct, k, C.o.p, N);
+            r &= calcXUVariableAux(&ct, nullptr, k, &C.o);
+            if(!cost_only) r &= ddpf(xnext, &ct, k, C.o.p, N);
+            r &= ddpL(&ct, k, &C.o);
+            return r;
+        };
+        int r = step();
+        if(H.huge != 0.0) {  // an argument beyond the fast sin/cos reduction: once more through the library
+            H.nonfinite = nf0;
+            H.slow = 1.0;
+            r = step();
+            H.slow = 0.0;
         }
-        if(!ddpL(&ct, k, &o)) { ok = 0; break; }
+        okc &= r;
         csum += ct.c;
+        // The step's results are stored right away, i.e. BEHIND the prefetch of the next step in issue order: the
+        // memory counter retires in issue order, so the wait for the prefetched values at the end of this
+        // iteration (vmcnt = number of younger operations) leaves these stores in flight.
         if(store) {
 #pragma unroll
-            for(int i = 0; i < NX; i++) px[i] = ct.x[i];
+            for(int i = 0; i < NX; i++) xo[i * SI] = ct.x[i];
 #pragma unroll
-            for(int i = 0; i < NU; i++) pu[i] = ct.u[i];
-            pk = k;
+            for(int i = 0; i < NU; i++) uo[i * SI] = ct.u[i];
         }
         if(!cost_only) {
 #pragma unroll
             for(int i = 0; i < NX; i++) xc[i] = xnext[i];
         }
         cur = nxt;
+        q = qn;
+        xo += xs;
+        uo += us;
     }
-    if(store && pk >= 0) {
-#pragma unroll
-        for(int i = 0; i < NX; i++) P.f[ILQG_F_X][ix(P, NX, N + 1, pk, i, b)] = px[i];
-#pragma unroll
-        for(int i = 0; i < NU; i++) P.f[ILQG_F_U][ix(P, NU, N, pk, i, b)] = pu[i];
-    }
-    if(ok) {
+    // final cost (iLQG_func.tem:179-182); q.x now points at step N
+    {
         trajFin_t cf;
-        init_final(&cf, &o);
-        if(cost_only) {
+        init_final(&cf, &C.o);
+        double xin[NX];
 #pragma unroll
-            for(int i = 0; i < NX; i++) cf.x[i] = P.f[ILQG_F_X][ix(P, NX, N + 1, N, i, b)];
-        } else {
+        for(int i = 0; i < NX; i++) xin[i] = cost_only ? q.x[i * SI] : xc[i];
+        const double nf0 = H.nonfinite;
+        H.huge = 0.0;
+        auto fin = [&]() {
 #pragma unroll
-            for(int i = 0; i < NX; i++) cf.x[i] = xc[i];
+            for(int i = 0; i < NX; i++) cf.x[i] = xin[i];
+            int r = calcFVariableAux(&cf, nullptr, &C.o);
+            r &= ddpF(&cf, &C.o);
+            return r;
+        };
+        int r = fin();
+        if(H.huge != 0.0) {
+            H.nonfinite = nf0;
+            H.slow = 1.0;
+            r = fin();
+            H.slow = 0.0;
         }
-        if(!calcFVariableAux(&cf, nullptr, &o)) ok = 0;
-        if(ok && !ddpF(&cf, &o)) ok = 0;
-        if(ok) {
-            csum += cf.c;
-            if(store) {
+        okc &= r;
+        csum += cf.c;
+        if(store) {
 #pragma unroll
-                for(int i = 0; i < NX; i++) P.f[ILQG_F_X][ix(P, NX, N + 1, N, i, b)] = cf.x[i];
-            }
+            for(int i = 0; i < NX; i++) xo[i * SI] = cf.x[i];  // xo points at step N now
         }
     }
+    // forward_pass returns 0 as soon as a guarded value is NaN or Inf (genenerator_main.mac:193-198)
+    const int ok = (okc && H.nonfinite == 0.0) ? 1 : 0;
 
     if(mode == ROLL_SEARCH || mode == ROLL_SEARCH_LIST) {
-        P.f[ILQG_F_ALPHA_COST][(size_t)ai * P.Bp + b] = csum;
+        P.f[ILQG_F_ALPHA_COST][tile_ix(ILQG_MAX_ALPHA, ai, b)] = csum;
         P.i[ILQG_I_ALPHA_OK][(size_t)ai * P.Bp + b] = ok;
     } else if(mode == ROLL_WINNER) {
         P.f[ILQG_F_NEW_COST][b] = csum;
@@ -899,7 +1120,7 @@ __global__ void k_select(DevPtrs P, ilqg_dev_opts_t O, int a0, int a1, int from_
     for(i = a0; i < a1; i++) {
         const double a = O.alpha[i];
         ok = P.i[ILQG_I_ALPHA_OK][(size_t)i * Bp + b];
-        cnew = P.f[ILQG_F_ALPHA_COST][(size_t)i * Bp + b];
+        cnew = P.f[ILQG_F_ALPHA_COST][tile_ix(ILQG_MAX_ALPHA, i, b)];
         if(!ok) continue;
         dcost = cost - cnew;
         expected = -a * (dV0 + a * dV1);
@@ -907,7 +1128,8 @@ __global__ void k_select(DevPtrs P, ilqg_dev_opts_t O, int a0, int a1, int from_
         if(z > O.zMin) break;
         ok = 0;
     }
-    if(!ok && a1 < O.n_alpha) P.pending[atomicAdd(P.n_pending_next, 1)] = b;  // to the second stage
+    // to the second stage.  (Appending in trajectory order instead of atomic order was measured: no gain.)
+    if(!ok && a1 < O.n_alpha) P.pending[atomicAdd(P.n_pending_next, 1)] = b;
     P.i[ILQG_I_ALPHA_IDX][b] = i + 1;
     P.i[ILQG_I_ACCEPTED][b] = ok;
     P.f[ILQG_F_NEW_COST][b] = cnew;
@@ -1074,6 +1296,7 @@ struct ilqg_dev {
     DevPtrs P;
     ilqg_dev_opts_t O;
     std::vector<double *> param_bufs;
+    ParamValues pv;       // fixed-size parameters, passed to the kernels by value
     double *staging;
     size_t staging_bytes;
     int *counter;
@@ -1124,16 +1347,18 @@ struct Timed {
     ilqg_dev *d;
     int kernel;
     hipEvent_t a, b;
-    Timed(ilqg_dev *d_, int k) : d(d_), kernel(k), a(nullptr), b(nullptr) {
+    hipStream_t st;
+    Timed(ilqg_dev *d_, int k, hipStream_t stream = nullptr) : d(d_), kernel(k), a(nullptr), b(nullptr) {
+        st = stream ? stream : d->stream;
         if(d->timing) {
             hipEventCreate(&a);
             hipEventCreate(&b);
-            hipEventRecord(a, d->stream);
+            hipEventRecord(a, st);
         }
     }
     ~Timed() {
         if(d->timing) {
-            hipEventRecord(b, d->stream);
+            hipEventRecord(b, st);
             d->spans.push_back({kernel, a, b});
         }
     }
@@ -1182,7 +1407,7 @@ void ilqg_dev_dims(int *out) {
 const char *ilqg_dev_kernel_name(int k) {
     static const char *names[ILQG_K_COUNT] = {"k_derivs", "k_backward", "k_rollout[search]", "k_select",
                                               "k_rollout[winner]", "k_update", "k_rollout[cost]", "k_rollout[init]",
-                                              "k_to_soa/k_to_aos", "k_backward[fused derivs]", "k_rollout[search stage 2]"};
+                                              "k_to_dev/k_from_dev", "k_backward[fused derivs]", "k_rollout[search stage 2]"};
     return (k >= 0 && k < ILQG_K_COUNT) ? names[k] : "?";
 }
 
@@ -1211,6 +1436,7 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
     memset(d->t_n, 0, sizeof(d->t_n));
     memset(&d->P, 0, sizeof(d->P));
     memset(&d->O, 0, sizeof(d->O));
+    memset(&d->pv, 0, sizeof(d->pv));
     d->P.B = d->B;
     d->P.Bp = d->Bp;
     d->P.N = d->N;
@@ -1289,6 +1515,21 @@ int ilqg_dev_set_params(ilqg_dev_t *d, int n_params, const int *sizes, const dou
     if(d->P.p) hipFree(d->P.p);
     d->P.p = nullptr;
     std::vector<double *> ptrs(n_params > 0 ? n_params : 1, nullptr);
+    {
+        constexpr int want[ILQG_NP > 0 ? ILQG_NP : 1] = ILQG_PSIZES;
+        constexpr int offs[ILQG_NP > 0 ? ILQG_NP : 1] = ILQG_POFFSETS;
+        if(n_params != ILQG_NP) {
+            g_err = "ilqg_dev_set_params: parameter count differs from the problem this library was built for";
+            return 1;
+        }
+        for(int i = 0; i < n_params; i++) {
+            if(sizes[i] != want[i]) {
+                g_err = "ilqg_dev_set_params: parameter size differs from the problem's paramdesc[]";
+                return 1;
+            }
+            for(int j = 0; j < sizes[i]; j++) d->pv.v[offs[i] + j] = values[i][j];
+        }
+    }
     for(int i = 0; i < n_params; i++) {
         const int sz = sizes[i] == -1 ? d->N + 1 : sizes[i];
         double *buf = nullptr;
@@ -1393,7 +1634,7 @@ int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps
     {
         Timed t(d, ILQG_K_TRANSPOSE);
         const size_t total = (size_t)d->B * steps * fi.wd;
-        hipLaunchKernelGGL(k_to_soa, grid1(total, 256), dim3(256), 0, d->stream, d->staging, d->P.f[field], d->B, d->Bp,
+        hipLaunchKernelGGL(k_to_dev, grid1(total, 256), dim3(256), 0, d->stream, d->staging, d->P.f[field], d->B, d->Bp,
                            steps, fi.wh, fi.wd);
     }
     HIP_TRY(hipGetLastError());
@@ -1420,7 +1661,7 @@ int ilqg_dev_read(ilqg_dev_t *d, int field, double *host) {
     if(ensure_staging(d, n * sizeof(double))) return 1;
     {
         Timed t(d, ILQG_K_TRANSPOSE);
-        hipLaunchKernelGGL(k_to_aos, grid1(n, 256), dim3(256), 0, d->stream, d->P.f[field], d->staging, d->B, d->Bp,
+        hipLaunchKernelGGL(k_from_dev, grid1(n, 256), dim3(256), 0, d->stream, d->P.f[field], d->staging, d->B, d->Bp,
                            steps, fi.wh, fi.wd);
     }
     HIP_TRY(hipGetLastError());
@@ -1465,9 +1706,16 @@ int ilqg_dev_reset(ilqg_dev_t *d) {
     return 0;
 }
 
-static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_alpha) {
-    Timed t(d, kernel_id);
-    hipLaunchKernelGGL(k_rollout, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE), 0, d->stream, d->P, d->O, mode, a0);
+static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_alpha, hipStream_t stream = nullptr) {
+    if(!stream) stream = d->stream;
+    Timed t(d, kernel_id, stream);
+    const dim3 grid(d->Bp / WAVE, n_alpha), block(WAVE);
+    if(mode == ROLL_INIT)
+        hipLaunchKernelGGL(k_rollout<RK_INIT>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
+    else if(mode == ROLL_COST)
+        hipLaunchKernelGGL(k_rollout<RK_COST>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
+    else
+        hipLaunchKernelGGL(k_rollout<RK_GENERAL>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
     return 0;
 }
 
@@ -1489,7 +1737,7 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
         if(do_derivs) {
             Timed t(d, ILQG_K_DERIVS);
             const size_t total = (size_t)cnt * (d->N + 1);
-            hipLaunchKernelGGL(k_derivs_wave, grid1(total, 64), dim3(64), 0, d->stream, d->P, d->O, c0, cnt,
+            hipLaunchKernelGGL(k_derivs_wave, grid1(total, 64), dim3(64), 0, d->stream, d->P, d->O, d->pv, c0, cnt,
                                d->work_consts ? 0 : 1);
         }
         if(do_backward) {
@@ -1516,7 +1764,7 @@ int ilqg_dev_derivs(ilqg_dev_t *d) {
     {
         Timed t(d, ILQG_K_DERIVS);
         const size_t total = (size_t)d->Bp * (d->N + 1);
-        hipLaunchKernelGGL(k_derivs, grid1(total, 256), dim3(256), 0, d->stream, d->P, d->O);
+        hipLaunchKernelGGL(k_derivs, grid1(total, 256), dim3(256), 0, d->stream, d->P, d->O, d->pv);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1541,22 +1789,25 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
         Timed t(d, mode == 2 ? ILQG_K_BACKWARD_FUSED : ILQG_K_BACKWARD);
         const dim3 grid(d->Bp / WAVE), block(WAVE);
         if(mode == 0)
-            hipLaunchKernelGGL(k_backward<0>, grid, block, 0, d->stream, d->P, d->O);
+            hipLaunchKernelGGL(k_backward<0>, grid, block, 0, d->stream, d->P, d->O, d->pv);
         else if(mode == 1)
-            hipLaunchKernelGGL(k_backward<1>, grid, block, 0, d->stream, d->P, d->O);
+            hipLaunchKernelGGL(k_backward<1>, grid, block, 0, d->stream, d->P, d->O, d->pv);
         else
-            hipLaunchKernelGGL(k_backward<2>, grid, block, 0, d->stream, d->P, d->O);
+            hipLaunchKernelGGL(k_backward<2>, grid, block, 0, d->stream, d->P, d->O, d->pv);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 #endif
 }
 
+// Line search (line_search.c:33-78) in up to two stages, see k_select / k_rollout:
+//   stage 1: step sizes [0, s1) for every trajectory; selection
+//   stage 2: step sizes [s1, n_alpha) for the trajectories still without an acceptable one; selection
 int ilqg_dev_search(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
     const int A = d->O.n_alpha;
-    const int s1 = (d->O.ls_split > 0 && d->O.ls_split < A) ? d->O.ls_split : A;  // step sizes in stage 1
+    const int s1 = (d->O.ls_split > 0 && d->O.ls_split < A) ? d->O.ls_split : A;
     HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), d->stream));
     launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, 0, s1);
     {
@@ -1564,8 +1815,7 @@ int ilqg_dev_search(ilqg_dev_t *d) {
         hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O, 0, s1, 0);
     }
     if(s1 < A) {
-        // second stage: only the trajectories without an acceptable step size so far.  The grid covers the
-        // worst case; blocks beyond the pending count return at once.
+        // The grid covers the worst case; blocks beyond the pending count return at once.
         launch_rollout(d, ROLL_SEARCH_LIST, ILQG_K_ROLLOUT_SEARCH2, s1, A - s1);
         Timed t(d, ILQG_K_SELECT);
         hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O, s1, A, 1);

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("ILQG_LIBDIR", os.path.join(HERE, "lib"))  # override: experiments with other builds
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")

@@ -142,9 +142,30 @@ static double qp_value(const double *H, const double *g, const double *x, int n)
     return v;
 }
 
+/* optional instrumentation for tools/divergence_stats.py (not part of the algorithm): when a log is
+ * attached, every call appends {outer iterations, factorisations, Armijo trials} */
+int *ilqg_oracle_boxqp_log = NULL;
+long ilqg_oracle_boxqp_log_cap = 0, ilqg_oracle_boxqp_log_n = 0;
+static int boxqp_core(double *H, const double *g, const double *lower, const double *upper, double *x,
+                      double *Hfree, double *U, double *grad, double *grad_clamped, double *search,
+                      int *is_clamped, int *n_free_, double *invHfree, const int n, int *stat);
+
 int boxQP(double *H, const double *g, const double *lower, const double *upper, double *x,
           double *Hfree, double *U, double *grad, double *grad_clamped, double *search,
           int *is_clamped, int *n_free_, double *invHfree, const int n) {
+    int stat[3] = {0, 0, 0};
+    const int rc = boxqp_core(H, g, lower, upper, x, Hfree, U, grad, grad_clamped, search, is_clamped, n_free_,
+                              invHfree, n, stat);
+    if(ilqg_oracle_boxqp_log && ilqg_oracle_boxqp_log_n < ilqg_oracle_boxqp_log_cap) {
+        int *e = ilqg_oracle_boxqp_log + 3 * ilqg_oracle_boxqp_log_n++;
+        e[0] = stat[0]; e[1] = stat[1]; e[2] = stat[2];
+    }
+    return rc;
+}
+
+static int boxqp_core(double *H, const double *g, const double *lower, const double *upper, double *x,
+                      double *Hfree, double *U, double *grad, double *grad_clamped, double *search,
+                      int *is_clamped, int *n_free_, double *invHfree, const int n, int *stat) {
     /* constants: boxQP.c:52-57 */
     const int max_iter = 100;
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
@@ -163,6 +184,7 @@ int boxQP(double *H, const double *g, const double *lower, const double *upper, 
     for(int iter = 0; iter < max_iter; iter++) {
         if(iter > 0 && (oldvalue - value) < min_rel_improve * fabs(oldvalue)) return 4;
         oldvalue = value;
+        stat[0]++;
 
         /* gradient and clamp flags (boxQP.c:91-117): a variable sitting on a
          * bound with the gradient pushing outwards is clamped */
@@ -202,6 +224,7 @@ int boxQP(double *H, const double *g, const double *lower, const double *upper, 
                 }
                 jf++;
             }
+            stat[1]++;
             if(!cholesky_tri(Hfree, n_free, U)) return -1;
             cholesky_tri_inv(U, invHfree, n_free, search);
         }
@@ -246,6 +269,7 @@ int boxQP(double *H, const double *g, const double *lower, const double *upper, 
                 if(xc[i] < lower[i]) xc[i] = lower[i];
             }
             vc = qp_value(H, g, xc, n);
+            stat[2]++;
             if(((vc - oldvalue) / (step * sdotg)) >= armijo) break;
             step = step * step_dec;
             if(step < min_step) return 2;

@@ -34,9 +34,10 @@ def run(B, nch, split, stagger):
     print("B %6d chunks %d split %d stagger %d: %.2f ms/iter  %.1f it/s  cost mean %.6f" % (B, nch, split, stagger, 1e3 * dt / K, K / dt, c), flush=True)
     for s in ss: s.close()
 
-for split in (3, 4):
+import sys
+for split in (5, 3, 2):
     run(65536, 1, split, 0)
     run(65536, 2, split, 0)
     run(65536, 2, split, 1)
-    run(65536, 3, split, 1)
-run(131072, 1, 4, 0)
+    run(65536, 4, split, 0)
+    run(65536, 4, split, 1)
