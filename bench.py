@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--fuse-derivs", type=int, default=1)
     ap.add_argument("--ls-split", type=int, default=5)
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary run with materialised derivative records")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="independent sets of trajectories advanced on separate HIP streams (0: library default)")
     args = ap.parse_args()
 
     import torch
@@ -148,7 +150,7 @@ def main():
     params = ilqg.CAR_PARAMS if car else synth.SYNTH16_PARAMS
     s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=N_HOR, device=local, params=params,
                          opts=dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_split=args.ls_split),
-                         strict=("wave" if args.mapping == "wave" else False))
+                         strict=("wave" if args.mapping == "wave" else False), groups=args.groups)
     args.full_ddp = fd
     if args.resweep >= 0:
         s.set_option("resweep", args.resweep)
@@ -157,8 +159,8 @@ def main():
         s.iterate(W)
         s.sync()
         s.init(x0, u0)  # back to iteration 0: the timed window is always iterations 1..K
-    # zero-copy view of the solver's cost vector (device memory) for the collective
-    cost_view = pkg.dist.device_view(s.cost_device_ptr(), B, dev, fallback=lambda: s.scalar("cost"))
+    # device buffer the solver's per-trajectory costs are copied into (device to device) for the collective
+    cost_dev = torch.empty(B, dtype=torch.float64, device=dev)
 
     def barrier():
         if world > 1:
@@ -169,9 +171,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     s.iterate(K)
-    s.sync()
+    s.scalar_to_device("cost", cost_dev.data_ptr())  # synchronises the solver's streams
     # the single collective of the path: per-trajectory costs to rank 0 over RCCL/xGMI
-    gathered = pkg.dist.gather_costs(cost_view, rank, world)
+    gathered = pkg.dist.gather_costs(cost_dev, rank, world)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -234,6 +236,7 @@ def main():
                        "mapping": ("one wavefront per trajectory" if s.problem.wave_mapping else
                                    "one lane per trajectory (64 trajectories per wavefront)"),
                        "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split, "resweep": args.resweep,
+                       "stream_groups": s.groups(),
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

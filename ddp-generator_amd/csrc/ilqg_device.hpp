@@ -20,6 +20,23 @@ namespace ilqg {
 
 #define ILQG_DEV __device__ __forceinline__
 
+// Optional cycle accounting of the sections of a backward step (builds with -DILQG_PROFILE_SECTIONS only;
+// tools/section_profile.py).  probe(i) charges the cycles since the previous probe to section i.
+struct Prof {
+    long long last, acc[8];
+    ILQG_DEV void start() {
+        for(int i = 0; i < 8; i++) acc[i] = 0;
+        last = __builtin_readcyclecounter();
+    }
+    ILQG_DEV void probe(int i) {
+#ifdef ILQG_PROFILE_SECTIONS
+        const long long t = __builtin_readcyclecounter();
+        acc[i] += t - last;
+        last = t;
+#endif
+    }
+};
+
 __host__ __device__ constexpr int tri(int n) { return n * (n + 1) / 2; }
 __host__ __device__ constexpr int ut(int r, int c) { return c * (c + 1) / 2 + r; }               // r <= c
 __host__ __device__ constexpr int sy(int i, int j) { return i > j ? ut(j, i) : ut(i, j); }
@@ -154,6 +171,21 @@ ILQG_DEV double qp_value(const double *H, const double *g, const double *x) {
     return v;
 }
 
+// The acceptance test of the backtracking line search, boxQP.c:219:
+//     (vc - oldvalue) / (step * sdotg) >= armijo          (step > 0, sdotg < 0)
+// decided without the division wherever the outcome is beyond doubt: with n = vc - oldvalue, d = step*sdotg < 0
+// the quotient is >= armijo iff n <= armijo*d.  Both sides carry a few rounding errors of relative size 2^-53
+// each, so the comparison is trusted only outside a band of relative width 1e-15 (nine times that) around
+// armijo*d; inside the band — and for NaN, where every comparison fails — the reference's own expression is
+// evaluated.  The result is therefore always the reference's.
+ILQG_DEV bool armijo_passes(double vc, double oldvalue, double step, double sdotg, double armijo) {
+    const double n = vc - oldvalue, d = step * sdotg;
+    const double t = armijo * d, m = fabs(t) * 1e-15;
+    if(n < t - m) return true;
+    if(n > t + m) return false;
+    return (n / d) >= armijo;
+}
+
 // Projected-Newton box QP.  Same iteration, constants and return codes as
 // boxQP.c:39-238.  One representational difference: the reference compacts
 // the free rows/columns into a smaller matrix (which needs runtime indices);
@@ -164,12 +196,21 @@ ILQG_DEV double qp_value(const double *H, const double *g, const double *x) {
 // for free i,j equals the reference's invHfree[sy(i_free,j_free)].
 template <int M>
 ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const double *upper, double *x,
-                    int *clamp, int &n_free_out, double *invH) {
+                    int *clamp, int &n_free_out, double *invH, Prof *pf = nullptr) {
+    // Control flow.  The reference leaves its loop through seven `return`s; compiled literally for 64 lanes in
+    // lock step each of them is a divergent branch (save/restore of the execution mask, a VALU->SALU round
+    // trip, a fetch bubble), and with one wavefront per SIMD nothing hides them: measured, the branches cost
+    // more than the arithmetic between them.  Here a lane that has reached a return only RECORDS its code in
+    // `rc` and stops committing results (everything below is predicated on rc == 0 through selects); it leaves
+    // at the single test at the end of the iteration.  The lanes of a wavefront wait for the slowest one
+    // anyway, so the work a finished lane still steps through costs no time.  Results, codes and the state
+    // left in x / clamp / invH at each exit are the reference's.
     constexpr int T = tri(M);
     const int max_iter = 100;
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
-    double grad[M], search[M], xc[M];
+    double grad[M], search[M];
     double value, oldvalue = 0.0;
+    int rc = 0;  // 0: iterating
 
 #pragma unroll
     for(int i = 0; i < M; i++) {
@@ -183,9 +224,11 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
     value = qp_value<M>(H, g, x);
 
     for(int iter = 0; iter < max_iter; iter++) {
-        if(iter > 0 && (oldvalue - value) < min_rel_improve * fabs(oldvalue)) return 4;
-        oldvalue = value;
+        if(iter > 0 && (oldvalue - value) < min_rel_improve * fabs(oldvalue)) rc = 4;  // boxQP.c:85-86
+        const bool live0 = (rc == 0);
+        oldvalue = live0 ? value : oldvalue;
 
+        // gradient and clamp flags (boxQP.c:95-117)
         bool all_clamped = true, changed = false;
         int n_free = 0;
         double gnorm = 0.0;
@@ -196,33 +239,41 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
             for(int j = 0; j < M; j++) hx += H[sy(i, j)] * x[j];
             grad[i] = g[i] + hx;
             const int was = clamp[i];
+            int now;
             if(x[i] <= lower[i] && grad[i] > 0)
-                clamp[i] = 1;
+                now = 1;
             else if(x[i] >= upper[i] && grad[i] < 0)
-                clamp[i] = 2;
+                now = 2;
             else {
-                clamp[i] = 0;
+                now = 0;
                 all_clamped = false;
                 gnorm += grad[i] * grad[i];
                 n_free++;
             }
-            if((!was) != (!clamp[i])) changed = true;
+            if((!was) != (!now)) changed = true;
+            clamp[i] = live0 ? now : was;
         }
-        n_free_out = n_free;
-        if(all_clamped) return 6;
+        n_free_out = live0 ? n_free : n_free_out;
+        if(live0 && all_clamped) rc = 6;  // boxQP.c:124-126
 
-        if(iter == 0 || changed) {
-            double Hm[T], U[T];
+        // factor + explicit inverse of the free block when the free set changed (boxQP.c:129-146)
+        if(pf) pf->probe(2);
+        if(rc == 0 && (iter == 0 || changed)) {
+            double Hm[T], U[T], inv[T];
 #pragma unroll
             for(int j = 0; j < M; j++)
 #pragma unroll
                 for(int i = 0; i <= j; i++)
                     Hm[ut(i, j)] = (clamp[i] || clamp[j]) ? ((i == j) ? 1.0 : 0.0) : H[ut(i, j)];
-            if(!chol_factor<M>(Hm, U)) return -1;
-            chol_inverse<M>(U, invH);
+            const bool pd = chol_factor<M>(Hm, U);
+            chol_inverse<M>(U, inv);
+            if(!pd) rc = -1;
+#pragma unroll
+            for(int i = 0; i < T; i++) invH[i] = pd ? inv[i] : invH[i];
         }
+        if(pf) pf->probe(3);
 
-        if(gnorm < min_grad * min_grad) return 5;
+        if(rc == 0 && gnorm < min_grad * min_grad) rc = 5;  // boxQP.c:149-150
 
         // search(free) = -invH(free,free) * (g + H x_clamped)(free) - x(free); search(clamped) = 0
         double gc[M];
@@ -236,36 +287,64 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
         }
 #pragma unroll
         for(int i = 0; i < M; i++) {
-            double s = -x[i];
+            double sd = -x[i];
 #pragma unroll
             for(int j = 0; j < M; j++)
-                if(!clamp[j]) s -= invH[sy(i, j)] * gc[j];
-            search[i] = clamp[i] ? 0.0 : s;
+                if(!clamp[j]) sd -= invH[sy(i, j)] * gc[j];
+            search[i] = clamp[i] ? 0.0 : sd;
         }
-
         double sdotg = 0.0;
 #pragma unroll
         for(int i = 0; i < M; i++) sdotg += search[i] * grad[i];
-        if(sdotg >= 0.0) return -2;
+        if(rc == 0 && sdotg >= 0.0) rc = -2;  // boxQP.c:189-196
 
-        double step = 1.0, vc;
-        for(;;) {
+        // Armijo backtracking (boxQP.c:199-227): step = 1, 0.6, 0.6*0.6, ... until the candidate passes.
+        // Most calls pass at once, but the lanes of a wavefront wait for the slowest one (measured: 1.5 trials
+        // per lane, 9 per wavefront), so the loop is built for the long case: TWO consecutive step sizes are
+        // evaluated per trip, as independent instruction streams, and the acceptance test avoids the division
+        // (armijo_passes).  The sequence of step sizes, the order of the exits and every value are the
+        // reference's.
+        double step = 1.0, vc = value;
+        double xc[M];
+#pragma unroll
+        for(int i = 0; i < M; i++) xc[i] = x[i];
+        bool searching = (rc == 0);
+        if(pf) pf->probe(2);
+        while(searching) {
+            const double step2 = step * step_dec;
+            double xc1[M], xc2[M];
 #pragma unroll
             for(int i = 0; i < M; i++) {
-                xc[i] = x[i] + step * search[i];
-                if(xc[i] > upper[i]) xc[i] = upper[i];
-                if(xc[i] < lower[i]) xc[i] = lower[i];
+                xc1[i] = x[i] + step * search[i];
+                if(xc1[i] > upper[i]) xc1[i] = upper[i];
+                if(xc1[i] < lower[i]) xc1[i] = lower[i];
+                xc2[i] = x[i] + step2 * search[i];
+                if(xc2[i] > upper[i]) xc2[i] = upper[i];
+                if(xc2[i] < lower[i]) xc2[i] = lower[i];
             }
-            vc = qp_value<M>(H, g, xc);
-            if(((vc - oldvalue) / (step * sdotg)) >= armijo) break;
-            step = step * step_dec;
-            if(step < min_step) return 2;
-        }
+            const double vc1 = qp_value<M>(H, g, xc1);
+            const double vc2 = qp_value<M>(H, g, xc2);
+            const bool pass1 = armijo_passes(vc1, oldvalue, step, sdotg, armijo);
+            const bool pass2 = armijo_passes(vc2, oldvalue, step2, sdotg, armijo);
+            const double step3 = step2 * step_dec;
+            // what the reference's loop does with these two trials, in its order
+            const bool out_of_steps = !pass1 && ((step2 < min_step) || (!pass2 && step3 < min_step));
+            const bool take1 = pass1, take2 = !pass1 && !(step2 < min_step) && pass2;
 #pragma unroll
-        for(int i = 0; i < M; i++) x[i] = xc[i];
-        value = vc;
+            for(int i = 0; i < M; i++) xc[i] = take1 ? xc1[i] : (take2 ? xc2[i] : xc[i]);
+            vc = take1 ? vc1 : (take2 ? vc2 : vc);
+            if(out_of_steps) rc = 2;
+            step = step3;
+            searching = !(take1 || take2 || out_of_steps);
+        }
+        if(pf) pf->probe(4);
+        const bool accepted = (rc == 0);
+#pragma unroll
+        for(int i = 0; i < M; i++) x[i] = accepted ? xc[i] : x[i];
+        value = accepted ? vc : value;
+        if(rc != 0) break;
     }
-    return 1;
+    return rc ? rc : 1;  // 1: max_iter iterations (boxQP.c:237)
 }
 
 // ---------------------------------------------------------------------------
@@ -305,7 +384,8 @@ struct RecLayout {
 // Returns the box-QP code (< 1 means the sweep must be abandoned: the outputs are then meaningless).
 template <int NX, int NU, bool FULL, bool HX>
 ILQG_DEV int back_step(const double *r, const double *uk, double *Vx, double *Vxx, double *l, double *K,
-                       const double lambda, const int regType, double &dV0, double &dV1, double &gsum) {
+                       const double lambda, const int regType, double &dV0, double &dV1, double &gsum,
+                       Prof *pf = nullptr) {
     using R = RecLayout<NX, NU, FULL, HX>;
     constexpr int SXX = R::SXX, SUU = R::SUU, NXU = R::NXU;
     const double *cx = r + R::CX, *cxx = r + R::CXX, *cu = r + R::CU, *cuu = r + R::CUU, *cxu = r + R::CXU;
@@ -393,7 +473,9 @@ ILQG_DEV int back_step(const double *r, const double *uk, double *Vx, double *Vx
 
     int clamp[NU], n_free;
     double invH[SUU];
-    const int rc = box_qp<NU>(QuuF, Qu, lower, upper, l, clamp, n_free, invH);
+    if(pf) pf->probe(1);
+    const int rc = box_qp<NU>(QuuF, Qu, lower, upper, l, clamp, n_free, invH, pf);
+    if(pf) pf->probe(2);
     // No early return on rc < 1 (back_pass.c:168-171 abandons the sweep there): the rest of the step is
     // evaluated for every lane and the CALLER drops the lanes with rc < 1 afterwards.  A divergent return
     // here would put everything below under its own exec-mask region, cut off from the code the caller
@@ -479,6 +561,7 @@ ILQG_DEV int back_step(const double *r, const double *uk, double *Vx, double *Vx
         if(gi > gmax) gmax = gi;
     }
     gsum += gmax;
+    if(pf) pf->probe(5);
     return rc;
 }
 

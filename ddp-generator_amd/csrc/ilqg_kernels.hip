@@ -493,6 +493,10 @@ __device__ __forceinline__ void store_gains(const double *l, const double *K, do
     for(int i = 0; i < NXU; i++) ko[i * SI] = K[i];
 }
 
+#ifdef ILQG_PROFILE_SECTIONS
+__device__ unsigned long long ilqg_prof_cycles[8];  // summed over wavefronts: see tools/section_profile.py
+#endif
+
 // one sweep k = N-1..0; returns 0 ok, 1 box-QP failed (back_pass.c:168-171)
 __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double lambda, int regType, double &dV0,
                                               double &dV1, double &g_norm) {
@@ -612,8 +616,16 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
 #pragma unroll
     for(int i = 0; i < NU; i++) un[i] = (up - us)[i * SI];
     int result = 0;
+#ifdef ILQG_PROFILE_SECTIONS
+    Prof prof;
+    prof.start();
+    Prof *pf = &prof;
+#else
+    Prof *pf = nullptr;
+#endif
     drain_memory_ops();
     for(int k = N - 1; k >= 0; k--) {
+        if(pf) pf->probe(7);
         // step k-2 (clamped at step 0, so that the pipeline below needs no special case at its end: the
         // last iteration evaluates the record of step 0 once more and discards it)
         double xnn[NX], unn[NU];
@@ -622,7 +634,8 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
         for(int i = 0; i < NX; i++) xnn[i] = (xp - back * xs)[i * SI];
 #pragma unroll
         for(int i = 0; i < NU; i++) unn[i] = (up - back * us)[i * SI];
-        const int rc = back_step<NX, NU, FULL, HX>(cur, uk, Vx, Vxx, l, K, lambda, regType, dV0, dV1, gsum);
+        if(pf) pf->probe(0);
+        const int rc = back_step<NX, NU, FULL, HX>(cur, uk, Vx, Vxx, l, K, lambda, regType, dV0, dV1, gsum, pf);
         double nxt[REC];
         // The value-function update above is only needed by the next iteration, so the optimiser would
         // sink it behind the exit tests below, into a block of its own, where it cannot overlap with
@@ -641,6 +654,7 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
             result = 2;
             break;
         }
+        if(pf) pf->probe(6);
         store_gains(l, K, lo, ko);
         if(rc < 1) {
             result = 1;
@@ -661,6 +675,10 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
     }
 #undef GETF
     if(!result) g_norm = gsum / ((double)(N - 1));
+#ifdef ILQG_PROFILE_SECTIONS
+    if((threadIdx.x & 63) == 0)
+        for(int i = 0; i < 8; i++) atomicAdd(&ilqg_prof_cycles[i], (unsigned long long)prof.acc[i]);
+#endif
     return result;
 }
 
@@ -1558,6 +1576,17 @@ int ilqg_dev_field_steps(ilqg_dev_t *d, int field) { return field_steps(d, field
 void *ilqg_dev_field_ptr(ilqg_dev_t *d, int field) { return d->P.f[field]; }
 void *ilqg_dev_stream(ilqg_dev_t *d) { return (void *)d->stream; }
 
+// a per-trajectory scalar field (B doubles) into device memory of the caller, on the context's stream
+int ilqg_dev_copy_scalar_to(ilqg_dev_t *d, int field, void *dst_device) {
+    HIP_TRY(hipSetDevice(d->device));
+    if(field < ILQG_F_COST || field >= ILQG_F_ALPHA_COST) {
+        g_err = "ilqg_dev_copy_scalar_to: not a per-trajectory scalar field";
+        return 1;
+    }
+    HIP_TRY(hipMemcpyAsync(dst_device, d->P.f[field], (size_t)d->B * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+    return 0;
+}
+
 int ilqg_dev_write(ilqg_dev_t *d, int field, const double *host) {
     return ilqg_dev_write_steps(d, field, host, field_steps(d, field));
 }
@@ -1873,6 +1902,19 @@ int ilqg_dev_count_active(ilqg_dev_t *d, int *n_active) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(n_active, d->counter, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+// cycle accounting of -DILQG_PROFILE_SECTIONS builds: reads and clears the 8 section counters (zeros otherwise)
+int ilqg_dev_section_cycles(unsigned long long *out) {
+#ifdef ILQG_PROFILE_SECTIONS
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(ilqg_prof_cycles), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ilqg_prof_cycles), z, sizeof(z)));
+#else
+    for(int i = 0; i < 8; i++) out[i] = 0;
+#endif
     return 0;
 }
 

@@ -123,6 +123,8 @@ int ilqg_dev_field_steps(ilqg_dev_t *d, int field);  /* time steps stored */
 /* device address of a per-trajectory scalar field (for collectives on device memory) */
 void *ilqg_dev_field_ptr(ilqg_dev_t *d, int field);
 void *ilqg_dev_stream(ilqg_dev_t *d);
+/* a per-trajectory scalar field (batch doubles) into device memory of the caller, on the context's stream */
+int ilqg_dev_copy_scalar_to(ilqg_dev_t *d, int field, void *dst_device);
 
 /* stages (all asynchronous on the context's stream) */
 int ilqg_dev_reset(ilqg_dev_t *d);            /* solver entry state (iLQG.c:226-237) */
@@ -137,6 +139,9 @@ int ilqg_dev_update(ilqg_dev_t *d);           /* accept/reject bookkeeping (iLQG
 int ilqg_dev_iterate(ilqg_dev_t *d, int n);   /* n lock-step iterations */
 int ilqg_dev_sync(ilqg_dev_t *d);
 int ilqg_dev_count_active(ilqg_dev_t *d, int *n_active); /* synchronises */
+
+/* builds with -DILQG_PROFILE_SECTIONS: cycles per section of the fused backward step, summed over wavefronts */
+int ilqg_dev_section_cycles(unsigned long long *out8);
 
 /* per-kernel HIP-event timing on the context's stream */
 int ilqg_dev_timing(ilqg_dev_t *d, int enable);

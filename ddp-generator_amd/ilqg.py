@@ -58,6 +58,10 @@ def load_library(problem="carparking", full_ddp=0, strict=False):
     lib.ilqg_problem_param_size.argtypes = [C.c_int]
     lib.ilqg_batch_create.restype = v
     lib.ilqg_batch_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.ilqg_batch_create_groups.restype = v
+    lib.ilqg_batch_create_groups.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.ilqg_batch_groups.argtypes = [v]
+    lib.ilqg_batch_scalar_to_device.argtypes = [v, C.c_char_p, v]
     lib.ilqg_batch_destroy.argtypes = [v]
     lib.ilqg_batch_error.restype = C.c_char_p
     lib.ilqg_batch_error.argtypes = [v]
@@ -118,11 +122,13 @@ class BatchSolver:
     """B trajectories of one problem advanced in lock step on one GPU."""
 
     def __init__(self, problem="carparking", full_ddp=0, batch=1, n_hor=500, device=0, params=None, opts=None,
-                 strict=False):
+                 strict=False, groups=0):
+        """groups: the batch advances as that many independent sets of trajectories on separate HIP streams
+        (0 = the library's choice, see ilqg_batch_create_groups)"""
         self.problem = Problem(problem, full_ddp, strict)
         self.lib = self.problem.lib
         self.B, self.N = int(batch), int(n_hor)
-        self.h = self.lib.ilqg_batch_create(int(device), self.B, self.N)
+        self.h = self.lib.ilqg_batch_create_groups(int(device), self.B, self.N, int(groups))
         if not self.h:
             raise IlqgError(self.lib.ilqg_batch_error(None).decode())
         for k, val in (params or {}).items():
@@ -258,6 +264,13 @@ class BatchSolver:
     # -- plumbing for collectives / profiling ------------------------------
     def cost_device_ptr(self):
         return self.lib.ilqg_batch_cost_device_ptr(self.h)
+
+    def groups(self):
+        return int(self.lib.ilqg_batch_groups(self.h))
+
+    def scalar_to_device(self, name, device_ptr):
+        """per-trajectory scalar of the whole batch into caller-owned device memory (B doubles), no host copy"""
+        self._ck(self.lib.ilqg_batch_scalar_to_device(self.h, name.encode(), C.c_void_p(int(device_ptr))))
 
     def stream(self):
         return self.lib.ilqg_batch_stream(self.h)

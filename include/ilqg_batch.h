@@ -44,6 +44,12 @@ int ilqg_problem_param_size(int i);
 int ilqg_device_count(void);
 
 ilqg_batch_t *ilqg_batch_create(int device, int batch, int n_hor); /* NULL on failure (ilqg_batch_error(NULL)) */
+/* The batch is advanced as `groups` independent sets of consecutive trajectories, each on its own HIP stream,
+ * so that the latency-bound kernels of one set overlap with the throughput-bound ones of another.  Results do
+ * not depend on it.  groups = 0 (what ilqg_batch_create passes): ILQG_GROUPS from the environment, else 3 for
+ * batches >= 8192 in the one-lane-per-trajectory mapping (measured best at 65 536 trajectories), else 1.  At most 4. */
+ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int groups);
+int ilqg_batch_groups(const ilqg_batch_t *c);
 void ilqg_batch_destroy(ilqg_batch_t *c);
 const char *ilqg_batch_error(const ilqg_batch_t *c);
 
@@ -105,8 +111,11 @@ int ilqg_batch_set_scalar(ilqg_batch_t *c, const char *name, const double *in);
 int ilqg_batch_get_int(ilqg_batch_t *c, const char *name, int *out);
 int ilqg_batch_set_int(ilqg_batch_t *c, const char *name, const int *in);
 
-/* device address of the per-trajectory cost vector (B doubles, for a collective
- * over device memory) and the HIP stream all work of this context runs on */
+/* For a collective over device memory: a per-trajectory scalar of the whole batch ("cost", ...) copied device to
+ * device into `dst_device` (batch doubles, contiguous); synchronises.  ilqg_batch_cost_device_ptr is the address
+ * of the cost vector itself while the batch is ONE group (NULL otherwise); ilqg_batch_stream the HIP stream of
+ * the first group. */
+int ilqg_batch_scalar_to_device(ilqg_batch_t *c, const char *name, void *dst_device);
 void *ilqg_batch_cost_device_ptr(ilqg_batch_t *c);
 void *ilqg_batch_stream(ilqg_batch_t *c);
 

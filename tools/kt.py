@@ -9,7 +9,7 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 split = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 B = 65536
 x0, u0 = synth.car_batch(B, 500)
-s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=K + 2, ls_split=split))
+s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=K + 2, ls_split=split), groups=int(os.environ.get("NGROUPS", "0")))
 s.init(x0, u0); s.iterate(2); s.sync(); s.init(x0, u0)
 s.timing(False)
 t0 = time.perf_counter(); s.iterate(K); s.sync(); dt = time.perf_counter() - t0
