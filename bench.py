@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resweep", type=int, default=-1, help="-1: library default (off without multipliers)")
     ap.add_argument("--fuse-derivs", type=int, default=1)
-    ap.add_argument("--ls-split", type=int, default=5)
+    ap.add_argument("--ls-split", type=int, default=3)
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary run with materialised derivative records")
     ap.add_argument("--groups", type=int, default=0,
                     help="independent sets of trajectories advanced on separate HIP streams (0: library default)")
@@ -187,9 +187,13 @@ def main():
 
     # secondary, untimed for `value`: the same iterations with the derivative records materialised in
     # HBM (k_derivs + k_backward<0>), the two kernels the HBM roofline of SURVEY 8(d) was written for
+    # It runs as ONE group of trajectories, so that a launch covers the whole batch and nothing else is on the GPU
+    # while it is timed (the timed run above overlaps the kernels of several groups).
     unfused = {}
     if rank == 0 and args.fuse_derivs and not args.no_unfused and not s.problem.wave_mapping:
-        s.set_option("fuse_derivs", 0)
+        s.close()
+        s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=N_HOR, device=local, params=params,
+                             opts=dict(max_iter=max(K, W) + 1, fuse_derivs=0, ls_split=args.ls_split), groups=1)
         s.init(x0, u0)
         s.timing(True)
         s.iterate(5)
@@ -199,10 +203,14 @@ def main():
                 b_alg = ALG_BYTES[kname] * N_HOR * B
                 unfused[kname] = {"avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": b_alg,
                                   "achieved_GBs": b_alg / (ms / n * 1e-3) / 1e9,
-                                  "frac_of_peak": b_alg / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                  "frac_of_peak": b_alg / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "stream_groups": 1}
     if rank == 0:
         per_iter = {k: v[1] / max(1, K) for k, v in times.items() if v[0]}
-        dominant = max((k for k in per_iter if k in ALG_BYTES), key=lambda k: per_iter[k])
+        # the kernel the HBM roofline is about: the one that accounts for most ALGORITHMIC bytes of an iteration
+        # (the backward pass incl. derivatives: 1 024 of 1 200 B per step and trajectory; the roll-outs read 128 B
+        # shared by all step sizes and are fp64-VALU bound — their times are in kernels_ms_per_iteration)
+        dominant = max((k for k in per_iter if k in ALG_BYTES), key=lambda k: ALG_BYTES[k] * times[k][0])
         n_launch, total_ms = times[dominant]
         avg_ms = total_ms / n_launch
         # per launch; in the wave mapping a kernel is launched once per chunk of trajectories per iteration
@@ -211,10 +219,7 @@ def main():
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (tools/collect_traffic.sh), if committed
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and B == 65536 and car and not s.problem.wave_mapping:
-            key = dominant
-            if dominant == "k_rollout[search]":  # the profiler sees one k_rollout; its modes differ by grid size
-                key = "k_rollout[grid=%d]" % (B * (args.ls_split if 0 < args.ls_split < 8 else 8))
-            traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(dominant, {}).get("hbm_bytes_per_launch")
         iter_bytes = ITERATION_BYTES * N_HOR * B
         out = {
             "metric": ("iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)" if car else
@@ -241,12 +246,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_launch,
-                         "note": "achieved = ALGORITHMIC bytes of SURVEY 8(d) / HIP-event time. For "
-                                 "k_backward[fused derivs] that is the figure of the two kernels it replaces "
-                                 "(k_derivs 488 B + k_backward 536 B per step and trajectory), as SURVEY 8(d) "
-                                 "prescribes; the fused kernel itself moves 128 B per step and trajectory and is "
-                                 "bound by fp64 VALU issue, so frac can exceed 1. See unfused_kernels for the "
-                                 "HBM-bound kernels measured in the same run.",
+                         "note": "achieved = ALGORITHMIC bytes of SURVEY 8(d) per launch / average HIP-event "
+                                 "time of a launch. For k_backward[fused derivs] that is the figure of the two "
+                                 "kernels it replaces (k_derivs 488 B + k_backward 536 B per step and trajectory), "
+                                 "as SURVEY 8(d) prescribes; the fused kernel itself moves 128 B per step and "
+                                 "trajectory (= traffic) and is bound by fp64 VALU issue, not by HBM. The batch "
+                                 "advances as stream_groups sets of trajectories on separate streams: a launch "
+                                 "covers one set and shares the GPU with the kernels of the others while it is "
+                                 "timed. See unfused_kernels for the HBM-bound kernels measured alone, and "
+                                 "iteration_roofline for the whole iteration.",
                          "moved_bytes_per_launch": (FUSED_MOVED_BYTES * N_HOR * B) if "fused" in dominant else alg_bytes},
             "unfused_kernels": unfused,
             "iteration_roofline": {"algorithmic_bytes_per_iteration": iter_bytes,

@@ -248,7 +248,7 @@ ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int gro
      * gets bit-identical costs from it, so it is skipped unless asked for */
     c->resweep = (sizeof(multipliersEl_t) > 0 || sizeof(multipliersFin_t) > 0) ? 1 : 0;
     c->fuse_derivs = 1;
-    c->ls_split = 5;
+    c->ls_split = 3;
     standard_parameters(&c->opt);
     if(groups <= 0) {
         const char *e = getenv("ILQG_GROUPS");

@@ -226,6 +226,7 @@ struct DevPtrs {
     int *n_pending;      // their count (read by the second stage)
     int *n_pending_next; // counter the first-stage selection appends with (same word as n_pending)
     trajEl_t *work;      // wave mapping: derivative records of one chunk of trajectories, [chunk][N]
+    double *nom;         // packed trajectory records, see nomp()
     double **p;
     int B, Bp, N;
 };
@@ -239,12 +240,11 @@ __device__ __forceinline__ void drain_memory_ops() { __builtin_amdgcn_s_waitcnt(
 // "this value is needed HERE": keeps the optimiser from sinking its computation into a later block
 __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
 
-// Layout of a per-step field of width W (doubles per step and trajectory) with `steps` time steps.
-//   lane mapping: [step][tile of 64 trajectories][component][trajectory in tile] — the 64 lanes of a
-//                 wavefront read one component as 512 contiguous bytes, the components of a step sit
-//                 at FIXED distances of 512 bytes (instruction immediates), and one pointer per field,
-//                 advanced by W*Bp doubles per step, addresses everything a lane touches;
-//   wave mapping: [trajectory][step][component] (trajectory-major, = the host layout).
+// Layout of the derivative-record fields (DER, FIN) of width W (doubles per step and trajectory):
+//   lane mapping: [step][tile of 64 trajectories][component][trajectory in tile] — k_derivs, lane = (trajectory,
+//                 step), writes and the backward kernel, lane = trajectory, reads one component as 512 contiguous
+//                 bytes per wavefront; the components of a step sit at fixed distances of 512 bytes;
+//   wave mapping: trajEl_t structs / [trajectory][component] (FIN).
 constexpr int SI = WAVE_MAP ? 1 : WAVE;  // distance between components
 __device__ __forceinline__ size_t step_stride(const DevPtrs &P, int W) { return WAVE_MAP ? (size_t)W : (size_t)W * P.Bp; }
 __device__ __forceinline__ size_t traj_off(const DevPtrs &P, int W, int steps, int b) {
@@ -252,10 +252,42 @@ __device__ __forceinline__ size_t traj_off(const DevPtrs &P, int W, int steps, i
 }
 // component i of a width-W, single-step field that is tiled in BOTH mappings (per-step-size costs)
 __device__ __forceinline__ size_t tile_ix(int W, int i, int b) { return (size_t)(b >> 6) * (W * WAVE) + (size_t)i * WAVE + (b & 63); }
-// element (step k, component i of W) of trajectory b
+// The trajectory fields X, U, l, L live in ONE packed record per trajectory and time step,
+//     nom[trajectory][step 0..N][ x (N_X) | u (N_U) | l (N_U) | L (N_U*N_X) ]        (step N holds x_N only)
+// i.e. what a lane of the roll-out reads of the nominal trajectory per step is one contiguous piece (128 bytes =
+// one cache line for CarParking), the step stride is a compile-time constant, and a lane's accesses do not depend
+// on which other trajectories share its wavefront.  Measured (tools/ubench/layout_gather.hip): with the next step
+// prefetched this costs the same as a [step][tile][component][lane] layout when the lanes are consecutive
+// trajectories, and — unlike it — nothing extra when they are an arbitrary subset (the compacted second stage of
+// the line search: up to 2x there, 6-13x for a full shuffle).  Four separate trajectory-major arrays, on the other
+// hand, fetch four partly used cache lines per lane and step and were measured 2x slower.
+constexpr int NOM_X = 0, NOM_U = NX, NOM_L = NX + NU, NOM_K = NX + 2 * NU;
+constexpr int RN = (NX + 2 * NU + NXU + 1) / 2 * 2;  // doubles per record (even: 16-byte aligned pieces)
+__device__ __forceinline__ double *nomp(const DevPtrs &P, int k, int b) {
+    return P.nom + ((size_t)b * (P.N + 1) + k) * RN;
+}
+// element (step k, component i of W) of trajectory b of a derivative-record field (DER, FIN)
 __device__ __forceinline__ size_t ix(const DevPtrs &P, int W, int steps, int k, int i, int b) {
     return traj_off(P, W, steps, b) + (size_t)k * step_stride(P, W) + (size_t)i * SI;
 }
+
+// In the lane mapping the trajectory (x, u) exists twice.  The packed records above are what the line search reads
+// (lane = any trajectory).  Writing them from a roll-out is slow, though: a lane-per-trajectory store touches 64
+// different cache lines, and a step of the winner pass is short (measured: the pass doubles from 1.1 to 2.1 ms).
+// So the roll-outs STORE into tiled arrays X and U, [step][tile of 64][component][trajectory in tile], 512
+// contiguous bytes per component and wavefront, which the passes over consecutive trajectories also read
+// (derivatives, backward pass, cost sweep, host copies); and the backward pass, whose steps are long enough to
+// absorb scattered stores, copies each (x_k, u_k) it reads into the record it completes with the gains of step k.
+// The records are therefore current whenever a line search starts.  (Wave mapping: records only.)
+constexpr int XSI = WAVE_MAP ? 1 : WAVE;  // distance between components of x / u in that representation
+__device__ __forceinline__ double *cur_x(const DevPtrs &P, int k, int b) {
+    return WAVE_MAP ? nomp(P, k, b) + NOM_X : P.f[ILQG_F_X] + ix(P, NX, P.N + 1, k, 0, b);
+}
+__device__ __forceinline__ double *cur_u(const DevPtrs &P, int k, int b) {
+    return WAVE_MAP ? nomp(P, k, b) + NOM_U : P.f[ILQG_F_U] + ix(P, NU, P.N, k, 0, b);
+}
+__device__ __forceinline__ size_t cur_xstride(const DevPtrs &P) { return WAVE_MAP ? (size_t)RN : (size_t)NX * P.Bp; }
+__device__ __forceinline__ size_t cur_ustride(const DevPtrs &P) { return WAVE_MAP ? (size_t)RN : (size_t)NU * P.Bp; }
 
 // Per-lane snapshot of the problem parameters.  The generated callbacks read parameters as
 // p[i][j] through a `double **`; read from global memory, every such value would have to be
@@ -338,6 +370,22 @@ __global__ void k_to_dev(const double *__restrict__ host, double *__restrict__ d
     const int b = (int)(i / ((size_t)wd * steps));
     dev[(size_t)k * wd * Bp + (size_t)(b >> 6) * (wd * WAVE) + (size_t)fcol * WAVE + (b & 63)] =
         host[((size_t)b * steps + k) * wh + fcol];
+}
+
+// host [b][steps][w]  <->  columns [col0, col0 + w) of the packed trajectory records nom[b][0..N][RN]
+__global__ void k_nom_io(double *__restrict__ nom, double *__restrict__ host, int B, int N, int steps, int w, int col0,
+                         int to_device) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * steps * w;
+    if(i >= total) return;
+    const int c = (int)(i % w);
+    const int k = (int)((i / w) % steps);
+    const int b = (int)(i / ((size_t)w * steps));
+    double *rec = nom + ((size_t)b * (N + 1) + k) * RN + col0 + c;
+    if(to_device)
+        *rec = host[i];
+    else
+        host[i] = *rec;
 }
 
 __global__ void k_from_dev(const double *__restrict__ dev, double *__restrict__ host, int B, int Bp, int steps, int wh,
@@ -446,12 +494,18 @@ __global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O, Pa
     if(k < P.N) {
         trajEl_t t;
         init_running(&t, &C.o1);
-        const double *xs = P.f[ILQG_F_X] + ix(P, NX, P.N + 1, k, 0, b);
-        const double *us = P.f[ILQG_F_U] + ix(P, NU, P.N, k, 0, b);
+        const double *xs = cur_x(P, k, b), *us = cur_u(P, k, b);
 #pragma unroll
-        for(int i = 0; i < NX; i++) t.x[i] = xs[i * SI];
+        for(int i = 0; i < NX; i++) t.x[i] = xs[i * XSI];
 #pragma unroll
-        for(int i = 0; i < NU; i++) t.u[i] = us[i * SI];
+        for(int i = 0; i < NU; i++) t.u[i] = us[i * XSI];
+        {  // keep the line search's records current (see cur_x)
+            double *rec = nomp(P, k, b);
+#pragma unroll
+            for(int i = 0; i < NX; i++) rec[NOM_X + i] = t.x[i];
+#pragma unroll
+            for(int i = 0; i < NU; i++) rec[NOM_U + i] = t.u[i];
+        }
         ok = derivs_step(t, C, H, k, P.N, [] {});
         double *out = P.f[ILQG_F_DER] + ix(P, REC, P.N, k, 0, b);
 #define PUT(off, arr, cnt) _Pragma("unroll") for(int i = 0; i < (cnt); i++) out[((off) + i) * SI] = (arr)[i];
@@ -459,9 +513,14 @@ __global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O, Pa
     } else {
         trajFin_t fin;
         init_final(&fin, &C.o);
-        const double *xs = P.f[ILQG_F_X] + ix(P, NX, P.N + 1, P.N, 0, b);
+        const double *xs = cur_x(P, P.N, b);
 #pragma unroll
-        for(int i = 0; i < NX; i++) fin.x[i] = xs[i * SI];
+        for(int i = 0; i < NX; i++) fin.x[i] = xs[i * XSI];
+        {
+            double *rec = nomp(P, P.N, b);
+#pragma unroll
+            for(int i = 0; i < NX; i++) rec[NOM_X + i] = fin.x[i];
+        }
         ok = derivs_final(fin, C, H, P.N);
         double *out = P.f[ILQG_F_FIN] + ix(P, FIN, 1, 0, 0, b);
         PUT(0, fin.cx, NX)
@@ -478,7 +537,7 @@ __device__ __forceinline__ void load_record(double *dst, double *udst, const dou
 #pragma unroll
     for(int i = 0; i < REC; i++) dst[i] = src[i * SI];
 #pragma unroll
-    for(int i = 0; i < NU; i++) udst[i] = us[i * SI];
+    for(int i = 0; i < NU; i++) udst[i] = us[i * XSI];
 }
 
 // The gains of a step are stored right behind its arithmetic, i.e. BEHIND the prefetch of the next step's inputs
@@ -488,9 +547,9 @@ __device__ __forceinline__ void load_record(double *dst, double *udst, const dou
 // retry rewrites all gains.
 __device__ __forceinline__ void store_gains(const double *l, const double *K, double *lo, double *ko) {
 #pragma unroll
-    for(int i = 0; i < NU; i++) lo[i * SI] = l[i];
+    for(int i = 0; i < NU; i++) lo[i] = l[i];
 #pragma unroll
-    for(int i = 0; i < NXU; i++) ko[i * SI] = K[i];
+    for(int i = 0; i < NXU; i++) ko[i] = K[i];
 }
 
 #ifdef ILQG_PROFILE_SECTIONS
@@ -515,10 +574,11 @@ __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double la
 
     // pointers to step k of this lane's trajectory, walked backwards
     const double *rp = P.f[ILQG_F_DER] + ix(P, REC, N, N - 1, 0, b);
-    const double *up = P.f[ILQG_F_U] + ix(P, NU, N, N - 1, 0, b);
-    double *lo = P.f[ILQG_F_LG] + ix(P, NU, N, N - 1, 0, b);
-    double *ko = P.f[ILQG_F_KG] + ix(P, NXU, N, N - 1, 0, b);
-    const size_t rs = step_stride(P, REC), us = step_stride(P, NU), ks = step_stride(P, NXU);
+    const double *up = cur_u(P, N - 1, b);
+    double *lo = nomp(P, N - 1, b) + NOM_L;
+    double *ko = nomp(P, N - 1, b) + NOM_K;
+    const size_t rs = step_stride(P, REC), us = cur_ustride(P);
+    constexpr int ks = RN;
 
     double cur[REC], ucur[NU];
     load_record(cur, ucur, rp, up);
@@ -536,7 +596,7 @@ __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double la
         }
         rp -= rs;
         up -= us;
-        lo -= us;
+        lo -= ks;
         ko -= ks;
 #pragma unroll
         for(int i = 0; i < REC; i++) cur[i] = nxt[i];
@@ -556,18 +616,22 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
                                                     double &dV0, double &dV1, double &g_norm) {
     const int N = P.N;
     H.nonfinite = 0.0;
-    const double *xp = P.f[ILQG_F_X] + ix(P, NX, N + 1, N, 0, b);
-    const double *up = P.f[ILQG_F_U] + ix(P, NU, N, N - 1, 0, b);
-    double *lo = P.f[ILQG_F_LG] + ix(P, NU, N, N - 1, 0, b);
-    double *ko = P.f[ILQG_F_KG] + ix(P, NXU, N, N - 1, 0, b);
-    const size_t xs = step_stride(P, NX), us = step_stride(P, NU), ks = step_stride(P, NXU);
+    const double *xp = cur_x(P, N, b);
+    const double *up = cur_u(P, N - 1, b);
+    double *rec_k = nomp(P, N - 1, b);  // record of step k, completed here: (x_k, u_k) as read + the gains
+    const size_t xs = cur_xstride(P), us = cur_ustride(P);
 
     double Vx[NX], Vxx[SXX], l[NU], K[NXU];
     {
         trajFin_t fin;
         init_final(&fin, &C.o);
 #pragma unroll
-        for(int i = 0; i < NX; i++) fin.x[i] = xp[i * SI];
+        for(int i = 0; i < NX; i++) fin.x[i] = xp[i * XSI];
+        if(!WAVE_MAP) {
+            double *recN = nomp(P, N, b);
+#pragma unroll
+            for(int i = 0; i < NX; i++) recN[NOM_X + i] = fin.x[i];
+        }
         const int ok = derivs_final(fin, C, H, N);
         if(!ok || H.nonfinite != 0.0) return 2;
 #pragma unroll
@@ -588,7 +652,7 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
     // fill the latency of one with the other.
     trajEl_t t;
     init_running(&t, &C.o1);  // constant entries of the record (iLQG_func.tem:312-347)
-    double uk[NU];            // control of the step whose record is in `cur`
+    double xk[NX], uk[NU];    // state and control of the step whose record is in `cur`
     double cur[REC];
 #define GETF(off, arr, cnt) _Pragma("unroll") for(int i = 0; i < (cnt); i++) rec[(off) + i] = (arr)[i];
     auto record_of = [&](const double *xv, const double *uv, int k, double *rec, auto &&overlapped) {
@@ -601,20 +665,19 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
         return ok;
     };
     {
-        double xv[NX];
 #pragma unroll
-        for(int i = 0; i < NX; i++) xv[i] = xp[i * SI];
+        for(int i = 0; i < NX; i++) xk[i] = xp[i * XSI];
 #pragma unroll
-        for(int i = 0; i < NU; i++) uk[i] = up[i * SI];
-        const int ok = record_of(xv, uk, N - 1, cur, [] {});
+        for(int i = 0; i < NU; i++) uk[i] = up[i * XSI];
+        const int ok = record_of(xk, uk, N - 1, cur, [] {});
         if(!ok || H.nonfinite != 0.0) return 2;
     }
     // (x, u) of step k-1, loaded one iteration ahead of their use (N >= 2)
     double xn[NX], un[NU];
 #pragma unroll
-    for(int i = 0; i < NX; i++) xn[i] = (xp - xs)[i * SI];
+    for(int i = 0; i < NX; i++) xn[i] = (xp - xs)[i * XSI];
 #pragma unroll
-    for(int i = 0; i < NU; i++) un[i] = (up - us)[i * SI];
+    for(int i = 0; i < NU; i++) un[i] = (up - us)[i * XSI];
     int result = 0;
 #ifdef ILQG_PROFILE_SECTIONS
     Prof prof;
@@ -631,9 +694,9 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
         double xnn[NX], unn[NU];
         const int back = (k > 1) ? 2 : k;
 #pragma unroll
-        for(int i = 0; i < NX; i++) xnn[i] = (xp - back * xs)[i * SI];
+        for(int i = 0; i < NX; i++) xnn[i] = (xp - back * xs)[i * XSI];
 #pragma unroll
-        for(int i = 0; i < NU; i++) unn[i] = (up - back * us)[i * SI];
+        for(int i = 0; i < NU; i++) unn[i] = (up - back * us)[i * XSI];
         if(pf) pf->probe(0);
         const int rc = back_step<NX, NU, FULL, HX>(cur, uk, Vx, Vxx, l, K, lambda, regType, dV0, dV1, gsum, pf);
         double nxt[REC];
@@ -655,7 +718,14 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
             break;
         }
         if(pf) pf->probe(6);
-        store_gains(l, K, lo, ko);
+        // the record of step k for the line search: gains, and (lane mapping) the (x_k, u_k) they belong to
+        store_gains(l, K, rec_k + NOM_L, rec_k + NOM_K);
+        if(!WAVE_MAP) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) rec_k[NOM_X + i] = xk[i];
+#pragma unroll
+            for(int i = 0; i < NU; i++) rec_k[NOM_U + i] = uk[i];
+        }
         if(rc < 1) {
             result = 1;
             break;
@@ -664,8 +734,9 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
         for(int i = 0; i < REC; i++) cur[i] = nxt[i];
         xp -= xs;
         up -= us;
-        lo -= us;
-        ko -= ks;
+        rec_k -= RN;
+#pragma unroll
+        for(int i = 0; i < NX; i++) xk[i] = xn[i];
 #pragma unroll
         for(int i = 0; i < NU; i++) uk[i] = un[i];
 #pragma unroll
@@ -755,8 +826,8 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
         trajEl_t *t = P.work + (size_t)bw * P.N + k;
         if(init_consts) init_running(t, &C.o1);  // constant entries, once per buffer (init_opt, iLQG_func.tem:402-415)
         auto body = [&]() {
-            for(int i = 0; i < NX; i++) t->x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, k, i, b)];
-            for(int i = 0; i < NU; i++) t->u[i] = P.f[ILQG_F_U][ix(P, NU, P.N, k, i, b)];
+            for(int i = 0; i < NX; i++) t->x[i] = nomp(P, k, b)[NOM_X + i];
+            for(int i = 0; i < NU; i++) t->u[i] = nomp(P, k, b)[NOM_U + i];
             ok = calcXVariableAux(t, nullptr, k, &o);
             ok &= calcXUVariableAux(t, nullptr, k, &o);
             ok &= calcLAuxDeriv(t, nullptr, k, &o);
@@ -773,7 +844,7 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
         trajFin_t fin;
         init_final(&fin, &o);
         auto body = [&]() {
-            for(int i = 0; i < NX; i++) fin.x[i] = P.f[ILQG_F_X][ix(P, NX, P.N + 1, P.N, i, b)];
+            for(int i = 0; i < NX; i++) fin.x[i] = nomp(P, P.N, b)[NOM_X + i];
             ok = calcFVariableAux(&fin, nullptr, &o);
             ok &= calcFAuxDeriv(&fin, nullptr, &o);
             ok &= bp_derivsF(&fin, P.N, o.p);
@@ -816,9 +887,9 @@ __device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const Dev
 #endif
         F.lower_sign = t->lower_sign; F.upper_sign = t->upper_sign;
         F.lower_hx = t->lower_hx; F.upper_hx = t->upper_hx;
-        F.u = P.f[ILQG_F_U] + ix(P, NU, N, k, 0, b);
-        const int rc = back_step_wave<NX, NU, FULL, HX>(S, F, P.f[ILQG_F_LG] + ix(P, NU, N, k, 0, b),
-                                                        P.f[ILQG_F_KG] + ix(P, NXU, N, k, 0, b), lambda, regType, dV0,
+        F.u = nomp(P, k, b) + NOM_U;
+        const int rc = back_step_wave<NX, NU, FULL, HX>(S, F, nomp(P, k, b) + NOM_L,
+                                                        nomp(P, k, b) + NOM_K, lambda, regType, dV0,
                                                         dV1, gsum);
         if(rc < 1) return 1;
     }
@@ -897,18 +968,19 @@ struct NomPtrs {
     const double *x, *u, *l, *K;
 };
 
-template <bool GAINS>
+// CS: distance between the components of x and u where they are read (1 in the records, XSI in X / U)
+template <bool GAINS, int CS>
 __device__ __forceinline__ void load_nominal(NomStep &s, const NomPtrs &q) {
 #pragma unroll
-    for(int i = 0; i < NX; i++) s.x[i] = q.x[i * SI];
+    for(int i = 0; i < NX; i++) s.x[i] = q.x[i * CS];
 #pragma unroll
-    for(int i = 0; i < NU; i++) s.u[i] = q.u[i * SI];
+    for(int i = 0; i < NU; i++) s.u[i] = q.u[i * CS];
     if(GAINS) {
 #pragma unroll
-        for(int i = 0; i < NU; i++) s.l[i] = q.l[i * SI];
+        for(int i = 0; i < NU; i++) s.l[i] = q.l[i];
         if(!WAVE_MAP) {
 #pragma unroll
-            for(int i = 0; i < NXU; i++) s.K[i] = q.K[i * SI];
+            for(int i = 0; i < NXU; i++) s.K[i] = q.K[i];
         }
     }
 }
@@ -932,7 +1004,9 @@ __device__ __forceinline__ void load_nominal(NomStep &s, const NomPtrs &q) {
 // The time step itself is straight-line code: the generated callbacks' NaN/Inf guards and the
 // huge-argument case of sin/cos are hooks (see ilqg_hooks), tested once per step.
 enum { RK_GENERAL = 0, RK_INIT = 1, RK_COST = 2 };
-#ifndef ILQG_ROLLOUT_ATTR
+#ifdef ILQG_ROLLOUT_WAVES  // experiments: force that many wavefronts of the roll-out kernels per SIMD (register cap)
+#define ILQG_ROLLOUT_ATTR __attribute__((amdgpu_waves_per_eu(ILQG_ROLLOUT_WAVES)))
+#else
 #define ILQG_ROLLOUT_ATTR
 #endif
 
@@ -966,31 +1040,37 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
     init_running(&ct, &C.o1);  // constant auxiliaries of this problem (iLQG_func.tem:312-347)
 
     // this trajectory's step 0 in every field; all of them advance by one step per iteration
+    // The line search reads the packed records; the initial roll-out and the cost sweep read the current (x, u)
+    // where every roll-out stores them (see cur_x).
+    constexpr int CS = (KIND == RK_GENERAL) ? 1 : XSI;
     NomPtrs q;
-    q.x = P.f[ILQG_F_X] + ix(P, NX, N + 1, 0, 0, b);
-    q.u = P.f[ILQG_F_U] + ix(P, NU, N, 0, 0, b);
-    // a stored roll-out (initial, winner) replaces the nominal trajectory in place
-    double *xo = const_cast<double *>(q.x), *uo = const_cast<double *>(q.u);
-    q.l = P.f[ILQG_F_LG] + ix(P, NU, N, 0, 0, b);
-    q.K = P.f[ILQG_F_KG] + ix(P, NXU, N, 0, 0, b);
-    const size_t xs = step_stride(P, NX), us = step_stride(P, NU), ks = step_stride(P, NXU);
+    q.x = (KIND == RK_GENERAL) ? nomp(P, 0, b) + NOM_X : cur_x(P, 0, b);
+    q.u = (KIND == RK_GENERAL) ? nomp(P, 0, b) + NOM_U : cur_u(P, 0, b);
+    q.l = nomp(P, 0, b) + NOM_L;
+    q.K = nomp(P, 0, b) + NOM_K;
+    const size_t xs = (KIND == RK_GENERAL) ? (size_t)RN : cur_xstride(P), us = (KIND == RK_GENERAL) ? (size_t)RN : cur_ustride(P);
+    constexpr int ks = RN;
+    // a stored roll-out (initial, winner) replaces the current trajectory
+    double *xo = cur_x(P, 0, b), *uo = cur_u(P, 0, b);
+    const size_t xos = cur_xstride(P), uos = cur_ustride(P);
+    double *ro = nomp(P, 0, b);  // initial roll-out: the record's copy as well
 
     double xc[NX];
 #pragma unroll
-    for(int i = 0; i < NX; i++) xc[i] = q.x[i * SI];  // x0 (iLQG_func.tem:141-142)
+    for(int i = 0; i < NX; i++) xc[i] = q.x[i * CS];  // x0 (iLQG_func.tem:141-142)
     double csum = 0.0;
     int okc = 1;
     NomStep cur;
-    load_nominal<gains>(cur, q);
+    load_nominal<gains, CS>(cur, q);
     drain_memory_ops();
     for(int k = 0; k < N; k++) {
         NomPtrs qn;
         qn.x = q.x + xs;
         qn.u = q.u + us;
-        qn.l = q.l + us;
+        qn.l = q.l + ks;
         qn.K = q.K + ks;
         NomStep nxt;
-        if(k + 1 < N) load_nominal<gains>(nxt, qn);  // in flight while this step computes
+        if(k + 1 < N) load_nominal<gains, CS>(nxt, qn);  // in flight while this step computes
 
         // inputs of the step
         double xin[NX], uin[NU];
@@ -1057,9 +1137,15 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
         // iteration (vmcnt = number of younger operations) leaves these stores in flight.
         if(store) {
 #pragma unroll
-            for(int i = 0; i < NX; i++) xo[i * SI] = ct.x[i];
+            for(int i = 0; i < NX; i++) xo[i * XSI] = ct.x[i];
 #pragma unroll
-            for(int i = 0; i < NU; i++) uo[i * SI] = ct.u[i];
+            for(int i = 0; i < NU; i++) uo[i * XSI] = ct.u[i];
+            if(KIND == RK_INIT && !WAVE_MAP) {
+#pragma unroll
+                for(int i = 0; i < NX; i++) ro[NOM_X + i] = ct.x[i];
+#pragma unroll
+                for(int i = 0; i < NU; i++) ro[NOM_U + i] = ct.u[i];
+            }
         }
         if(!cost_only) {
 #pragma unroll
@@ -1067,8 +1153,9 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
         }
         cur = nxt;
         q = qn;
-        xo += xs;
-        uo += us;
+        xo += xos;
+        uo += uos;
+        ro += RN;
     }
     // final cost (iLQG_func.tem:179-182); q.x now points at step N
     {
@@ -1076,7 +1163,7 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
         init_final(&cf, &C.o);
         double xin[NX];
 #pragma unroll
-        for(int i = 0; i < NX; i++) xin[i] = cost_only ? q.x[i * SI] : xc[i];
+        for(int i = 0; i < NX; i++) xin[i] = cost_only ? q.x[i * CS] : xc[i];
         const double nf0 = H.nonfinite;
         H.huge = 0.0;
         auto fin = [&]() {
@@ -1097,7 +1184,11 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
         csum += cf.c;
         if(store) {
 #pragma unroll
-            for(int i = 0; i < NX; i++) xo[i * SI] = cf.x[i];  // xo points at step N now
+            for(int i = 0; i < NX; i++) xo[i * XSI] = cf.x[i];  // xo points at step N now
+            if(KIND == RK_INIT && !WAVE_MAP) {
+#pragma unroll
+                for(int i = 0; i < NX; i++) ro[NOM_X + i] = cf.x[i];
+            }
         }
     }
     // forward_pass returns 0 as soon as a guarded value is NaN or Inf (genenerator_main.mac:193-198)
@@ -1344,6 +1435,18 @@ FieldInfo field_info(int f) {
     }
 }
 
+// columns of the packed trajectory records (nomp): first column, or -1 for any other field
+int nom_column(int field) {
+    switch(field) {
+        case ILQG_F_X: return NOM_X;
+        case ILQG_F_U: return NOM_U;
+        case ILQG_F_LG: return NOM_L;
+        case ILQG_F_KG: return NOM_K;
+        default: return -1;
+    }
+}
+// lane mapping: X and U also exist as tiled arrays, the representation the host reads (see cur_x)
+bool has_tiled_copy(int field) { return !WAVE_MAP && (field == ILQG_F_X || field == ILQG_F_U); }
 int field_steps(const ilqg_dev *d, int f) {
     const FieldInfo fi = field_info(f);
     return fi.steps_plus < 0 ? 1 : d->N + fi.steps_plus;
@@ -1479,10 +1582,19 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
             d->P.f[f] = nullptr;
             continue;
         }
+        if(nom_column(f) >= 0 && !has_tiled_copy(f)) {  // columns of the packed trajectory records only
+            d->P.f[f] = nullptr;
+            continue;
+        }
         const FieldInfo fi = field_info(f);
         const size_t bytes = (size_t)field_steps(d, f) * fi.wd * d->Bp * sizeof(double);
         HIP_TRY(hipMalloc((void **)&d->P.f[f], bytes));
         HIP_TRY(hipMemsetAsync(d->P.f[f], 0, bytes, d->stream));
+    }
+    {
+        const size_t bytes = (size_t)d->Bp * (d->N + 1) * RN * sizeof(double);
+        HIP_TRY(hipMalloc((void **)&d->P.nom, bytes));
+        HIP_TRY(hipMemsetAsync(d->P.nom, 0, bytes, d->stream));
     }
     for(int f = 0; f < ILQG_I_COUNT; f++) {
         const size_t bytes = (size_t)int_field_width(f) * d->Bp * sizeof(int);
@@ -1513,6 +1625,7 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     for(int f = 0; f < ILQG_F_COUNT; f++)
         if(d->P.f[f]) hipFree(d->P.f[f]);
     if(d->P.work) hipFree(d->P.work);
+    if(d->P.nom) hipFree(d->P.nom);
     for(int f = 0; f < ILQG_I_COUNT; f++) hipFree(d->P.i[f]);
     hipFree(d->P.derivs_failed);
     hipFree(d->counter);
@@ -1591,10 +1704,23 @@ int ilqg_dev_write(ilqg_dev_t *d, int field, const double *host) {
     return ilqg_dev_write_steps(d, field, host, field_steps(d, field));
 }
 
-// wave mapping: these fields are trajectory-major on the device, i.e. already in host layout
-static bool is_traj_major(int field) {
-    return WAVE_MAP && (field == ILQG_F_X || field == ILQG_F_U || field == ILQG_F_LG || field == ILQG_F_KG ||
-                        field == ILQG_F_FIN);
+// trajectory-major on the device, i.e. already in host layout: copied without a kernel
+static bool is_traj_major(int field) { return WAVE_MAP && field == ILQG_F_FIN; }
+
+static int nom_io(ilqg_dev *d, int field, double *host_rw, const double *host_ro, int steps) {
+    const FieldInfo fi = field_info(field);
+    const size_t n = (size_t)d->B * steps * fi.wh;
+    if(ensure_staging(d, n * sizeof(double))) return 1;
+    if(host_ro) HIP_TRY(hipMemcpyAsync(d->staging, host_ro, n * sizeof(double), hipMemcpyHostToDevice, d->stream));
+    {
+        Timed t(d, ILQG_K_TRANSPOSE);
+        hipLaunchKernelGGL(k_nom_io, grid1(n, 256), dim3(256), 0, d->stream, d->P.nom, d->staging, d->B, d->N, steps,
+                           fi.wh, nom_column(field), host_ro ? 1 : 0);
+    }
+    HIP_TRY(hipGetLastError());
+    if(host_rw) HIP_TRY(hipMemcpyAsync(host_rw, d->staging, n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return 0;
 }
 
 #if ILQG_WAVE_MAP
@@ -1650,6 +1776,10 @@ int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps
         return der_io(d, nullptr, host);
     }
 #endif
+    if(nom_column(field) >= 0) {
+        if(nom_io(d, field, nullptr, host, steps)) return 1;
+        if(!has_tiled_copy(field)) return 0;  // else: the tiled copy below as well
+    }
     if(is_traj_major(field)) {
         const size_t row = (size_t)steps * fi.wd * sizeof(double);
         const size_t dpitch = (size_t)field_steps(d, field) * fi.wd * sizeof(double);
@@ -1682,6 +1812,7 @@ int ilqg_dev_read(ilqg_dev_t *d, int field, double *host) {
         return der_io(d, host, nullptr);
     }
 #endif
+    if(nom_column(field) >= 0 && !has_tiled_copy(field)) return nom_io(d, field, host, nullptr, steps);
     if(is_traj_major(field)) {
         HIP_TRY(hipMemcpyAsync(host, d->P.f[field], n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
         HIP_TRY(hipStreamSynchronize(d->stream));
