@@ -499,13 +499,7 @@ __global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O, Pa
         for(int i = 0; i < NX; i++) t.x[i] = xs[i * XSI];
 #pragma unroll
         for(int i = 0; i < NU; i++) t.u[i] = us[i * XSI];
-        {  // keep the line search's records current (see cur_x)
-            double *rec = nomp(P, k, b);
-#pragma unroll
-            for(int i = 0; i < NX; i++) rec[NOM_X + i] = t.x[i];
-#pragma unroll
-            for(int i = 0; i < NU; i++) rec[NOM_U + i] = t.u[i];
-        }
+
         ok = derivs_step(t, C, H, k, P.N, [] {});
         double *out = P.f[ILQG_F_DER] + ix(P, REC, P.N, k, 0, b);
 #define PUT(off, arr, cnt) _Pragma("unroll") for(int i = 0; i < (cnt); i++) out[((off) + i) * SI] = (arr)[i];
@@ -516,11 +510,7 @@ __global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O, Pa
         const double *xs = cur_x(P, P.N, b);
 #pragma unroll
         for(int i = 0; i < NX; i++) fin.x[i] = xs[i * XSI];
-        {
-            double *rec = nomp(P, P.N, b);
-#pragma unroll
-            for(int i = 0; i < NX; i++) rec[NOM_X + i] = fin.x[i];
-        }
+
         ok = derivs_final(fin, C, H, P.N);
         double *out = P.f[ILQG_F_FIN] + ix(P, FIN, 1, 0, 0, b);
         PUT(0, fin.cx, NX)
@@ -545,11 +535,12 @@ __device__ __forceinline__ void load_record(double *dst, double *udst, const dou
 // of younger operations) leaves the stores in flight.  They are stored for every lane, also for one whose box QP
 // has just failed (back_pass.c:168-171 returns before writing L): that lane leaves the sweep right after, and a
 // retry rewrites all gains.
+template <int CS = 1>
 __device__ __forceinline__ void store_gains(const double *l, const double *K, double *lo, double *ko) {
 #pragma unroll
-    for(int i = 0; i < NU; i++) lo[i] = l[i];
+    for(int i = 0; i < NU; i++) lo[i * CS] = l[i];
 #pragma unroll
-    for(int i = 0; i < NXU; i++) ko[i] = K[i];
+    for(int i = 0; i < NXU; i++) ko[i * CS] = K[i];
 }
 
 #ifdef ILQG_PROFILE_SECTIONS
@@ -574,11 +565,13 @@ __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double la
 
     // pointers to step k of this lane's trajectory, walked backwards
     const double *rp = P.f[ILQG_F_DER] + ix(P, REC, N, N - 1, 0, b);
+    // This sweep streams the stored records; its gains go to the tiled arrays l / L (512 contiguous bytes per
+    // component and wavefront) and k_pack_records turns them into the line search's records afterwards.
     const double *up = cur_u(P, N - 1, b);
-    double *lo = nomp(P, N - 1, b) + NOM_L;
-    double *ko = nomp(P, N - 1, b) + NOM_K;
+    double *lo = WAVE_MAP ? nomp(P, N - 1, b) + NOM_L : P.f[ILQG_F_LG] + ix(P, NU, N, N - 1, 0, b);
+    double *ko = WAVE_MAP ? nomp(P, N - 1, b) + NOM_K : P.f[ILQG_F_KG] + ix(P, NXU, N, N - 1, 0, b);
     const size_t rs = step_stride(P, REC), us = cur_ustride(P);
-    constexpr int ks = RN;
+    const size_t ls = WAVE_MAP ? (size_t)RN : step_stride(P, NU), ks = WAVE_MAP ? (size_t)RN : step_stride(P, NXU);
 
     double cur[REC], ucur[NU];
     load_record(cur, ucur, rp, up);
@@ -589,14 +582,14 @@ __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double la
         if(k > 0) load_record(nxt, unxt, rp - rs, up - us);  // in flight while this step computes
         // l still holds the solution of step k+1: the warm start (back_pass.c:165-166)
         const int rc = back_step<NX, NU, FULL, HX>(cur, ucur, Vx, Vxx, l, K, lambda, regType, dV0, dV1, gsum);
-        store_gains(l, K, lo, ko);
+        store_gains<XSI>(l, K, lo, ko);
         if(rc < 1) {
             failed = 1;
             break;
         }
         rp -= rs;
         up -= us;
-        lo -= ks;
+        lo -= ls;
         ko -= ks;
 #pragma unroll
         for(int i = 0; i < REC; i++) cur[i] = nxt[i];
@@ -804,6 +797,28 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
     P.f[ILQG_F_GNORM][b] = g_norm;
     P.i[ILQG_I_BP_CALLS][b] = calls;
     P.i[ILQG_I_BP_RC][b] = rc;
+}
+
+// After a backward pass over stored records (modes 0 and 1): the line search's packed records from the tiled
+// X, U, l, L.  One lane per (trajectory, time step); step N holds x_N only.
+__global__ __launch_bounds__(256) void k_pack_records(DevPtrs P) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(tid % P.Bp);
+    const int k = (int)(tid / P.Bp);
+    if(k > P.N || b >= P.B) return;
+    double *rec = nomp(P, k, b);
+    const double *xs = cur_x(P, k, b);
+#pragma unroll
+    for(int i = 0; i < NX; i++) rec[NOM_X + i] = xs[i * XSI];
+    if(k == P.N) return;
+    const double *us = cur_u(P, k, b);
+    const double *ls = P.f[ILQG_F_LG] + ix(P, NU, P.N, k, 0, b), *ks = P.f[ILQG_F_KG] + ix(P, NXU, P.N, k, 0, b);
+#pragma unroll
+    for(int i = 0; i < NU; i++) rec[NOM_U + i] = us[i * XSI];
+#pragma unroll
+    for(int i = 0; i < NU; i++) rec[NOM_L + i] = ls[i * SI];
+#pragma unroll
+    for(int i = 0; i < NXU; i++) rec[NOM_K + i] = ks[i * SI];
 }
 
 #else  // ILQG_WAVE_MAP
@@ -1447,6 +1462,9 @@ int nom_column(int field) {
 }
 // lane mapping: X and U also exist as tiled arrays, the representation the host reads (see cur_x)
 bool has_tiled_copy(int field) { return !WAVE_MAP && (field == ILQG_F_X || field == ILQG_F_U); }
+// lane mapping: tiled l / L are the output of the backward pass over stored records only (see k_pack_records);
+// the host reads and writes gains in the records
+bool has_tiled_scratch(int field) { return !WAVE_MAP && (field == ILQG_F_LG || field == ILQG_F_KG); }
 int field_steps(const ilqg_dev *d, int f) {
     const FieldInfo fi = field_info(f);
     return fi.steps_plus < 0 ? 1 : d->N + fi.steps_plus;
@@ -1528,7 +1546,7 @@ void ilqg_dev_dims(int *out) {
 const char *ilqg_dev_kernel_name(int k) {
     static const char *names[ILQG_K_COUNT] = {"k_derivs", "k_backward", "k_rollout[search]", "k_select",
                                               "k_rollout[winner]", "k_update", "k_rollout[cost]", "k_rollout[init]",
-                                              "k_to_dev/k_from_dev", "k_backward[fused derivs]", "k_rollout[search stage 2]"};
+                                              "layout kernels", "k_backward[fused derivs]", "k_rollout[search stage 2]"};
     return (k >= 0 && k < ILQG_K_COUNT) ? names[k] : "?";
 }
 
@@ -1582,7 +1600,7 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
             d->P.f[f] = nullptr;
             continue;
         }
-        if(nom_column(f) >= 0 && !has_tiled_copy(f)) {  // columns of the packed trajectory records only
+        if(nom_column(f) >= 0 && !has_tiled_copy(f) && !has_tiled_scratch(f)) {  // columns of the packed records only
             d->P.f[f] = nullptr;
             continue;
         }
@@ -1954,6 +1972,11 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
             hipLaunchKernelGGL(k_backward<1>, grid, block, 0, d->stream, d->P, d->O, d->pv);
         else
             hipLaunchKernelGGL(k_backward<2>, grid, block, 0, d->stream, d->P, d->O, d->pv);
+    }
+    if(mode != 2) {
+        Timed t(d, ILQG_K_TRANSPOSE);
+        const size_t total = (size_t)d->Bp * (d->N + 1);
+        hipLaunchKernelGGL(k_pack_records, grid1(total, 256), dim3(256), 0, d->stream, d->P);
     }
     HIP_TRY(hipGetLastError());
     return 0;
