@@ -50,7 +50,7 @@ ALG_BYTES = {
 # derivatives evaluated inside the backward kernel: priced against the UNFUSED figure of the two
 # kernels it replaces; what it actually moves is 6 dbl read + 10 written = 128 B
 ALG_BYTES["k_backward[fused derivs]"] = ALG_BYTES["k_derivs"] + ALG_BYTES["k_backward"]
-FUSED_MOVED_BYTES = (NX + NU + NU + NXU) * 8
+FUSED_MOVED_BYTES = (NX + NU) * 8 + (NX + 2 * NU + NXU) * 8
 ITERATION_BYTES = 1200  # per step and trajectory, SURVEY.md §8(d)
 
 
@@ -143,7 +143,7 @@ def main():
         "k_rollout[winner]": (NX + NU) * 8,
     }
     ALG_BYTES["k_backward[fused derivs]"] = ALG_BYTES["k_derivs"] + ALG_BYTES["k_backward"]
-    FUSED_MOVED_BYTES = (NX + NU + NU + NXU) * 8
+    FUSED_MOVED_BYTES = (NX + NU) * 8 + (NX + 2 * NU + NXU) * 8  # reads (x_k,u_k), writes the packed record of step k
     ITERATION_BYTES = sum(ALG_BYTES[k] for k in ("k_derivs", "k_backward", "k_rollout[search]", "k_rollout[winner]"))
     first = pkg.dist.shard_first(rank, B)
     x0, u0 = synth.car_batch(B, N_HOR, first=first) if car else synth.synth16_batch(B, N_HOR, first=first)
@@ -249,13 +249,13 @@ def main():
                          "note": "achieved = ALGORITHMIC bytes of SURVEY 8(d) per launch / average HIP-event "
                                  "time of a launch. For k_backward[fused derivs] that is the figure of the two "
                                  "kernels it replaces (k_derivs 488 B + k_backward 536 B per step and trajectory), "
-                                 "as SURVEY 8(d) prescribes; the fused kernel itself moves 128 B per step and "
-                                 "trajectory (= traffic) and is bound by fp64 VALU issue, not by HBM. The batch "
+                                 "as SURVEY 8(d) prescribes; the fused kernel itself moves 176 B per step and "
+                                 "trajectory (48 B read, the 128 B record of the step written = traffic) and is bound by fp64 VALU issue, not by HBM. The batch "
                                  "advances as stream_groups sets of trajectories on separate streams: a launch "
                                  "covers one set and shares the GPU with the kernels of the others while it is "
                                  "timed. See unfused_kernels for the HBM-bound kernels measured alone, and "
                                  "iteration_roofline for the whole iteration.",
-                         "moved_bytes_per_launch": (FUSED_MOVED_BYTES * N_HOR * B) if "fused" in dominant else alg_bytes},
+                         "moved_bytes_per_launch": (FUSED_MOVED_BYTES * N_HOR * B * K / n_launch) if "fused" in dominant else alg_bytes},
             "unfused_kernels": unfused,
             "iteration_roofline": {"algorithmic_bytes_per_iteration": iter_bytes,
                                    "achieved_GBs": iter_bytes * (K / dt) / 1e9 / world * 1.0,

@@ -347,6 +347,115 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
     return rc ? rc : 1;  // 1: max_iter iterations (boxQP.c:237)
 }
 
+// The same algorithm in the reference's own control flow (early returns, one trial per trip of the Armijo loop):
+// for callers whose lanes all solve the SAME problem (wave mapping: the box QP of a step is evaluated redundantly
+// by every lane), where nothing diverges and the predicated form above would only add work.
+template <int M>
+ILQG_DEV int box_qp_uniform(const double *H, const double *g, const double *lower, const double *upper, double *x,
+                    int *clamp, int &n_free_out, double *invH) {
+    constexpr int T = tri(M);
+    const int max_iter = 100;
+    const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+    double grad[M], search[M], xc[M];
+    double value, oldvalue = 0.0;
+
+#pragma unroll
+    for(int i = 0; i < M; i++) {
+        if(x[i] > upper[i]) x[i] = upper[i];
+        if(x[i] < lower[i]) x[i] = lower[i];
+        clamp[i] = 0;
+    }
+#pragma unroll
+    for(int i = 0; i < T; i++) invH[i] = 0.0;
+    n_free_out = 0;
+    value = qp_value<M>(H, g, x);
+
+    for(int iter = 0; iter < max_iter; iter++) {
+        if(iter > 0 && (oldvalue - value) < min_rel_improve * fabs(oldvalue)) return 4;
+        oldvalue = value;
+
+        bool all_clamped = true, changed = false;
+        int n_free = 0;
+        double gnorm = 0.0;
+#pragma unroll
+        for(int i = 0; i < M; i++) {
+            double hx = 0.0;
+#pragma unroll
+            for(int j = 0; j < M; j++) hx += H[sy(i, j)] * x[j];
+            grad[i] = g[i] + hx;
+            const int was = clamp[i];
+            if(x[i] <= lower[i] && grad[i] > 0)
+                clamp[i] = 1;
+            else if(x[i] >= upper[i] && grad[i] < 0)
+                clamp[i] = 2;
+            else {
+                clamp[i] = 0;
+                all_clamped = false;
+                gnorm += grad[i] * grad[i];
+                n_free++;
+            }
+            if((!was) != (!clamp[i])) changed = true;
+        }
+        n_free_out = n_free;
+        if(all_clamped) return 6;
+
+        if(iter == 0 || changed) {
+            double Hm[T], U[T];
+#pragma unroll
+            for(int j = 0; j < M; j++)
+#pragma unroll
+                for(int i = 0; i <= j; i++)
+                    Hm[ut(i, j)] = (clamp[i] || clamp[j]) ? ((i == j) ? 1.0 : 0.0) : H[ut(i, j)];
+            if(!chol_factor<M>(Hm, U)) return -1;
+            chol_inverse<M>(U, invH);
+        }
+
+        if(gnorm < min_grad * min_grad) return 5;
+
+        // search(free) = -invH(free,free) * (g + H x_clamped)(free) - x(free); search(clamped) = 0
+        double gc[M];
+#pragma unroll
+        for(int i = 0; i < M; i++) {
+            double hc = 0.0;
+#pragma unroll
+            for(int j = 0; j < M; j++)
+                if(clamp[j]) hc += H[sy(i, j)] * x[j];
+            gc[i] = g[i] + hc;
+        }
+#pragma unroll
+        for(int i = 0; i < M; i++) {
+            double s = -x[i];
+#pragma unroll
+            for(int j = 0; j < M; j++)
+                if(!clamp[j]) s -= invH[sy(i, j)] * gc[j];
+            search[i] = clamp[i] ? 0.0 : s;
+        }
+
+        double sdotg = 0.0;
+#pragma unroll
+        for(int i = 0; i < M; i++) sdotg += search[i] * grad[i];
+        if(sdotg >= 0.0) return -2;
+
+        double step = 1.0, vc;
+        for(;;) {
+#pragma unroll
+            for(int i = 0; i < M; i++) {
+                xc[i] = x[i] + step * search[i];
+                if(xc[i] > upper[i]) xc[i] = upper[i];
+                if(xc[i] < lower[i]) xc[i] = lower[i];
+            }
+            vc = qp_value<M>(H, g, xc);
+            if(((vc - oldvalue) / (step * sdotg)) >= armijo) break;
+            step = step * step_dec;
+            if(step < min_step) return 2;
+        }
+#pragma unroll
+        for(int i = 0; i < M; i++) x[i] = xc[i];
+        value = vc;
+    }
+    return 1;
+}
+
 // ---------------------------------------------------------------------------
 // one time step of back_pass.c
 // ---------------------------------------------------------------------------

@@ -71,10 +71,15 @@ __device__ __forceinline__ int ilqg_note_nonfinite(double **p, double v) {
     *f = v * 0.0 + *f;
     return 0;
 }
+// Large generated files (-DILQG_SINCOS_CALL: thousands of guarded assignments in functions too big to inline, e.g.
+// the tensors of an n = 16 problem) keep the plain guards: there the parameter table and the hooks stay in scratch
+// memory, and a recorded guard would cost memory operations instead of a compare and a branch (measured 4x slower).
+#ifndef ILQG_SINCOS_CALL
 #undef mxIsNaN
 #undef mxIsInf
 #define mxIsNaN(v) ilqg_note_nonfinite(p, (v))
 #define mxIsInf(v) 0
+#endif
 
 // The generated callbacks call sin(x) and cos(x) of the same few arguments many times, spread
 // over several functions (calcXUVariableAux, ddpf, bp_derivsL, ...).  The device math

@@ -11,7 +11,7 @@
 // x, u, l, L are trajectory-major [trajectory][step][field].
 //
 // The box QP of a step (boxQP.c:39-238, size NU) is evaluated redundantly by all lanes in
-// registers with the same template the lane mapping uses (box_qp<NU>); its results go through
+// registers with the same template the lane mapping uses (box_qp_uniform<NU>); its results go through
 // LDS because the gain formula indexes them per lane.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -181,7 +181,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             up[i] = F.upper[i];
             x[i] = S.l[i];  // warm start: the later step's solution (back_pass.c:163-166)
         }
-        rc = box_qp<NU>(H, g, lo, up, x, cl, nf, inv);
+        rc = box_qp_uniform<NU>(H, g, lo, up, x, cl, nf, inv);
         __syncthreads();
         if(lane == 0) {
             #pragma unroll
