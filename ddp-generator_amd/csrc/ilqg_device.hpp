@@ -186,6 +186,17 @@ ILQG_DEV bool armijo_passes(double vc, double oldvalue, double step, double sdot
     return (n / d) >= armijo;
 }
 
+// The same test in two parts, for callers that evaluate several trials before branching: the quick verdict
+// (+1 passes, -1 fails, 0 too close to call) without any control flow, and the reference's expression for the rest.
+ILQG_DEV int armijo_quick(double vc, double oldvalue, double step, double sdotg, double armijo) {
+    const double n = vc - oldvalue, d = step * sdotg;
+    const double t = armijo * d, m = fabs(t) * 1e-15;
+    return (n < t - m) ? 1 : ((n > t + m) ? -1 : 0);
+}
+ILQG_DEV bool armijo_exact(double vc, double oldvalue, double step, double sdotg, double armijo) {
+    return ((vc - oldvalue) / (step * sdotg)) >= armijo;
+}
+
 // Projected-Newton box QP.  Same iteration, constants and return codes as
 // boxQP.c:39-238.  One representational difference: the reference compacts
 // the free rows/columns into a smaller matrix (which needs runtime indices);
@@ -324,8 +335,15 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
             }
             const double vc1 = qp_value<M>(H, g, xc1);
             const double vc2 = qp_value<M>(H, g, xc2);
-            const bool pass1 = armijo_passes(vc1, oldvalue, step, sdotg, armijo);
-            const bool pass2 = armijo_passes(vc2, oldvalue, step2, sdotg, armijo);
+            // both quick verdicts first, ONE (rarely taken) branch for the exact expression: the two trials stay in
+            // one basic block and overlap
+            const int q1 = armijo_quick(vc1, oldvalue, step, sdotg, armijo);
+            const int q2 = armijo_quick(vc2, oldvalue, step2, sdotg, armijo);
+            bool pass1 = q1 > 0, pass2 = q2 > 0;
+            if(q1 == 0 || q2 == 0) {
+                if(q1 == 0) pass1 = armijo_exact(vc1, oldvalue, step, sdotg, armijo);
+                if(q2 == 0) pass2 = armijo_exact(vc2, oldvalue, step2, sdotg, armijo);
+            }
             const double step3 = step2 * step_dec;
             // what the reference's loop does with these two trials, in its order
             const bool out_of_steps = !pass1 && ((step2 < min_step) || (!pass2 && step3 < min_step));
