@@ -183,6 +183,7 @@ def main():
 
     times = s.kernel_times()
     active = s.active()
+    stream_groups = s.groups()
     cost = gathered.cpu().numpy() if world > 1 and rank == 0 else s.scalar("cost")
 
     # secondary, untimed for `value`: the same iterations with the derivative records materialised in
@@ -241,7 +242,7 @@ def main():
                        "mapping": ("one wavefront per trajectory" if s.problem.wave_mapping else
                                    "one lane per trajectory (64 trajectories per wavefront)"),
                        "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split, "resweep": args.resweep,
-                       "stream_groups": s.groups(),
+                       "stream_groups": stream_groups,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

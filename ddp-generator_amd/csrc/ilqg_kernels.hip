@@ -807,6 +807,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
 // After a backward pass over stored records (modes 0 and 1): the line search's packed records from the tiled
 // X, U, l, L.  One lane per (trajectory, time step); step N holds x_N only.
 __global__ __launch_bounds__(256) void k_pack_records(DevPtrs P) {
+    // (lanes = consecutive trajectories: coalesced reads, scattered record writes; the transposed assignment —
+    // contiguous writes, gathered reads — was measured slower: 14 vs 9 ms for 65 536 x 501 records)
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = (int)(tid % P.Bp);
     const int k = (int)(tid / P.Bp);
