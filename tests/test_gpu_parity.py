@@ -652,6 +652,58 @@ def test_properties_at_benchmark_size(ilqg, synth):
     s.close(); small.close()
 
 
+def test_results_do_not_depend_on_stream_groups(ilqg, synth):
+    """the batch advances as 1..4 groups of trajectories on separate HIP streams (ilqg_batch_create_groups):
+    bit-identical results, ragged group sizes included"""
+    B, iters = 1000, 6
+    x0, u0 = synth.car_batch(B, first=123)
+    ref = None
+    for groups in (1, 2, 3, 4):
+        s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=iters),
+                             groups=groups)
+        assert s.groups() == groups
+        s.init(x0, u0)
+        s.iterate(iters)
+        out = (s.scalar("cost"), s.scalar("lambda"), s.x(), s.u(), s.ints("alpha_idx"), s.ints("status"))
+        l, L = s.gains()
+        if ref is None:
+            ref = out + (l, L)
+        else:
+            for a, r in zip(out + (l, L), ref):
+                assert np.array_equal(a, r)
+        s.close()
+
+
+def test_huge_angle_goes_through_the_library_sincos(ilqg, synth, oracle_built):
+    """sin/cos of the generated callbacks are straight-line code for |x| < 8e5; beyond that the step is evaluated
+    a second time through the device library (the `huge` hook).  A heading angle of 1e7 rad in ONE trajectory of
+    a wavefront: that trajectory matches the CPU (exact range reduction), its neighbours are untouched."""
+    B, iters = 64, 3
+    x0, u0 = synth.car_batch(B, first=500)
+    x0 = x0.copy()
+    x0[5, 2] = 1.0e7 + 0.25
+    s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=iters))
+    s.init(x0, u0)
+    c0 = s.scalar("cost")
+    s.iterate(iters)
+    cost, x = s.scalar("cost"), s.x()
+    for b in (4, 5, 6):
+        d = Driver(lib_path("oracle", full_ddp=0), 500, CAR_PARAMS, dict(max_iter=iters))
+        assert d.init(x0[b], u0[b]) == 1
+        if b == 5:
+            assert close(c0[b], d.scalars()["cost"], 1e-9)   # initial roll-out
+        d.solve()
+        assert close(cost[b], d.scalars()["cost"], 1e-8), (b, cost[b], d.scalars()["cost"])
+        assert np.abs(x[b] - d.traj(0)[0]).max() < 1e-6 * max(1.0, np.abs(x[b]).max())
+        d.close()
+    # and the unfused derivative kernel takes the same path
+    s2 = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=iters, fuse_derivs=0))
+    s2.init(x0, u0)
+    s2.iterate(iters)
+    assert np.allclose(s2.scalar("cost"), cost, rtol=1e-9, atol=0)
+    s.close(); s2.close()
+
+
 # ---------------------------------------------------------------------------
 # edge cases: failures, exits, degenerate sizes
 # ---------------------------------------------------------------------------
