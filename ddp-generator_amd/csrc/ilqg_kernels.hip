@@ -8,9 +8,9 @@
 // iLQG_func.tem:40-347).  A Maxima-generated problem file drops in the same way.
 //
 // Mapping ("lane mapping"): one lane = one trajectory, 64 trajectories per
-// wavefront.  Device arrays are [time step][field][trajectory] so that a
-// wavefront reads/writes 512 contiguous bytes per field.  All small matrices
-// of a trajectory live in that lane's VGPRs (ilqg_device.hpp).
+// wavefront; all small matrices of a trajectory live in that lane's VGPRs
+// (ilqg_device.hpp).  Data layout: the line search reads packed per-step
+// records (nomp), the roll-outs store tiled arrays (cur_x); DESIGN.md §2.
 //
 // Kernels                             replaces (reference)
 //   k_derivs     lane = (traj, step)   calc_derivs            iLQG_func.tem:187-221

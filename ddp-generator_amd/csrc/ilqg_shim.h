@@ -4,9 +4,9 @@
  * Host-side data crosses this boundary in trajectory-major layout
  * [trajectory][time step][field], i.e. what a caller holding `trajEl_t`
  * arrays can produce with a memcpy per field (reference iLQG_mex.c:113-137
- * walks its trajectories the same way).  On the device the batch is stored
- * batch-innermost, [time step][field][trajectory], so that one wavefront of 64
- * trajectories reads 512 contiguous bytes per field.
+ * walks its trajectories the same way).  The device layouts (packed per-step
+ * trajectory records, tiled arrays) are private to ilqg_kernels.hip, see
+ * DESIGN.md section 2.
  */
 #ifndef ILQG_SHIM_H
 #define ILQG_SHIM_H
