@@ -652,6 +652,37 @@ def test_properties_at_benchmark_size(ilqg, synth):
     s.close(); small.close()
 
 
+def test_properties_at_full_benchmark_batch(ilqg, synth, oracle_built):
+    """B = 65 536 (BASELINE config 3, the batch the metric is quoted on; three stream groups by default): accepted
+    steps reduce the cost, every trajectory is still active inside the window, trajectories picked from different
+    groups and tiles equal the same trajectories solved alone, and one of them equals the CPU oracle."""
+    B, iters = 65536, 3
+    x0, u0 = synth.car_batch(B)
+    s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=50))
+    assert s.groups() == 3
+    s.init(x0, u0)
+    prev = s.scalar("cost")
+    for _ in range(iters):
+        s.iterate(1)
+        c = s.scalar("cost")
+        acc = s.ints("accepted").astype(bool)
+        assert np.all(c[acc] < prev[acc]) and np.array_equal(c[~acc], prev[~acc])
+        prev = c
+    assert s.active() == B and np.all(s.ints("iterations") == iters)
+    pick = [0, 63, 64, 21887, 21888, 40000, 43775, 43776, 65535]   # group and tile boundaries (groups of 21 888)
+    x_big, u_big = s.x()[pick], s.u()[pick]
+    small = ilqg.BatchSolver("carparking", 0, batch=len(pick), n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=50))
+    small.init(x0[pick], u0[pick])
+    small.iterate(iters)
+    assert np.array_equal(small.scalar("cost"), prev[pick])
+    assert np.array_equal(small.x(), x_big) and np.array_equal(small.u(), u_big)
+    d = Driver(lib_path("oracle", full_ddp=0), 500, CAR_PARAMS, dict(max_iter=iters))
+    assert d.init(x0[40000], u0[40000]) == 1
+    d.solve()
+    assert close(prev[40000], d.scalars()["cost"], 1e-9)
+    d.close(); s.close(); small.close()
+
+
 def test_results_do_not_depend_on_stream_groups(ilqg, synth):
     """the batch advances as 1..4 groups of trajectories on separate HIP streams (ilqg_batch_create_groups):
     bit-identical results, ragged group sizes included"""
