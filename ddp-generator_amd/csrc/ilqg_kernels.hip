@@ -1091,9 +1091,6 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
         qn.u = q.u + us;
         qn.l = q.l + ks;
         qn.K = q.K + ks;
-        NomStep nxt;
-        if(k + 1 < N) load_nominal<gains, CS>(nxt, qn);  // in flight while this step computes
-
         // inputs of the step
         double xin[NX], uin[NU];
         if(cost_only) {
@@ -1128,6 +1125,12 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
                 for(int j = 0; j < NU; j++) uin[j] = cur.u[j];
             }
         }
+
+        // The nominal data of this step have been consumed: the next step's are loaded into the same variables
+        // right here and are in flight while the step computes (no second buffer, no hand-over copies).
+        // (unconditionally: the records have a step N; the tiled U has not, its pointer stays on the last step)
+        if(KIND != RK_GENERAL && k + 1 >= N) qn.u = q.u;
+        load_nominal<gains, CS>(cur, qn);
 
         // the step (iLQG_func.tem:160-176)
         double xnext[NX];
@@ -1173,7 +1176,6 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
 #pragma unroll
             for(int i = 0; i < NX; i++) xc[i] = xnext[i];
         }
-        cur = nxt;
         q = qn;
         xo += xos;
         uo += uos;
