@@ -188,6 +188,9 @@ ILQG_DEV bool armijo_passes(double vc, double oldvalue, double step, double sdot
 
 // The same test in two parts, for callers that evaluate several trials before branching: the quick verdict
 // (+1 passes, -1 fails, 0 too close to call) without any control flow, and the reference's expression for the rest.
+#ifndef ARMIJO_TRIALS
+#define ARMIJO_TRIALS 2
+#endif
 ILQG_DEV int armijo_quick(double vc, double oldvalue, double step, double sdotg, double armijo) {
     const double n = vc - oldvalue, d = step * sdotg;
     const double t = armijo * d, m = fabs(t) * 1e-15;
@@ -322,38 +325,47 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
         bool searching = (rc == 0);
         if(pf) pf->probe(2);
         while(searching) {
-            const double step2 = step * step_dec;
-            double xc1[M], xc2[M];
+            // ARMIJO_TRIALS consecutive step sizes per trip, evaluated as independent instruction streams
+            double st[ARMIJO_TRIALS + 1], xt[ARMIJO_TRIALS][M], vt[ARMIJO_TRIALS];
+            int qt[ARMIJO_TRIALS];
+            st[0] = step;
 #pragma unroll
-            for(int i = 0; i < M; i++) {
-                xc1[i] = x[i] + step * search[i];
-                if(xc1[i] > upper[i]) xc1[i] = upper[i];
-                if(xc1[i] < lower[i]) xc1[i] = lower[i];
-                xc2[i] = x[i] + step2 * search[i];
-                if(xc2[i] > upper[i]) xc2[i] = upper[i];
-                if(xc2[i] < lower[i]) xc2[i] = lower[i];
-            }
-            const double vc1 = qp_value<M>(H, g, xc1);
-            const double vc2 = qp_value<M>(H, g, xc2);
-            // both quick verdicts first, ONE (rarely taken) branch for the exact expression: the two trials stay in
-            // one basic block and overlap
-            const int q1 = armijo_quick(vc1, oldvalue, step, sdotg, armijo);
-            const int q2 = armijo_quick(vc2, oldvalue, step2, sdotg, armijo);
-            bool pass1 = q1 > 0, pass2 = q2 > 0;
-            if(q1 == 0 || q2 == 0) {
-                if(q1 == 0) pass1 = armijo_exact(vc1, oldvalue, step, sdotg, armijo);
-                if(q2 == 0) pass2 = armijo_exact(vc2, oldvalue, step2, sdotg, armijo);
-            }
-            const double step3 = step2 * step_dec;
-            // what the reference's loop does with these two trials, in its order
-            const bool out_of_steps = !pass1 && ((step2 < min_step) || (!pass2 && step3 < min_step));
-            const bool take1 = pass1, take2 = !pass1 && !(step2 < min_step) && pass2;
+            for(int j = 0; j < ARMIJO_TRIALS; j++) st[j + 1] = st[j] * step_dec;
+            bool unsure = false;
 #pragma unroll
-            for(int i = 0; i < M; i++) xc[i] = take1 ? xc1[i] : (take2 ? xc2[i] : xc[i]);
-            vc = take1 ? vc1 : (take2 ? vc2 : vc);
-            if(out_of_steps) rc = 2;
-            step = step3;
-            searching = !(take1 || take2 || out_of_steps);
+            for(int j = 0; j < ARMIJO_TRIALS; j++) {
+#pragma unroll
+                for(int i = 0; i < M; i++) {
+                    xt[j][i] = x[i] + st[j] * search[i];
+                    if(xt[j][i] > upper[i]) xt[j][i] = upper[i];
+                    if(xt[j][i] < lower[i]) xt[j][i] = lower[i];
+                }
+                vt[j] = qp_value<M>(H, g, xt[j]);
+                qt[j] = armijo_quick(vt[j], oldvalue, st[j], sdotg, armijo);
+                unsure = unsure || qt[j] == 0;
+            }
+            // all quick verdicts first, ONE (rarely taken) branch for the exact expression: the trials stay in one
+            // basic block and overlap
+            if(unsure) {
+#pragma unroll
+                for(int j = 0; j < ARMIJO_TRIALS; j++)
+                    if(qt[j] == 0) qt[j] = armijo_exact(vt[j], oldvalue, st[j], sdotg, armijo) ? 1 : -1;
+            }
+            // what the reference's loop does with these trials, in its order: trial j is reached if all before it
+            // failed and its step size is not below minStep (boxQP.c:222-224 returns 2 there)
+            bool open = true;  // still looking, within this trip
+#pragma unroll
+            for(int j = 0; j < ARMIJO_TRIALS; j++) {
+                const bool take = open && qt[j] > 0;
+#pragma unroll
+                for(int i = 0; i < M; i++) xc[i] = take ? xt[j][i] : xc[i];
+                vc = take ? vt[j] : vc;
+                const bool ran_out = open && !take && (st[j + 1] < min_step);
+                if(ran_out) rc = 2;
+                searching = searching && !(take || ran_out);
+                open = open && !(take || ran_out);
+            }
+            step = st[ARMIJO_TRIALS];
         }
         if(pf) pf->probe(4);
         const bool accepted = (rc == 0);
