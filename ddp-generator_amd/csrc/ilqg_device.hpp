@@ -22,6 +22,9 @@ namespace ilqg {
 
 // Optional cycle accounting of the sections of a backward step (builds with -DILQG_PROFILE_SECTIONS only;
 // tools/section_profile.py).  probe(i) charges the cycles since the previous probe to section i.
+#ifdef ILQG_PROFILE_SECTIONS
+__device__ unsigned long long ilqg_prof_cycles[8];  // summed over wavefronts: see tools/section_profile.py
+#endif
 struct Prof {
     long long last, acc[8];
     ILQG_DEV void start() {

@@ -548,10 +548,6 @@ __device__ __forceinline__ void store_gains(const double *l, const double *K, do
     for(int i = 0; i < NXU; i++) ko[i * CS] = K[i];
 }
 
-#ifdef ILQG_PROFILE_SECTIONS
-__device__ unsigned long long ilqg_prof_cycles[8];  // summed over wavefronts: see tools/section_profile.py
-#endif
-
 // one sweep k = N-1..0; returns 0 ok, 1 box-QP failed (back_pass.c:168-171)
 __device__ __forceinline__ int backward_sweep(const DevPtrs &P, int b, double lambda, int regType, double &dV0,
                                               double &dV1, double &g_norm) {
@@ -897,7 +893,15 @@ __device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const Dev
     dV0 = 0.0;
     dV1 = 0.0;
     double gsum = 0.0;
+#ifdef ILQG_PROFILE_SECTIONS
+    Prof prof;
+    prof.start();
+    Prof *pf = &prof;
+#else
+    Prof *pf = nullptr;
+#endif
     for(int k = N - 1; k >= 0; k--) {
+        if(pf) pf->probe(7);
         const trajEl_t *t = P.work + (size_t)bw * N + k;
         StepFields<NX, NU> F;
         F.cx = t->cx; F.cxx = t->cxx; F.cu = t->cu; F.cuu = t->cuu; F.cxu = t->cxu;
@@ -912,9 +916,13 @@ __device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const Dev
         F.u = nomp(P, k, b) + NOM_U;
         const int rc = back_step_wave<NX, NU, FULL, HX>(S, F, nomp(P, k, b) + NOM_L,
                                                         nomp(P, k, b) + NOM_K, lambda, regType, dV0,
-                                                        dV1, gsum);
+                                                        dV1, gsum, pf);
         if(rc < 1) return 1;
     }
+#ifdef ILQG_PROFILE_SECTIONS
+    if(lane == 0)
+        for(int i = 0; i < 8; i++) atomicAdd(&ilqg_prof_cycles[i], (unsigned long long)prof.acc[i]);
+#endif
     g_norm = gsum / ((double)(N - 1));
     return 0;
 }

@@ -58,7 +58,7 @@ struct StepFields {
 template <int NX, int NU, bool FULL, bool HX>
 __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFields<NX, NU> &F, double *lout,
                                               double *Kout, const double lambda, const int regType, double &dV0,
-                                              double &dV1, double &gsum) {
+                                              double &dV1, double &gsum, Prof *pf = nullptr) {
     constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
     constexpr int LDX = NX + 1, LDU = NU + 1;  // padded leading dimensions of the LDS copies
     const int lane = threadIdx.x & 63;
@@ -96,6 +96,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     }
     __syncthreads();
 
+    if(pf) pf->probe(0);
     // Qxu = cxu + fx' T2 (+ sum_i Vx_i fxu_i)        (back_pass.c:90-102)
     for(int j = lane; j < NXU; j += 64) {
         const int r = j % NX, q = j / NX;
@@ -140,6 +141,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     }
     __syncthreads();
 
+    if(pf) pf->probe(1);
     // regularisation (back_pass.c:134-159); regType 2 literally as in the reference
     for(int e = lane; e < SUU; e += 64) {
         int r, c;
@@ -167,6 +169,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     }
     __syncthreads();
 
+    if(pf) pf->probe(2);
     // box QP, redundantly on every lane (wave-uniform data)
     int rc;
     {
@@ -194,6 +197,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         }
         __syncthreads();
     }
+    if(pf) pf->probe(3);
     if(rc < 1) return rc;
 
     // feedback gains (back_pass.c:175-201); invH is in full-index form (see box_qp)
@@ -228,6 +232,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     for(int i = lane; i < NU; i += 64) lout[i] = S.l[i];
     __syncthreads();
 
+    if(pf) pf->probe(4);
     // expected cost change, redundantly on every lane (back_pass.c:205-214)
     #pragma unroll
     for(int i = 0; i < NU; i++) dV0 += S.Qu[i] * S.l[i];
@@ -256,6 +261,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     }
     __syncthreads();
 
+    if(pf) pf->probe(5);
     // Vx, Vxx with the unregularised Quu / Qxu (back_pass.c:219-241)
     for(int o = lane; o < NX + SXX; o += 64) {
         if(o < NX) {
@@ -305,6 +311,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     }
     gsum += gmax;
     __syncthreads();
+    if(pf) pf->probe(6);
     return rc;
 }
 

@@ -1,0 +1,23 @@
+"""Cycle accounting of the wave-mapped backward step (synthetic n=16/m=8 problem).  Needs
+    make -C ddp-generator_amd/csrc PROBLEMS=synth16x8 WAVE_PROBLEMS= LIBDIR=../lib_prof OBJDIR=../build_prof EXTRA_HIPFLAGS=-DILQG_PROFILE_SECTIONS
+    ILQG_LIBDIR=$PWD/ddp-generator_amd/lib_prof python tools/section_profile_wave.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as g
+g.load_package()
+from ddp_generator_amd import ilqg, synth
+B, N, K = 2048, 1000, 3
+x0, u0 = synth.synth16_batch(B, N)
+s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=synth.SYNTH16_PARAMS, opts=dict(max_iter=K + 2))
+s.init(x0, u0)
+out = (C.c_ulonglong * 8)()
+s.lib.ilqg_dev_section_cycles(out)
+names = ["stage fx,fu; Qu,Qx; Vxx*fx, Vxx*fu", "Qxu, Quu, Qxx incl. tensors", "regularisation", "box QP (every lane, size 8)",
+         "gains", "dV, Quu*l, Quu*K", "Vx, Vxx, g_norm", "loop head"]
+for it in range(K):
+    s.iterate(1); s.sync()
+    s.lib.ilqg_dev_section_cycles(out)
+    calls = s.ints("bp_calls").sum()
+    v = np.array(list(out), dtype=float) / max(1, calls) / N   # per sweep and step
+    print("iteration %d (%.2f sweeps per trajectory): %.0f ticks per step: " % (it + 1, calls / B, v.sum()) + ", ".join("%s %.0f" % (n, x) for n, x in zip(names, v)))
