@@ -801,27 +801,46 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
 }
 
 // After a backward pass over stored records (modes 0 and 1): the line search's packed records from the tiled
-// X, U, l, L.  One lane per (trajectory, time step); step N holds x_N only.
-__global__ __launch_bounds__(256) void k_pack_records(DevPtrs P) {
-    // (lanes = consecutive trajectories: coalesced reads, scattered record writes; the transposed assignment —
-    // contiguous writes, gathered reads — was measured slower: 14 vs 9 ms for 65 536 x 501 records)
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = (int)(tid % P.Bp);
-    const int k = (int)(tid / P.Bp);
-    if(k > P.N || b >= P.B) return;
-    double *rec = nomp(P, k, b);
-    const double *xs = cur_x(P, k, b);
+// X, U, l, L.  One wavefront per (tile of 64 trajectories, time step): the tile's RN values per trajectory are read
+// as coalesced rows (lane = trajectory), turned through LDS, and written as whole records (16 consecutive lanes =
+// one 128-byte record for CarParking) — a lane-per-trajectory write of the records would touch 64 cache lines per
+// instruction (measured 8.8 ms for 65 536 x 501 records; this form is bandwidth bound).  Step N holds x_N only.
+constexpr int PACK_WAVES = 4, PACK_LD = RN + 1;  // row stride padded by one double: no LDS bank conflicts
+__global__ __launch_bounds__(WAVE *PACK_WAVES) void k_pack_records(DevPtrs P) {
+    __shared__ double rows[PACK_WAVES][WAVE * PACK_LD];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x, k = blockIdx.y * PACK_WAVES + w;
+    double *row = rows[w];
+    const int b = tile * WAVE + lane;
+    if(k <= P.N) {
+        double v[RN];
 #pragma unroll
-    for(int i = 0; i < NX; i++) rec[NOM_X + i] = xs[i * XSI];
-    if(k == P.N) return;
-    const double *us = cur_u(P, k, b);
-    const double *ls = P.f[ILQG_F_LG] + ix(P, NU, P.N, k, 0, b), *ks = P.f[ILQG_F_KG] + ix(P, NXU, P.N, k, 0, b);
+        for(int i = 0; i < RN; i++) v[i] = 0.0;
+        const double *xs = cur_x(P, k, b);
 #pragma unroll
-    for(int i = 0; i < NU; i++) rec[NOM_U + i] = us[i * XSI];
+        for(int i = 0; i < NX; i++) v[NOM_X + i] = xs[i * XSI];
+        if(k < P.N) {
+            const double *us = cur_u(P, k, b);
+            const double *ls = P.f[ILQG_F_LG] + ix(P, NU, P.N, k, 0, b), *ks = P.f[ILQG_F_KG] + ix(P, NXU, P.N, k, 0, b);
 #pragma unroll
-    for(int i = 0; i < NU; i++) rec[NOM_L + i] = ls[i * SI];
+            for(int i = 0; i < NU; i++) v[NOM_U + i] = us[i * XSI];
 #pragma unroll
-    for(int i = 0; i < NXU; i++) rec[NOM_K + i] = ks[i * SI];
+            for(int i = 0; i < NU; i++) v[NOM_L + i] = ls[i * SI];
+#pragma unroll
+            for(int i = 0; i < NXU; i++) v[NOM_K + i] = ks[i * SI];
+        }
+#pragma unroll
+        for(int i = 0; i < RN; i++) row[lane * PACK_LD + i] = v[i];
+    }
+    __syncthreads();
+    if(k <= P.N) {
+#pragma unroll
+        for(int r = 0; r < RN; r++) {
+            const int e = r * WAVE + lane;       // element e of the tile's WAVE x RN values, trajectory-major
+            const int tt = e / RN, c = e % RN;
+            if(tile * WAVE + tt < P.B) nomp(P, k, tile * WAVE + tt)[c] = row[tt * PACK_LD + c];
+        }
+    }
 }
 
 #else  // ILQG_WAVE_MAP
@@ -1992,8 +2011,8 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
     }
     if(mode != 2) {
         Timed t(d, ILQG_K_TRANSPOSE);
-        const size_t total = (size_t)d->Bp * (d->N + 1);
-        hipLaunchKernelGGL(k_pack_records, grid1(total, 256), dim3(256), 0, d->stream, d->P);
+        hipLaunchKernelGGL(k_pack_records, dim3(d->Bp / WAVE, (d->N + 1 + PACK_WAVES - 1) / PACK_WAVES),
+                           dim3(WAVE * PACK_WAVES), 0, d->stream, d->P);
     }
     HIP_TRY(hipGetLastError());
     return 0;
