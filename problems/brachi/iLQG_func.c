@@ -1,0 +1,404 @@
+/* Problem functions for 'Brachi' emitted by tools/gen_problem.py. Do not edit.
+ * Function set, signatures and evaluation order: reference iLQG_func.tem:40-521. */
+#include "iLQG.h"
+#include "matMult.h"
+
+#define mcond(cond, a, dummy, b) ((cond)? a: b)
+#define sec(x) (1.0/cos(x))
+#define csc(x) (1.0/sin(x))
+
+int n_params= 3;
+
+tParamDesc p_name1= {"dx", 1, 0};
+tParamDesc p_name2= {"g", 1, 0};
+tParamDesc p_name3= {"yf", 1, 0};
+int n_vars= 0;
+
+tParamDesc *paramdesc[]= {&p_name1, &p_name2, &p_name3};
+
+#define aux_hfe_1 t->hfe_1
+#define aux_pfe_1 t->pfe_1
+#define daux_dpfe_1_x0 t->dpfe_1_x0
+#define daux_dpfe_1_x0x0 t->dpfe_1_x0x0
+
+static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o);
+static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o);
+static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o);
+static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o);
+static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o);
+static int bp_derivsL(trajEl_t *t, int k, double **p);
+static int bp_derivsF(trajFin_t *t, int k, double **p);
+
+static int ddpL(trajEl_t *t, int k, tOptSet *o) {
+    const double *x= t->x;
+    const double *u= t->u;
+    double **p= o->p;
+
+    t->c= -sqrt(2.0)*sqrt((u[0]*u[0]) + 1.0)*(-sqrt(-x[0]) + sqrt(-p[0][0]*u[0] - x[0]))*sqrt(1.0/p[1][0])/u[0];
+    if(isNANorINF(t->c)) { PRNT("    @k %d: t->c in line %d is nan or inf: %g\n", k, __LINE__-1, t->c); return 0; }
+
+    return 1;
+}
+
+static int ddpF(trajFin_t *t, tOptSet *o) {
+    const double *x= t->x;
+    const int k= o->n_hor;
+    double **p= o->p;
+
+    t->c= aux_pfe_1;
+    if(isNANorINF(t->c)) { PRNT("    @k %d: t->c in line %d is nan or inf: %g\n", k, __LINE__-1, t->c); return 0; }
+
+    return 1;
+}
+
+static int ddpf(double x_next[], trajEl_t *t, int k, double **p, int N) {
+    const double *x= t->x;
+    const double *u= t->u;
+
+    x_next[0]= p[0][0]*u[0] + x[0];
+    if(isNANorINF(x_next[0])) { PRNT("    @k %d: x_next[0] in line %d is nan or inf: %g\n", k, __LINE__-1, x_next[0]); return 0; }
+    return 1;
+}
+
+void clampU(double *u, trajEl_t *t, int k, double **p, int N) {
+    double limit;
+    const double *x= t->x;
+
+}
+
+static void limitsU(trajEl_t *t, int k, double **p, int N) {
+    int i, j;
+    int lower_idx[N_U], upper_idx[N_U], *idx_;
+    double limit;
+    const double *x= t->x;
+    double *hx_, *h_sign;
+
+    for(i= 0; i<N_U; i++) {
+        lower_idx[i]= -1;
+        upper_idx[i]= -1;
+        t->lower[i]= -INF;
+        t->upper[i]= INF;
+    }
+
+    for(i= 0; i<N_U; i++) {
+        t->lower[i]-= t->u[i];
+        t->upper[i]-= t->u[i];
+    }
+
+    for(j= 0; j<2; j++) {
+        if(j==0) {
+            idx_= lower_idx;
+            hx_= t->lower_hx;
+            h_sign= t->lower_sign;
+        } else {
+            idx_= upper_idx;
+            hx_= t->upper_hx;
+            h_sign= t->upper_sign;
+        }
+        for(i= 0; i<N_U; i++, hx_+= N_X, h_sign++) {
+            switch(idx_[i]) {
+                case -1:
+                    h_sign[0]= 0.0;
+                    break;
+            }
+        }
+    }
+}
+
+int forward_pass(traj_t *c, tOptSet *o, double alpha, double *csum, int cost_only) {
+    int i, k, j;
+    double dx;
+    double *x0= o->x0;
+    int N= o->n_hor;
+    double **params= o->p;
+
+    trajEl_t *t= o->nominal->t;
+    trajEl_t *ct= c->t;
+    trajFin_t *cf= &c->f;
+
+    multipliersEl_t *m= o->multipliers.t;
+    multipliersFin_t *mf= &o->multipliers.f;
+
+    double *x_next;
+
+    csum[0]= 0.0;
+
+    if(!cost_only)
+        for(i= 0; i<N_X; i++) ct->x[i]= x0[i];
+
+    for(k= 0; k<N; k++, t++, ct++, m++) {
+        if(!cost_only) {
+            if(alpha) {
+                /* u = u_nom + alpha*l + L*(x - x_nom), accumulated state by state */
+                for(j= 0; j<N_U; j++)
+                    ct->u[j]= t->u[j] + t->l[j]*alpha;
+                for(i= 0; i<N_X; i++) {
+                    dx= ct->x[i] - t->x[i];
+                    for(j= 0; j<N_U; j++)
+                        ct->u[j]+= t->L[MAT_IDX(j, i, N_U)]*dx;
+                }
+            } else {
+                for(j= 0; j<N_U; j++)
+                    ct->u[j]= t->u[j];
+            }
+        }
+        if(!calcXVariableAux(ct, m, k, o)) return 0;
+
+        if(!cost_only)
+            clampU(ct->u, ct, k, params, N);
+        if(!calcXUVariableAux(ct, m, k, o)) return 0;
+
+        if(!cost_only) {
+            x_next= (k>=N-1)? cf->x: (ct+1)->x;
+            if(!ddpf(x_next, ct, k, params, N)) return 0;
+        }
+
+        if(!ddpL(ct, k, o)) return 0;
+        csum[0]+= ct->c;
+    }
+
+    if(!calcFVariableAux(cf, mf, o)) return 0;
+    if(!ddpF(cf, o)) return 0;
+    csum[0]+= cf->c;
+
+    return 1;
+}
+
+int calc_derivs(tOptSet *o) {
+    int k;
+    int N= o->n_hor;
+
+    trajEl_t *t= o->nominal->t + N - 1;
+    trajFin_t *f= &o->nominal->f;
+
+    multipliersEl_t *m= o->multipliers.t + N - 1;
+    multipliersFin_t *mf= &o->multipliers.f;
+
+    if(!calcFAuxDeriv(f, mf, o)) return 0;
+    if(!bp_derivsF(f, N, o->p)) return 0;
+
+    for(k= N-1; k>=0; k--, t--, m--) {
+        if(!calcLAuxDeriv(t, m, k, o)) return 0;
+        if(!bp_derivsL(t, k, o->p)) return 0;
+
+        limitsU(t, k, o->p, N);
+    }
+    return 1;
+}
+
+static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
+    const double *x= t->x;
+    double **p= o->p;
+    const double w_pen= o->w_pen_l;
+
+    return 1;
+}
+
+static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
+    const double *x= t->x;
+    const double *u= t->u;
+    double **p= o->p;
+    const double w_pen= o->w_pen_l;
+
+    return 1;
+}
+
+static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
+    const double *x= t->x;
+    double **p= o->p;
+    const double w_pen= o->w_pen_f;
+    const int k= o->n_hor;
+
+    aux_hfe_1= -p[2][0] + x[0];
+    if(isNANorINF(aux_hfe_1)) { PRNT("    @k %d: aux_hfe_1 in line %d is nan or inf: %g\n", k, __LINE__-1, aux_hfe_1); return 0; }
+    aux_pfe_1= 0.5*(aux_hfe_1*aux_hfe_1)*w_pen + aux_hfe_1*m->mu_fe[0];
+    if(isNANorINF(aux_pfe_1)) { PRNT("    @k %d: aux_pfe_1 in line %d is nan or inf: %g\n", k, __LINE__-1, aux_pfe_1); return 0; }
+    return 1;
+}
+
+static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
+    const double *x= t->x;
+    const double *u= t->u;
+    const double w_pen= o->w_pen_l;
+    double **p= o->p;
+
+#if FULL_DDP
+#endif
+    return 1;
+}
+
+static int bp_derivsL(trajEl_t *t, int k, double **p) {
+    const double *x= t->x;
+    const double *u= t->u;
+
+// derivatives of f
+
+
+#if FULL_DDP
+#endif
+
+// derivatives of L
+    t->cx[0]= -sqrt(2.0)*sqrt((u[0]*u[0]) + 1.0)*(-(1.0/2.0)/sqrt(-p[0][0]*u[0] - x[0]) - 1.0/2.0*sqrt(-x[0])/x[0])*sqrt(1.0/p[1][0])/u[0];
+    if(isNANorINF(t->cx[0])) { PRNT("    @k %d: t->cx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[0]); return 0; }
+
+    t->cxx[0]= -sqrt(2.0)*sqrt((u[0]*u[0]) + 1.0)*(-(1.0/4.0)/((-p[0][0]*u[0] - x[0])*sqrt(-p[0][0]*u[0] - x[0])) + (1.0/4.0)*sqrt(-x[0])/(x[0]*x[0]))*sqrt(1.0/p[1][0])/u[0];
+    if(isNANorINF(t->cxx[0])) { PRNT("    @k %d: t->cxx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxx[0]); return 0; }
+
+    t->cu[0]= (1.0/2.0)*sqrt(2.0)*p[0][0]*sqrt((u[0]*u[0]) + 1.0)*sqrt(1.0/p[1][0])/(u[0]*sqrt(-p[0][0]*u[0] - x[0])) - sqrt(2.0)*(-sqrt(-x[0]) + sqrt(-p[0][0]*u[0] - x[0]))*sqrt(1.0/p[1][0])/sqrt((u[0]*u[0]) + 1.0) + sqrt(2.0)*sqrt((u[0]*u[0]) + 1.0)*(-sqrt(-x[0]) + sqrt(-p[0][0]*u[0] - x[0]))*sqrt(1.0/p[1][0])/(u[0]*u[0]);
+    if(isNANorINF(t->cu[0])) { PRNT("    @k %d: t->cu[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cu[0]); return 0; }
+
+    t->cuu[0]= (1.0/4.0)*sqrt(2.0)*(p[0][0]*p[0][0])*sqrt((u[0]*u[0]) + 1.0)*sqrt(1.0/p[1][0])/(u[0]*((-p[0][0]*u[0] - x[0])*sqrt(-p[0][0]*u[0] - x[0]))) + sqrt(2.0)*p[0][0]*sqrt(1.0/p[1][0])/(sqrt((u[0]*u[0]) + 1.0)*sqrt(-p[0][0]*u[0] - x[0])) - sqrt(2.0)*p[0][0]*sqrt((u[0]*u[0]) + 1.0)*sqrt(1.0/p[1][0])/((u[0]*u[0])*sqrt(-p[0][0]*u[0] - x[0])) + sqrt(2.0)*u[0]*(-sqrt(-x[0]) + sqrt(-p[0][0]*u[0] - x[0]))*sqrt(1.0/p[1][0])/(((u[0]*u[0]) + 1.0)*sqrt((u[0]*u[0]) + 1.0)) + sqrt(2.0)*(-sqrt(-x[0]) + sqrt(-p[0][0]*u[0] - x[0]))*sqrt(1.0/p[1][0])/(u[0]*sqrt((u[0]*u[0]) + 1.0)) - 2.0*sqrt(2.0)*sqrt((u[0]*u[0]) + 1.0)*(-sqrt(-x[0]) + sqrt(-p[0][0]*u[0] - x[0]))*sqrt(1.0/p[1][0])/(u[0]*u[0]*u[0]);
+    if(isNANorINF(t->cuu[0])) { PRNT("    @k %d: t->cuu[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cuu[0]); return 0; }
+
+    t->cxu[0]= (1.0/4.0)*sqrt(2.0)*p[0][0]*sqrt((u[0]*u[0]) + 1.0)*sqrt(1.0/p[1][0])/(u[0]*((-p[0][0]*u[0] - x[0])*sqrt(-p[0][0]*u[0] - x[0]))) - sqrt(2.0)*(-(1.0/2.0)/sqrt(-p[0][0]*u[0] - x[0]) - 1.0/2.0*sqrt(-x[0])/x[0])*sqrt(1.0/p[1][0])/sqrt((u[0]*u[0]) + 1.0) + sqrt(2.0)*sqrt((u[0]*u[0]) + 1.0)*(-(1.0/2.0)/sqrt(-p[0][0]*u[0] - x[0]) - 1.0/2.0*sqrt(-x[0])/x[0])*sqrt(1.0/p[1][0])/(u[0]*u[0]);
+    if(isNANorINF(t->cxu[0])) { PRNT("    @k %d: t->cxu[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxu[0]); return 0; }
+
+    return 1;
+}
+
+static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
+    const double *x= t->x;
+    const double w_pen= o->w_pen_f;
+    double **p= o->p;
+    const int k= o->n_hor;
+
+    daux_dpfe_1_x0= 1.0*aux_hfe_1*w_pen + m->mu_fe[0];
+    if(isNANorINF(daux_dpfe_1_x0)) { PRNT("    @k %d: daux_dpfe_1_x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_1_x0); return 0; }
+    daux_dpfe_1_x0x0= 1.0*w_pen;
+    if(isNANorINF(daux_dpfe_1_x0x0)) { PRNT("    @k %d: daux_dpfe_1_x0x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_1_x0x0); return 0; }
+    return 1;
+}
+
+static int bp_derivsF(trajFin_t *t, int k, double **p) {
+    const double *x= t->x;
+
+    t->cx[0]= daux_dpfe_1_x0;
+    if(isNANorINF(t->cx[0])) { PRNT("    @k %d: t->cx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[0]); return 0; }
+
+    t->cxx[0]= daux_dpfe_1_x0x0;
+    if(isNANorINF(t->cxx[0])) { PRNT("    @k %d: t->cxx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cxx[0]); return 0; }
+    return 1;
+}
+
+static int init_running(trajEl_t *t, tOptSet *o) {
+    int k;
+    double **p= o->p;
+
+    for(k= 0; k<o->n_hor; k++, t++) {
+#if FULL_DDP
+#endif
+
+// derivatives of L
+
+
+
+
+
+// derivatives of f
+        t->fx[0]= 1.0;
+
+        t->fu[0]= p[0][0];
+        if(isNANorINF(t->fu[0])) { PRNT("    @k %d: t->fu[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fu[0]); return 0; }
+
+#if FULL_DDP
+        { int i_; for(i_= 0; i_<N_X*sizeofQxx; i_++) t->fxx[i_]= 0.0; }
+
+        { int i_; for(i_= 0; i_<N_X*sizeofQuu; i_++) t->fuu[i_]= 0.0; }
+
+        { int i_; for(i_= 0; i_<N_X*sizeofQxu; i_++) t->fxu[i_]= 0.0; }
+
+#endif
+    }
+
+    return 1;
+}
+
+static int init_final(trajFin_t *t, tOptSet *o) {
+    double **p= o->p;
+    const int k= o->n_hor;
+
+
+
+    return 1;
+}
+
+int init_trajectory(traj_t *t, tOptSet *o) {
+    if(!init_running(t->t, o)) return 0;
+    if(!init_final(&t->f, o)) return 0;
+
+    return 1;
+}
+
+static int init_multipliers_running(tOptSet *o) {
+    return 1;
+}
+
+static int init_multipliers_final(tOptSet *o) {
+    multipliersFin_t *m= &o->multipliers.f;
+    int i;
+
+    for(i= 0; i<1; i++) { m->mu_fe[i]= 0.0; m->last_hfe[i]= 0.0; }
+
+    return 1;
+}
+
+int init_multipliers(tOptSet *o) {
+    if(!init_multipliers_running(o)) return 0;
+    if(!init_multipliers_final(o)) return 0;
+
+    return 1;
+}
+
+int init_opt(tOptSet *o) {
+    int i;
+
+    for(i= 0; i<NUMBER_OF_THREADS+1; i++)
+        if(!init_trajectory(&o->trajectories[i], o)) return 0;
+
+    o->nominal= &o->trajectories[0];
+    for(i= 1; i<NUMBER_OF_THREADS+1; i++)
+        o->candidates[i-1]= &o->trajectories[i];
+
+    if(!init_multipliers(o)) return 0;
+
+    return 1;
+}
+
+static int update_multipliers_running(tOptSet *o, int init) {
+    return 1;
+}
+
+static int update_multipliers_final(tOptSet *o, int init) {
+    trajFin_t *t= &o->nominal->f;
+    multipliersFin_t *m= &o->multipliers.f;
+    const double w_pen= o->w_pen_f;
+    double **p= o->p;
+    int increase_pen= 0;
+    int k= o->n_hor;
+
+    if(fabs(aux_hfe_1)>o->tolConstraint && o->w_pen_fact1*fabs(aux_hfe_1)>fabs(m->last_hfe[0])) increase_pen= 1;
+    m->last_hfe[0]= aux_hfe_1;
+
+    if(!init && increase_pen)
+        o->w_pen_f= min(o->w_pen_max_f, o->w_pen_f*o->w_pen_fact1);
+
+    if(init) return 1;
+    m->mu_fe[0]= aux_hfe_1*w_pen + m->mu_fe[0];
+    if(isNANorINF(m->mu_fe[0])) { PRNT("    @k %d: m->mu_fe[0] in line %d is nan or inf: %g\n", k, __LINE__-1, m->mu_fe[0]); return 0; }
+    return 1;
+}
+
+int update_multipliers(tOptSet *o, int init) {
+    if(!update_multipliers_running(o, init)) return 0;
+    if(!update_multipliers_final(o, init)) return 0;
+
+    return 1;
+}
+
+int get_g_size() {
+    return(0);
+}
+
+int calcG(double g[], trajEl_t *t, int k, double **p) {
+    return(1);
+}

@@ -1,0 +1,86 @@
+/* Problem header for 'Brachi' emitted by tools/gen_problem.py. Do not edit.
+ * Layout contract: reference iLQG_problem.tem:16-89. */
+#ifndef ILQG_PROBLEM_H
+#define ILQG_PROBLEM_H
+
+#include <math.h>
+#include "mex.h"
+#ifndef  HAVE_OCTAVE
+#include "matrix.h"
+#endif
+
+#define isNANorINF(v) (mxIsNaN(v) || mxIsInf(v))
+#define INF mxGetInf()
+
+#define N_X 1
+#define N_U 1
+
+#define sizeofQxx 1
+#define sizeofQuu 1
+#define sizeofQxu 1
+
+/* additive hints for the batched backend (absent in Maxima-generated headers,
+ * which are then treated as the general case) */
+#define ILQG_PROBLEM_NAME "Brachi"
+#define ILQG_STATE_DEPENDENT_LIMITS 0
+
+typedef struct {
+    double x[N_X];
+    double u[N_U];
+    double lower[N_U];
+    double upper[N_U];
+    double lower_sign[N_U];
+    double upper_sign[N_U];
+    double lower_hx[N_X*N_U];
+    double upper_hx[N_X*N_U];
+
+    double l[N_U];
+    double L[N_U*N_X];
+    double c;
+    double cx[N_X];
+    double cxx[sizeofQxx];
+    double cu[N_U];
+    double cuu[sizeofQuu];
+    double cxu[sizeofQxu];
+    double fx[N_X*N_X];
+    double fu[N_X*N_U];
+#if FULL_DDP
+    double fxx[N_X*sizeofQxx];
+    double fuu[N_X*sizeofQuu];
+    double fxu[N_X*sizeofQxu];
+#endif
+#if FULL_DDP
+#endif
+} trajEl_t;
+
+typedef struct {
+    double x[N_X];
+
+    double c;
+    double cx[N_X];
+    double cxx[sizeofQxx];
+    double hfe_1;
+    double pfe_1;
+    double dpfe_1_x0;
+    double dpfe_1_x0x0;
+} trajFin_t;
+
+typedef struct {
+    trajEl_t* t;
+    trajFin_t f;
+} traj_t;
+
+typedef struct {
+} multipliersEl_t;
+
+typedef struct {
+    double mu_fe[1];
+    double last_hfe[1];
+} multipliersFin_t;
+
+typedef struct {
+    multipliersEl_t* t;
+    multipliersFin_t f;
+} multipliers_t;
+
+#endif // ILQG_PROBLEM_H

@@ -23,8 +23,11 @@ What "conforming" means (layout contract, all from the reference):
   * auxiliary variables and their derivatives are struct members evaluated
     once per step and reused                    (gen_dep_graph.mac:187-229)
 
-Augmented-Lagrangian constraints (hfe/hfi/hle/hli) are not supported yet; the
-multiplier structs are emitted empty and update_multipliers is a no-op.
+Augmented-Lagrangian constraints hle / hli (running) and hfe / hfi (final) become penalty terms of
+L resp. F with multipliers mu and the penalty weight w_pen, exactly as genenerator_main.mac:46-124
+builds them (equality: mu*h + 0.5*w_pen*h^2; inequality after Ruxton: mu*h*(1+w_pen*h) for h >= 0,
+mu*h/(1-w_pen*h) else); multiplier structs, init_multipliers and update_multipliers follow
+iLQG_problem.tem:70-89 and iLQG_func.tem:371-509.
 
 Usage:  python tools/gen_problem.py problems/defs/carparking.py problems/carparking
 """
@@ -53,14 +56,17 @@ class Problem:
         self.L = None
         self.F = None
         self.h = []       # input constraints h_i < 0
+        # augmented-Lagrangian constraints (genenerator_main.mac:46-124): running equality / inequality (<= 0),
+        # final equality / inequality; may depend on x (running ones also on u) and parameters
+        self.hle, self.hli, self.hfe, self.hfi = [], [], [], []
         self.fast = False # True: skip sympy.simplify (large generated problems)
 
     def states(self, names):
-        self.x = list(sp.symbols(names, real=True))
+        self.x = list(sp.symbols(names, real=True, seq=True))
         return self.x
 
     def inputs(self, names):
-        self.u = list(sp.symbols(names, real=True))
+        self.u = list(sp.symbols(names, real=True, seq=True))
         return self.u
 
     def scalar(self, name):
@@ -253,13 +259,43 @@ class Emitter:
         self.p = prob
         self.n = len(prob.x)
         self.m = len(prob.u)
+        self._constraints()
         self.D = Deriver(prob)
         self.param_names = sorted(prob.params)  # internal consistency is all that matters
-        self.time_syms = set(prob.x) | set(prob.u)
+        self.time_syms = set(prob.x) | set(prob.u) | set(self.mu_c) | {self.w_pen}
         for nm in self.param_names:
             if prob.params[nm] == -1:
                 self.time_syms.add(sp.Symbol("%s[k]" % nm, real=True))
         self._derive()
+
+    # ---- augmented-Lagrangian terms (genenerator_main.mac:46-124) ----------
+    def _constraints(self):
+        """h and its penalty become auxiliaries (the reference assigns them with `::`), the penalty is added to
+        L (running) or F (final); mu_<kind>_<i> print as m->mu_<kind>[i-1], w_pen as the local w_pen"""
+        p = self.p
+        self.w_pen = sp.Symbol("w_pen", real=True)
+        self.mu_c = {}      # multiplier symbol -> C spelling
+        self.cons_al = {}   # kind -> list of (h aux symbol, mu symbol)
+        w = self.w_pen
+        for kind, exprs in (("le", p.hle), ("li", p.hli), ("fe", p.hfe), ("fi", p.hfi)):
+            self.cons_al[kind] = []
+            for i, h in enumerate(exprs):
+                h = sp.sympify(h)
+                if kind[0] == "f" and any(uu in h.free_symbols for uu in p.u):
+                    raise ValueError("h%s must not depend on any input u" % kind)  # genenerator_main.mac:48-49
+                hs = p.auxiliary("h%s_%d" % (kind, i + 1), h)
+                mu = sp.Symbol("mu_%s_%d" % (kind, i + 1), real=True)
+                self.mu_c[mu] = "m->mu_%s[%d]" % (kind, i)
+                if kind[1] == "e":
+                    pen = mu * hs + sp.Float(0.5) * w * hs**2
+                else:
+                    pen = sp.Piecewise((mu * hs * (1 + w * hs), hs >= 0), (mu * hs / (1 - w * hs), True))
+                ps = p.auxiliary("p%s_%d" % (kind, i + 1), pen)
+                if kind[0] == "l":
+                    p.L = p.L + ps
+                else:
+                    p.F = sp.sympify(p.F) + ps
+                self.cons_al[kind].append((hs, mu))
 
     # ---- symbolic work -------------------------------------------------
     def _derive(self):
@@ -339,6 +375,8 @@ class Emitter:
                     rep[sp.Symbol("%s[%d]" % (nm, j), real=True)] = sp.Symbol("p[%d][%d]" % (pi, j))
         for s in self.D.defs:
             rep[s] = sp.Symbol(self.macro_name(s))
+        for mu, spelling in self.mu_c.items():
+            rep[mu] = sp.Symbol(spelling)
         return e.xreplace(rep)
 
     def macro_name(self, s):
@@ -422,6 +460,15 @@ class Emitter:
         run_members = "".join("    double %s;\n" % s.name for s in self.aux_syms(self.run_need, ("aux", "d1", "d2")))
         run_members_full = "".join("    double %s;\n" % s.name for s in self.aux_syms(self.run_need_full, ("aux", "d1", "d2")))
         fin_members = "".join("    double %s;\n" % s.name for s in self.aux_syms(self.fin_need, ("aux", "d1", "d2")))
+
+        def mul_members(kinds):
+            out = ""
+            for kind in kinds:
+                cnt = len(self.cons_al[kind])
+                if cnt:
+                    out += "    double mu_%s[%d];\n    double last_h%s[%d];\n" % (kind, cnt, kind, cnt)
+            return out
+        mul_el, mul_fin = mul_members(("le", "li")), mul_members(("fe", "fi"))
         return f"""/* Problem header for '{self.p.name}' emitted by tools/gen_problem.py. Do not edit.
  * Layout contract: reference iLQG_problem.tem:16-89. */
 #ifndef ILQG_PROBLEM_H
@@ -491,10 +538,10 @@ typedef struct {{
 }} traj_t;
 
 typedef struct {{
-}} multipliersEl_t;
+{mul_el}}} multipliersEl_t;
 
 typedef struct {{
-}} multipliersFin_t;
+{mul_fin}}} multipliersFin_t;
 
 typedef struct {{
     multipliersEl_t* t;
@@ -747,15 +794,9 @@ int calc_derivs(tOptSet *o) {
     return 1;
 }
 
-static int init_multipliers_running(tOptSet *o) {
-    return 1;
-}
-
-static int init_multipliers_final(tOptSet *o) {
-    return 1;
-}
-
-int init_multipliers(tOptSet *o) {
+""")
+        w(self.multiplier_init())
+        w("""int init_multipliers(tOptSet *o) {
     if(!init_multipliers_running(o)) return 0;
     if(!init_multipliers_final(o)) return 0;
 
@@ -777,15 +818,9 @@ int init_opt(tOptSet *o) {
     return 1;
 }
 
-static int update_multipliers_running(tOptSet *o, int init) {
-    return 1;
-}
-
-static int update_multipliers_final(tOptSet *o, int init) {
-    return 1;
-}
-
-int update_multipliers(tOptSet *o, int init) {
+""")
+        w(self.multiplier_update())
+        w("""int update_multipliers(tOptSet *o, int init) {
     if(!update_multipliers_running(o, init)) return 0;
     if(!update_multipliers_final(o, init)) return 0;
 
@@ -801,6 +836,91 @@ int calcG(double g[], trajEl_t *t, int k, double **p) {
 }
 """)
         return "".join(o)
+
+
+def _multiplier_init(self):
+    """init_multipliers_running / _final (iLQG_func.tem:371-393): equality multipliers 0, inequality multipliers 1"""
+    al = self.cons_al
+    out = "static int init_multipliers_running(tOptSet *o) {\n"
+    if al["le"] or al["li"]:
+        out += "    multipliersEl_t *m= o->multipliers.t;\n    int k, i;\n\n    for(k= 0; k<o->n_hor; k++, m++) {\n"
+        if al["le"]:
+            out += "        for(i= 0; i<%d; i++) { m->mu_le[i]= 0.0; m->last_hle[i]= 0.0; }\n" % len(al["le"])
+        if al["li"]:
+            out += "        for(i= 0; i<%d; i++) { m->mu_li[i]= 1.0; m->last_hli[i]= 0.0; }\n" % len(al["li"])
+        out += "    }\n\n"
+    out += "    return 1;\n}\n\nstatic int init_multipliers_final(tOptSet *o) {\n"
+    if al["fe"] or al["fi"]:
+        out += "    multipliersFin_t *m= &o->multipliers.f;\n    int i;\n\n"
+        if al["fe"]:
+            out += "    for(i= 0; i<%d; i++) { m->mu_fe[i]= 0.0; m->last_hfe[i]= 0.0; }\n" % len(al["fe"])
+        if al["fi"]:
+            out += "    for(i= 0; i<%d; i++) { m->mu_fi[i]= 1.0; m->last_hfi[i]= 0.0; }\n" % len(al["fi"])
+        out += "\n"
+    out += "    return 1;\n}\n\n"
+    return out
+
+
+def _multiplier_update(self):
+    """update_multipliers_running / _final (iLQG_func.tem:419-509), literally: the constraint values are the
+    auxiliaries the last roll-out of the nominal trajectory left in its elements; with init != 0 the running part
+    returns inside its loop after the first element, as the reference's template does"""
+    al, w = self.cons_al, self.w_pen
+
+    def hval(hs):
+        return self.macro_name(hs)
+
+    def checks(kind, ind):
+        pad, out = " " * ind, ""
+        for i, (hs, mu) in enumerate(al[kind]):
+            h = hval(hs)
+            if kind[1] == "e":
+                out += ("%sif(fabs(%s)>o->tolConstraint && o->w_pen_fact1*fabs(%s)>fabs(m->last_h%s[%d])) increase_pen= 1;\n"
+                        % (pad, h, h, kind, i))
+            else:
+                out += ("%sif(%s>o->tolConstraint && o->w_pen_fact1*%s>m->last_h%s[%d]) increase_pen= 1;\n"
+                        % (pad, h, h, kind, i))
+            out += "%sm->last_h%s[%d]= %s;\n\n" % (pad, kind, i, h)
+        return out
+
+    def updates(kind, ind, ret="0"):
+        pad, out = " " * ind, ""
+        for i, (hs, mu) in enumerate(al[kind]):
+            lhs = self.mu_c[mu]
+            if kind[1] == "e":
+                out += self.assign(lhs, mu + w * hs, ind)
+            else:  # inequality constraints after D. Ruxton (iLQG_func.tem:455-463)
+                out += "%sif(%s>=0) {\n" % (pad, hval(hs))
+                out += self.assign(lhs, mu * (1 + 2 * w * hs), ind + 4)
+                out += "%s} else {\n" % pad
+                out += self.assign(lhs, mu * (1 - w * hs) ** -2, ind + 4)
+                out += "%s}\n\n" % pad
+        return out
+
+    out = "static int update_multipliers_running(tOptSet *o, int init) {\n"
+    if al["le"] or al["li"]:
+        out += ("    trajEl_t *t= o->nominal->t;\n    multipliersEl_t *m= o->multipliers.t;\n"
+                "    const double w_pen= o->w_pen_l;\n    double **p= o->p;\n    int increase_pen= 0;\n    int k;\n\n"
+                "    for(k= 0; k<o->n_hor; k++, m++, t++) {\n")
+        out += checks("le", 8) + checks("li", 8)
+        out += "        if(init) return 1;\n"
+        out += updates("le", 8) + updates("li", 8)
+        out += ("    }\n\n    if(!init && increase_pen)\n"
+                "        o->w_pen_l= min(o->w_pen_max_l, o->w_pen_l*o->w_pen_fact1);\n\n")
+    out += "    return 1;\n}\n\nstatic int update_multipliers_final(tOptSet *o, int init) {\n"
+    if al["fe"] or al["fi"]:
+        out += ("    trajFin_t *t= &o->nominal->f;\n    multipliersFin_t *m= &o->multipliers.f;\n"
+                "    const double w_pen= o->w_pen_f;\n    double **p= o->p;\n    int increase_pen= 0;\n    int k= o->n_hor;\n\n")
+        out += checks("fe", 4) + checks("fi", 4)
+        out += ("    if(!init && increase_pen)\n        o->w_pen_f= min(o->w_pen_max_f, o->w_pen_f*o->w_pen_fact1);\n\n"
+                "    if(init) return 1;\n")
+        out += updates("fe", 4) + updates("fi", 4)
+    out += "    return 1;\n}\n\n"
+    return out
+
+
+Emitter.multiplier_init = _multiplier_init
+Emitter.multiplier_update = _multiplier_update
 
 
 def load_problem(path):
