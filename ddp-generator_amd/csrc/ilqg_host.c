@@ -514,6 +514,26 @@ int ilqg_batch_get_derivs(ilqg_batch_t *c, double *rec, double *fin) {
     return each_read(c, ILQG_F_DER, rec, "get_derivs") || each_read(c, ILQG_F_FIN, fin, "get_derivs");
 }
 
+/* multipliers as arrays of doubles in the member order of multipliersEl_t / multipliersFin_t
+ * (iLQG_problem.tem:70-89): running [B][n_hor][el], final [B][fin] */
+void ilqg_problem_multiplier_dims(int *out) { ilqg_dev_multiplier_dims(out); }
+
+int ilqg_batch_get_multipliers(ilqg_batch_t *c, double *running, double *final) {
+    int dims[2];
+    ilqg_dev_multiplier_dims(dims);
+    if(dims[0] > 0 && running && each_read(c, ILQG_F_MUL, running, "get_multipliers")) return 1;
+    if(dims[1] > 0 && final && each_read(c, ILQG_F_MULF, final, "get_multipliers")) return 1;
+    return 0;
+}
+
+int ilqg_batch_set_multipliers(ilqg_batch_t *c, const double *running, const double *final) {
+    int dims[2];
+    ilqg_dev_multiplier_dims(dims);
+    if(dims[0] > 0 && running && each_write(c, ILQG_F_MUL, running, "set_multipliers")) return 1;
+    if(dims[1] > 0 && final && each_write(c, ILQG_F_MULF, final, "set_multipliers")) return 1;
+    return 0;
+}
+
 int ilqg_batch_set_derivs(ilqg_batch_t *c, const double *rec, const double *fin) {
     return each_write(c, ILQG_F_DER, rec, "set_derivs") || each_write(c, ILQG_F_FIN, fin, "set_derivs");
 }
@@ -522,7 +542,7 @@ static const struct { const char *name; int field; } scalar_names[] = {
     {"cost", ILQG_F_COST},         {"new_cost", ILQG_F_NEW_COST}, {"dcost", ILQG_F_DCOST},
     {"expected", ILQG_F_EXPECTED}, {"lambda", ILQG_F_LAMBDA},     {"dlambda", ILQG_F_DLAMBDA},
     {"g_norm", ILQG_F_GNORM},      {"dV0", ILQG_F_DV0},           {"dV1", ILQG_F_DV1},
-    {"alpha_cost", ILQG_F_ALPHA_COST},
+    {"alpha_cost", ILQG_F_ALPHA_COST}, {"w_pen_l", ILQG_F_WPEN_L},  {"w_pen_f", ILQG_F_WPEN_F},
 };
 static const struct { const char *name; int field; } int_names[] = {
     {"status", ILQG_I_STATUS},     {"iterations", ILQG_I_ITER},   {"alpha_idx", ILQG_I_ALPHA_IDX},
@@ -755,6 +775,14 @@ int line_search(tOptSet *o, int iter) {
     DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_LG, l), "line_search()");
     DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_KG, L), "line_search()");
     DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_COST, &o->cost), "line_search()");
+    if(sizeof(multipliersEl_t) > 0) { /* structs of doubles (iLQG_problem.tem:70-89): the array as it is */
+        DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_MUL, (const double *)o->multipliers.t), "line_search()");
+    }
+    if(sizeof(multipliersFin_t) > 0) {
+        DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_MULF, (const double *)&o->multipliers.f), "line_search()");
+    }
+    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_WPEN_L, &o->w_pen_l), "line_search()");
+    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_WPEN_F, &o->w_pen_f), "line_search()");
     DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_DV0, &o->dV[0]), "line_search()");
     DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_DV1, &o->dV[1]), "line_search()");
     DEV_OK(ilqg_dev_write_int(c->dev[0], ILQG_I_STATUS, &zero), "line_search()");

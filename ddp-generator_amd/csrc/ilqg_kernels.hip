@@ -211,6 +211,13 @@ constexpr int SXX = RL::SXX, SUU = RL::SUU, NXU = RL::NXU, REC = RL::SIZE, REC_H
 constexpr int FIN = NX + SXX;
 constexpr int WAVE = 64;
 constexpr bool WAVE_MAP = ILQG_WAVE_MAP;
+// Augmented-Lagrangian multipliers (iLQG_problem.tem:70-89): the generated structs hold nothing but doubles
+// (mu and the constraint value of the last update per constraint); empty for a problem without hle/hli/hfe/hfi.
+constexpr int ME = std::is_empty<multipliersEl_t>::value ? 0 : (int)(sizeof(multipliersEl_t) / sizeof(double));
+constexpr int MF = std::is_empty<multipliersFin_t>::value ? 0 : (int)(sizeof(multipliersFin_t) / sizeof(double));
+constexpr bool HAS_MUL = ME + MF > 0;
+constexpr int MEW = ME > 0 ? ME : 1, MFW = MF > 0 ? MF : 1;  // widths of the (possibly unused) device fields
+static_assert(!(WAVE_MAP && HAS_MUL), "multipliers are implemented for the lane mapping only");
 
 thread_local std::string g_err;
 
@@ -294,6 +301,45 @@ __device__ __forceinline__ double *cur_u(const DevPtrs &P, int k, int b) {
 __device__ __forceinline__ size_t cur_xstride(const DevPtrs &P) { return WAVE_MAP ? (size_t)RN : (size_t)NX * P.Bp; }
 __device__ __forceinline__ size_t cur_ustride(const DevPtrs &P) { return WAVE_MAP ? (size_t)RN : (size_t)NU * P.Bp; }
 
+// Multipliers of (trajectory b, step k) resp. the final ones: tiled like the derivative records,
+// [step][tile of 64][component][trajectory in tile].  The structs travel as arrays of doubles.
+__device__ __forceinline__ void load_mul(const DevPtrs &P, int k, int b, multipliersEl_t &m) {
+    if(ME > 0) {
+        double v[MEW];
+        const double *s = P.f[ILQG_F_MUL] + ix(P, ME, P.N, k, 0, b);
+#pragma unroll
+        for(int i = 0; i < ME; i++) v[i] = s[i * SI];
+        __builtin_memcpy(&m, v, sizeof(double) * ME);
+    }
+}
+__device__ __forceinline__ void store_mul(const DevPtrs &P, int k, int b, const multipliersEl_t &m) {
+    if(ME > 0) {
+        double v[MEW];
+        __builtin_memcpy(v, &m, sizeof(double) * ME);
+        double *s = P.f[ILQG_F_MUL] + ix(P, ME, P.N, k, 0, b);
+#pragma unroll
+        for(int i = 0; i < ME; i++) s[i * SI] = v[i];
+    }
+}
+__device__ __forceinline__ void load_mul_fin(const DevPtrs &P, int b, multipliersFin_t &m) {
+    if(MF > 0) {
+        double v[MFW];
+        const double *s = P.f[ILQG_F_MULF] + ix(P, MF, 1, 0, 0, b);
+#pragma unroll
+        for(int i = 0; i < MF; i++) v[i] = s[i * SI];
+        __builtin_memcpy(&m, v, sizeof(double) * MF);
+    }
+}
+__device__ __forceinline__ void store_mul_fin(const DevPtrs &P, int b, const multipliersFin_t &m) {
+    if(MF > 0) {
+        double v[MFW];
+        __builtin_memcpy(v, &m, sizeof(double) * MF);
+        double *s = P.f[ILQG_F_MULF] + ix(P, MF, 1, 0, 0, b);
+#pragma unroll
+        for(int i = 0; i < MF; i++) s[i * SI] = v[i];
+    }
+}
+
 // Per-lane snapshot of the problem parameters.  The generated callbacks read parameters as
 // p[i][j] through a `double **`; read from global memory, every such value would have to be
 // re-loaded after each store of the kernel (the compiler cannot prove that the parameter
@@ -352,6 +398,14 @@ __device__ __forceinline__ void make_callbacks(Callbacks &C, ParamTable &T, Para
     o.w_pen_max_f = O.w_pen_max_f;
     C.o1 = o;
     C.o1.n_hor = 1;
+}
+// problems with multipliers: the penalty weights are per trajectory (they grow with the constraint violation)
+__device__ __forceinline__ void set_penalty_weights(Callbacks &C, double w_l, double w_f) {
+    C.o.w_pen_l = C.o1.w_pen_l = w_l;
+    C.o.w_pen_f = C.o1.w_pen_f = w_f;
+}
+__device__ __forceinline__ void load_penalty_weights(Callbacks &C, const DevPtrs &P, int b) {
+    if(HAS_MUL) set_penalty_weights(C, P.f[ILQG_F_WPEN_L][b], P.f[ILQG_F_WPEN_F][b]);
 }
 // declares the callback context C and the lane's hooks H of a kernel with arguments (P, O, A)
 #define ILQG_CALLBACKS(C, H) \
@@ -414,7 +468,8 @@ __global__ void k_from_dev(const double *__restrict__ dev, double *__restrict__ 
 // `overlapped` is called between the evaluation and the test for the rare second evaluation: a caller
 // that has independent work in flight pins its results there, so that both share one basic block.
 template <class F>
-__device__ __forceinline__ int derivs_step(trajEl_t &t, Callbacks &C, ilqg_hooks &H, int k, int N, F &&overlapped) {
+__device__ __forceinline__ int derivs_step(trajEl_t &t, multipliersEl_t *m, Callbacks &C, ilqg_hooks &H, int k, int N,
+                                           F &&overlapped) {
     double x[NX], u[NU];
 #pragma unroll
     for(int i = 0; i < NX; i++) x[i] = t.x[i];
@@ -424,9 +479,9 @@ __device__ __forceinline__ int derivs_step(trajEl_t &t, Callbacks &C, ilqg_hooks
     H.huge = 0.0;
     int ok = 1;
     auto body = [&]() {
-        ok = calcXVariableAux(&t, nullptr, k, &C.o);
-        ok &= calcXUVariableAux(&t, nullptr, k, &C.o);
-        ok &= calcLAuxDeriv(&t, nullptr, k, &C.o);
+        ok = calcXVariableAux(&t, m, k, &C.o);
+        ok &= calcXUVariableAux(&t, m, k, &C.o);
+        ok &= calcLAuxDeriv(&t, m, k, &C.o);
         ok &= bp_derivsL(&t, k, C.o.p);
         limitsU(&t, k, C.o.p, N);
     };
@@ -445,7 +500,7 @@ __device__ __forceinline__ int derivs_step(trajEl_t &t, Callbacks &C, ilqg_hooks
     return ok;
 }
 
-__device__ __forceinline__ int derivs_final(trajFin_t &fin, Callbacks &C, ilqg_hooks &H, int N) {
+__device__ __forceinline__ int derivs_final(trajFin_t &fin, multipliersFin_t *m, Callbacks &C, ilqg_hooks &H, int N) {
     double x[NX];
 #pragma unroll
     for(int i = 0; i < NX; i++) x[i] = fin.x[i];
@@ -453,8 +508,8 @@ __device__ __forceinline__ int derivs_final(trajFin_t &fin, Callbacks &C, ilqg_h
     H.huge = 0.0;
     int ok = 1;
     auto body = [&]() {
-        ok = calcFVariableAux(&fin, nullptr, &C.o);
-        ok &= calcFAuxDeriv(&fin, nullptr, &C.o);
+        ok = calcFVariableAux(&fin, m, &C.o);
+        ok &= calcFAuxDeriv(&fin, m, &C.o);
         ok &= bp_derivsF(&fin, N, C.o.p);
     };
     body();
@@ -495,9 +550,12 @@ __global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O, Pa
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_NEED_DERIVS][b]) return;
 
     ILQG_CALLBACKS(C, H);
+    load_penalty_weights(C, P, b);
     int ok = 1;
     if(k < P.N) {
         trajEl_t t;
+        multipliersEl_t m;
+        load_mul(P, k, b, m);
         init_running(&t, &C.o1);
         const double *xs = cur_x(P, k, b), *us = cur_u(P, k, b);
 #pragma unroll
@@ -505,18 +563,20 @@ __global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O, Pa
 #pragma unroll
         for(int i = 0; i < NU; i++) t.u[i] = us[i * XSI];
 
-        ok = derivs_step(t, C, H, k, P.N, [] {});
+        ok = derivs_step(t, HAS_MUL ? &m : nullptr, C, H, k, P.N, [] {});
         double *out = P.f[ILQG_F_DER] + ix(P, REC, P.N, k, 0, b);
 #define PUT(off, arr, cnt) _Pragma("unroll") for(int i = 0; i < (cnt); i++) out[((off) + i) * SI] = (arr)[i];
         REC_COPY(PUT, t)
     } else {
         trajFin_t fin;
+        multipliersFin_t mf;
+        load_mul_fin(P, b, mf);
         init_final(&fin, &C.o);
         const double *xs = cur_x(P, P.N, b);
 #pragma unroll
         for(int i = 0; i < NX; i++) fin.x[i] = xs[i * XSI];
 
-        ok = derivs_final(fin, C, H, P.N);
+        ok = derivs_final(fin, HAS_MUL ? &mf : nullptr, C, H, P.N);
         double *out = P.f[ILQG_F_FIN] + ix(P, FIN, 1, 0, 0, b);
         PUT(0, fin.cx, NX)
         PUT(NX, fin.cxx, SXX)
@@ -626,7 +686,7 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
 #pragma unroll
             for(int i = 0; i < NX; i++) recN[NOM_X + i] = fin.x[i];
         }
-        const int ok = derivs_final(fin, C, H, N);
+        const int ok = derivs_final(fin, nullptr, C, H, N);  // no multipliers on this path (see ilqg_dev_set_opts)
         if(!ok || H.nonfinite != 0.0) return 2;
 #pragma unroll
         for(int i = 0; i < NX; i++) Vx[i] = fin.cx[i];
@@ -654,7 +714,7 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
         for(int i = 0; i < NX; i++) t.x[i] = xv[i];
 #pragma unroll
         for(int i = 0; i < NU; i++) t.u[i] = uv[i];
-        const int ok = derivs_step(t, C, H, k, N, overlapped);
+        const int ok = derivs_step(t, nullptr, C, H, k, N, overlapped);
         REC_COPY(GETF, t)
         return ok;
     };
@@ -1077,7 +1137,7 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
         if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) return;
         alpha = O.alpha[P.i[ILQG_I_ALPHA_IDX][b] - 1];
     } else if(mode == ROLL_COST) {
-        if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) return;
+        if(!P.i[ILQG_I_RESWEEP][b]) return;  // set by k_update
     }
     constexpr bool cost_only = (KIND == RK_COST);
     constexpr bool gains = (KIND == RK_GENERAL);
@@ -1085,7 +1145,13 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
     const bool feedback = (alpha != 0.0);  // alpha == 0.0: u = u_nom without feedback (iLQG_func.tem:156-158)
 
     ILQG_CALLBACKS(C, H);
+    // penalty weights of this trajectory; the initial roll-out runs before the solver entry sets them, with the
+    // zero-initialised option set of the MEX entry (iLQG_mex.c:23,116; iLQG.c:233-234)
+    if(HAS_MUL && KIND == RK_INIT) set_penalty_weights(C, 0.0, 0.0);
+    else load_penalty_weights(C, P, b);
     trajEl_t ct;
+    multipliersEl_t mk;
+    multipliersEl_t *const mp = HAS_MUL ? &mk : nullptr;
     init_running(&ct, &C.o1);  // constant auxiliaries of this problem (iLQG_func.tem:312-347)
 
     // this trajectory's step 0 in every field; all of them advance by one step per iteration
@@ -1159,6 +1225,15 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
         if(KIND != RK_GENERAL && k + 1 >= N) qn.u = q.u;
         load_nominal<gains, CS>(cur, qn);
 
+        if(HAS_MUL) {
+            if(KIND == RK_INIT) {  // init_opt -> init_multipliers (iLQG_func.tem:371-402), element by element
+                C.o1.multipliers.t = &mk;
+                init_multipliers_running(&C.o1);
+                store_mul(P, k, b, mk);
+            } else {
+                load_mul(P, k, b, mk);
+            }
+        }
         // the step (iLQG_func.tem:160-176)
         double xnext[NX];
         const double nf0 = H.nonfinite;
@@ -1168,9 +1243,9 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
             for(int i = 0; i < NX; i++) ct.x[i] = xin[i];
 #pragma unroll
             for(int j = 0; j < NU; j++) ct.u[j] = uin[j];
-            int r = calcXVariableAux(&ct, nullptr, k, &C.o);
+            int r = calcXVariableAux(&ct, mp, k, &C.o);
             if(!cost_only) clampU(ct.u, &ct, k, C.o.p, N);
-            r &= calcXUVariableAux(&ct, nullptr, k, &C.o);
+            r &= calcXUVariableAux(&ct, mp, k, &C.o);
             if(!cost_only) r &= ddpf(xnext, &ct, k, C.o.p, N);
             r &= ddpL(&ct, k, &C.o);
             return r;
@@ -1211,6 +1286,16 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
     // final cost (iLQG_func.tem:179-182); q.x now points at step N
     {
         trajFin_t cf;
+        multipliersFin_t mf;
+        if(HAS_MUL) {
+            if(KIND == RK_INIT) {
+                init_multipliers_final(&C.o);
+                mf = C.o.multipliers.f;
+                store_mul_fin(P, b, mf);
+            } else {
+                load_mul_fin(P, b, mf);
+            }
+        }
         init_final(&cf, &C.o);
         double xin[NX];
 #pragma unroll
@@ -1220,7 +1305,7 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
         auto fin = [&]() {
 #pragma unroll
             for(int i = 0; i < NX; i++) cf.x[i] = xin[i];
-            int r = calcFVariableAux(&cf, nullptr, &C.o);
+            int r = calcFVariableAux(&cf, HAS_MUL ? &mf : nullptr, &C.o);
             r &= ddpF(&cf, &C.o);
             return r;
         };
@@ -1304,6 +1389,7 @@ __global__ void k_update(DevPtrs P, ilqg_dev_opts_t O) {
     double lambda = P.f[ILQG_F_LAMBDA][b], dlambda = P.f[ILQG_F_DLAMBDA][b];
     int iter = P.i[ILQG_I_ITER][b];
     int status = ILQG_ST_ACTIVE;
+    int resweep = 0;
     if(P.i[ILQG_I_ACCEPTED][b]) {
         const double t1 = dlambda / O.lambdaFactor, t2 = 1.0 / O.lambdaFactor;
         dlambda = (t1 < t2) ? t1 : t2;
@@ -1311,7 +1397,14 @@ __global__ void k_update(DevPtrs P, ilqg_dev_opts_t O) {
         P.f[ILQG_F_COST][b] = P.f[ILQG_F_NEW_COST][b];
         P.i[ILQG_I_NEED_DERIVS][b] = 1;
         if(P.f[ILQG_F_DCOST][b] < O.tolFun) status = ILQG_ST_CONVERGED_FUN;
+        else resweep = 2;  // update_multipliers + cost-only sweep (iLQG.c:337-338)
     } else {
+        if(HAS_MUL && O.w_pen_fact2 > 1.0) {  // iLQG.c:345-349, before the lambdaMax exit
+            const double wl = P.f[ILQG_F_WPEN_L][b] * O.w_pen_fact2, wf = P.f[ILQG_F_WPEN_F][b] * O.w_pen_fact2;
+            P.f[ILQG_F_WPEN_L][b] = (O.w_pen_max_l < wl) ? O.w_pen_max_l : wl;
+            P.f[ILQG_F_WPEN_F][b] = (O.w_pen_max_f < wf) ? O.w_pen_max_f : wf;
+            resweep = 1;
+        }
         const double t1 = dlambda * O.lambdaFactor;
         dlambda = (t1 > O.lambdaFactor) ? t1 : O.lambdaFactor;
         const double t2 = lambda * dlambda;
@@ -1326,6 +1419,88 @@ __global__ void k_update(DevPtrs P, ilqg_dev_opts_t O) {
     P.f[ILQG_F_DLAMBDA][b] = dlambda;
     P.i[ILQG_I_ITER][b] = iter;
     P.i[ILQG_I_STATUS][b] = status;
+    // without multipliers the sweep reproduces the cost bit for bit: only where the solve goes on (option resweep)
+    if(!HAS_MUL && status != ILQG_ST_ACTIVE) resweep = 0;
+    P.i[ILQG_I_RESWEEP][b] = resweep;
+}
+
+// update_multipliers (iLQG_func.tem:419-521) for the trajectories k_update flagged, or with init != 0 at the solver
+// entry (iLQG.c:236) for all live ones.  The generated functions walk o->nominal->t and o->multipliers.t over
+// o->n_hor elements; here they see a one-element view per time step (the constraint values they read are the
+// auxiliaries of that element, recomputed from the stored (x, u) with the multipliers and weights of the roll-out
+// that stored them).  What they do across steps is restated around the calls: one raise of w_pen_l after the
+// walk if any step asked for it; with init != 0 the running part returns inside its loop after the first element
+// (iLQG_func.tem:447), so only step 0 is visited.
+__global__ __launch_bounds__(WAVE) void k_multipliers(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int init) {
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if(b >= P.B) return;
+    if(init) {
+        if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE && P.i[ILQG_I_STATUS][b] != ILQG_ST_MAX_ITER) return;
+    } else if(P.i[ILQG_I_RESWEEP][b] != 2) {
+        return;
+    }
+    const int N = P.N;
+    ILQG_CALLBACKS(C, H);
+    load_penalty_weights(C, P, b);
+    const double wl = C.o.w_pen_l;
+    traj_t view;
+    trajEl_t ct;
+    multipliersEl_t mk;
+    init_running(&ct, &C.o1);
+    view.t = &ct;
+    C.o.nominal = C.o1.nominal = &view;
+    C.o1.multipliers.t = &mk;
+    bool raise = false;
+    if(ME > 0) {
+        const int steps = init ? 1 : N;
+        for(int k = 0; k < steps; k++) {
+            const double *xs = cur_x(P, k, b), *us = cur_u(P, k, b);
+            load_mul(P, k, b, mk);
+            H.huge = 0.0;
+            auto aux = [&]() {
+#pragma unroll
+                for(int i = 0; i < NX; i++) ct.x[i] = xs[i * XSI];
+#pragma unroll
+                for(int i = 0; i < NU; i++) ct.u[i] = us[i * XSI];
+                calcXVariableAux(&ct, &mk, k, &C.o);
+                calcXUVariableAux(&ct, &mk, k, &C.o);
+            };
+            aux();
+            if(H.huge != 0.0) {
+                H.slow = 1.0;
+                aux();
+                H.slow = 0.0;
+            }
+            C.o1.w_pen_l = wl;
+            update_multipliers_running(&C.o1, init);
+            raise |= (C.o1.w_pen_l != wl);
+            store_mul(P, k, b, mk);
+        }
+    }
+    if(MF > 0) {
+        const double *xs = cur_x(P, N, b);
+        load_mul_fin(P, b, C.o.multipliers.f);
+        init_final(&view.f, &C.o);
+        H.huge = 0.0;
+        auto aux = [&]() {
+#pragma unroll
+            for(int i = 0; i < NX; i++) view.f.x[i] = xs[i * XSI];
+            calcFVariableAux(&view.f, &C.o.multipliers.f, &C.o);
+        };
+        aux();
+        if(H.huge != 0.0) {
+            H.slow = 1.0;
+            aux();
+            H.slow = 0.0;
+        }
+        update_multipliers_final(&C.o, init);
+        store_mul_fin(P, b, C.o.multipliers.f);
+        P.f[ILQG_F_WPEN_F][b] = C.o.w_pen_f;
+    }
+    if(raise) {
+        const double w = wl * O.w_pen_fact1;
+        P.f[ILQG_F_WPEN_L][b] = (O.w_pen_max_l < w) ? O.w_pen_max_l : w;
+    }
 }
 
 // solver entry state (iLQG.c:226-237)
@@ -1340,6 +1515,9 @@ __global__ void k_reset(DevPtrs P, ilqg_dev_opts_t O) {
     P.i[ILQG_I_ACCEPTED][b] = 0;
     P.i[ILQG_I_BP_CALLS][b] = 0;
     P.derivs_failed[b] = 0;
+    P.i[ILQG_I_RESWEEP][b] = 0;
+    P.f[ILQG_F_WPEN_L][b] = O.w_pen_init_l;
+    P.f[ILQG_F_WPEN_F][b] = O.w_pen_init_f;
     if(live) P.i[ILQG_I_STATUS][b] = (O.max_iter > 0) ? ILQG_ST_ACTIVE : ILQG_ST_MAX_ITER;
 }
 
@@ -1481,6 +1659,8 @@ FieldInfo field_info(int f) {
         case ILQG_F_KG: return {0, NXU, NXU};
         case ILQG_F_DER: return {0, WAVE_MAP ? REC_HOST : REC, REC_HOST};
         case ILQG_F_FIN: return {-1, FIN, FIN};
+        case ILQG_F_MUL: return {0, MEW, MEW};
+        case ILQG_F_MULF: return {-1, MFW, MFW};
         case ILQG_F_ALPHA_COST: return {-1, ILQG_MAX_ALPHA, ILQG_MAX_ALPHA};
         default: return {-1, 1, 1};
     }
@@ -1568,6 +1748,11 @@ int ilqg_dev_count(void) {
     return n;
 }
 
+void ilqg_dev_multiplier_dims(int *out) {
+    out[0] = ME;
+    out[1] = MF;
+}
+
 void ilqg_dev_dims(int *out) {
     out[0] = NX;
     out[1] = NU;
@@ -1582,7 +1767,8 @@ void ilqg_dev_dims(int *out) {
 const char *ilqg_dev_kernel_name(int k) {
     static const char *names[ILQG_K_COUNT] = {"k_derivs", "k_backward", "k_rollout[search]", "k_select",
                                               "k_rollout[winner]", "k_update", "k_rollout[cost]", "k_rollout[init]",
-                                              "layout kernels", "k_backward[fused derivs]", "k_rollout[search stage 2]"};
+                                              "layout kernels", "k_backward[fused derivs]", "k_rollout[search stage 2]",
+                                              "k_multipliers"};
     return (k >= 0 && k < ILQG_K_COUNT) ? names[k] : "?";
 }
 
@@ -1916,6 +2102,11 @@ int ilqg_dev_read_int(ilqg_dev_t *d, int field, int *host) {
 int ilqg_dev_reset(ilqg_dev_t *d) {
     HIP_TRY(hipSetDevice(d->device));
     hipLaunchKernelGGL(k_reset, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O);
+    if(HAS_MUL) {  // update_multipliers(o, 1) of the solver entry (iLQG.c:236)
+        NEED_PARAMS(d);
+        Timed t(d, ILQG_K_MULTIPLIERS);
+        hipLaunchKernelGGL(k_multipliers, dim3(d->Bp / WAVE), dim3(WAVE), 0, d->stream, d->P, d->O, d->pv, 1);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1992,6 +2183,12 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
         return 1;
     }
     if(mode == 2) NEED_PARAMS(d);
+    if(mode == 2 && HAS_MUL) {
+        // a rejected step may raise the penalty weights while the derivatives stay those of the last accepted
+        // trajectory (iLQG.c:345-349): they have to be kept, not re-evaluated
+        g_err = "ilqg_dev_backward: problems with multipliers keep their derivative records (modes 0 and 1)";
+        return 1;
+    }
 #if ILQG_WAVE_MAP
     if(mode != 2 && d->B > d->chunk) {
         g_err = "ilqg_dev_backward: stored records need the whole batch in the work buffer; use mode 2";
@@ -2058,14 +2255,18 @@ int ilqg_dev_update(ilqg_dev_t *d) {
         Timed t(d, ILQG_K_UPDATE);
         hipLaunchKernelGGL(k_update, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O);
     }
-    if(d->O.resweep) launch_rollout(d, ROLL_COST, ILQG_K_ROLLOUT_COST, 0, 1);
+    if(HAS_MUL) {
+        Timed t(d, ILQG_K_MULTIPLIERS);
+        hipLaunchKernelGGL(k_multipliers, dim3(d->Bp / WAVE), dim3(WAVE), 0, d->stream, d->P, d->O, d->pv, 0);
+    }
+    if(d->O.resweep || HAS_MUL) launch_rollout(d, ROLL_COST, ILQG_K_ROLLOUT_COST, 0, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int ilqg_dev_iterate(ilqg_dev_t *d, int n) {
     for(int it = 0; it < n; it++) {
-        if(d->O.fuse_derivs || WAVE_MAP) {  // wave mapping: derivatives + sweep chunk by chunk
+        if((d->O.fuse_derivs && !HAS_MUL) || WAVE_MAP) {  // wave mapping: derivatives + sweep chunk by chunk
             if(ilqg_dev_backward(d, 2)) return 1;
         } else {
             if(ilqg_dev_derivs(d)) return 1;

@@ -55,6 +55,8 @@ enum {
     ILQG_F_KG,       /* [N][N_U*N_X] feedback gains L (column-major)    */
     ILQG_F_DER,      /* [N][host record] derivative records             */
     ILQG_F_FIN,      /* [N_X+sizeofQxx] final cx, cxx                   */
+    ILQG_F_MUL,      /* [N][multipliersEl_t as doubles] running multipliers (problems with hle / hli) */
+    ILQG_F_MULF,     /* [multipliersFin_t as doubles]   final multipliers (problems with hfe / hfi)   */
     ILQG_F_COST,     /* scalars per trajectory from here on             */
     ILQG_F_NEW_COST,
     ILQG_F_DCOST,
@@ -64,6 +66,8 @@ enum {
     ILQG_F_GNORM,
     ILQG_F_DV0,
     ILQG_F_DV1,
+    ILQG_F_WPEN_L,   /* current penalty weights o->w_pen_l / o->w_pen_f (iLQG.h:78) */
+    ILQG_F_WPEN_F,
     ILQG_F_ALPHA_COST, /* [n_alpha] cost of every step size of the last line search */
     ILQG_F_COUNT
 };
@@ -77,6 +81,8 @@ enum {
     ILQG_I_ACCEPTED,
     ILQG_I_BP_CALLS,    /* backward sweeps in the last iteration         */
     ILQG_I_BP_RC,       /* result of the last backward sweep: 0 ok, 1 failed */
+    ILQG_I_RESWEEP,     /* set by the update: 2 = update multipliers + cost sweep (iLQG.c:337-338), 1 = cost
+                         * sweep after a rejected step raised the penalty weights (iLQG.c:345-349), 0 = none */
     ILQG_I_ALPHA_OK,    /* [n_alpha] forward pass finite?                */
     ILQG_I_COUNT
 };
@@ -94,6 +100,7 @@ enum {
     ILQG_K_TRANSPOSE,
     ILQG_K_BACKWARD_FUSED,
     ILQG_K_ROLLOUT_SEARCH2,
+    ILQG_K_MULTIPLIERS,
     ILQG_K_COUNT
 };
 
@@ -107,6 +114,8 @@ void ilqg_dev_destroy(ilqg_dev_t *d);
  * out[0..7] = N_X, N_U, FULL_DDP, host record size, device record size, state-dependent limits, n_params,
  * mapping (0 = one lane per trajectory, 1 = one wavefront per trajectory) */
 void ilqg_dev_dims(int *out);
+/* out[0..1] = doubles in multipliersEl_t / multipliersFin_t (0 for a problem without such constraints) */
+void ilqg_dev_multiplier_dims(int *out);
 
 int ilqg_dev_set_params(ilqg_dev_t *d, int n_params, const int *sizes, const double *const *values);
 int ilqg_dev_set_opts(ilqg_dev_t *d, const ilqg_dev_opts_t *o);

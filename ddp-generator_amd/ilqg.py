@@ -80,6 +80,9 @@ def load_library(problem="carparking", full_ddp=0, strict=False):
     lib.ilqg_batch_get_gains.argtypes = [v, _dp, _dp]
     lib.ilqg_batch_set_gains.argtypes = [v, _dp, _dp]
     lib.ilqg_batch_get_derivs.argtypes = [v, _dp, _dp]
+    lib.ilqg_problem_multiplier_dims.argtypes = [_ip]
+    lib.ilqg_batch_get_multipliers.argtypes = [v, _dp, _dp]
+    lib.ilqg_batch_set_multipliers.argtypes = [v, _dp, _dp]
     lib.ilqg_batch_set_derivs.argtypes = [v, _dp, _dp]
     lib.ilqg_batch_get_scalar.argtypes = [v, C.c_char_p, _dp]
     lib.ilqg_batch_set_scalar.argtypes = [v, C.c_char_p, _dp]
@@ -236,6 +239,25 @@ class BatchSolver:
         rec = np.ascontiguousarray(rec, dtype=np.float64).reshape(self.B, self.N, self.problem.rec_host)
         fin = np.ascontiguousarray(fin, dtype=np.float64).reshape(self.B, self.problem.nx + self.problem.sxx)
         self._ck(self.lib.ilqg_batch_set_derivs(self.h, rec, fin))
+
+    def multiplier_dims(self):
+        d = np.zeros(2, dtype=np.int32)
+        self.lib.ilqg_problem_multiplier_dims(d)
+        return int(d[0]), int(d[1])
+
+    def multipliers(self):
+        """(running [B, N, el], final [B, fin]): multipliersEl_t / multipliersFin_t member by member"""
+        me, mf = self.multiplier_dims()
+        run = np.zeros((self.B, self.N, max(me, 1)))
+        fin = np.zeros((self.B, max(mf, 1)))
+        self._ck(self.lib.ilqg_batch_get_multipliers(self.h, run, fin))
+        return run[:, :, :me], fin[:, :mf]
+
+    def set_multipliers(self, running, final):
+        me, mf = self.multiplier_dims()
+        run = np.ascontiguousarray(running, dtype=np.float64).reshape(self.B, self.N, max(me, 1))
+        fin = np.ascontiguousarray(final, dtype=np.float64).reshape(self.B, max(mf, 1))
+        self._ck(self.lib.ilqg_batch_set_multipliers(self.h, run, fin))
 
     def scalar(self, name):
         w = MAX_ALPHA if name == "alpha_cost" else 1

@@ -101,6 +101,14 @@ int ilqg_batch_get_x(ilqg_batch_t *c, double *x);
 int ilqg_batch_get_u(ilqg_batch_t *c, double *u);
 int ilqg_batch_get_gains(ilqg_batch_t *c, double *l, double *L);
 int ilqg_batch_get_derivs(ilqg_batch_t *c, double *rec /* [B][n_hor][record] */, double *fin /* [B][N_X+sizeofQxx] */);
+/* Augmented-Lagrangian multipliers of problems with hle / hli / hfe / hfi constraints (reference
+ * iLQG_problem.tem:70-89, iLQG_func.tem:371-521): out[0..1] = doubles in multipliersEl_t / multipliersFin_t
+ * (0, 0 for a problem without such constraints).  The arrays hold the structs member by member:
+ * running [B][n_hor][out[0]], final [B][out[1]]; either pointer may be NULL.  The current penalty weights
+ * are the per-trajectory scalars "w_pen_l" / "w_pen_f" of ilqg_batch_get_scalar. */
+void ilqg_problem_multiplier_dims(int *out);
+int ilqg_batch_get_multipliers(ilqg_batch_t *c, double *running, double *final);
+int ilqg_batch_set_multipliers(ilqg_batch_t *c, const double *running, const double *final);
 int ilqg_batch_set_derivs(ilqg_batch_t *c, const double *rec, const double *fin);
 int ilqg_batch_set_gains(ilqg_batch_t *c, const double *l, const double *L);
 /* name in: cost new_cost dcost expected lambda dlambda g_norm dV0 dV1 ([B] each),

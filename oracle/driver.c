@@ -302,6 +302,20 @@ void drv_get_scalars(drv_t *d, double *out) {
     out[8] = (double)d->o.iterations;
 }
 
+/* out[0..1] = doubles in multipliersEl_t / multipliersFin_t (0 for empty structs) */
+void drv_multiplier_dims(int *out) {
+    out[0] = (int)(sizeof(multipliersEl_t) / sizeof(double));
+    out[1] = (int)(sizeof(multipliersFin_t) / sizeof(double));
+}
+
+/* the multiplier structs member by member: el [n_hor][dims[0]], fin [dims[1]], w_pen = {w_pen_l, w_pen_f} */
+void drv_get_multipliers(drv_t *d, double *el, double *fin, double *w_pen) {
+    if(sizeof(multipliersEl_t) > 0) memcpy(el, d->o.multipliers.t, sizeof(multipliersEl_t) * d->n_hor);
+    if(sizeof(multipliersFin_t) > 0) memcpy(fin, &d->o.multipliers.f, sizeof(multipliersFin_t));
+    w_pen[0] = d->o.w_pen_l;
+    w_pen[1] = d->o.w_pen_f;
+}
+
 int drv_get_log_linesearch(drv_t *d, int iter) { return d->o.log_linesearch[iter]; }
 
 /* trace of the last drv_solve(): returns count; each array has room for `cap` */

@@ -59,6 +59,20 @@ def syn_inputs(batch, n_hor, first=0, seed=20261003):
     return m.synth16_batch(batch, n_hor, first, seed)
 
 
+# Brachistochrone with a terminal equality constraint, reference examples/Brachistochrone/testBrachi.m:7-25
+def brachi_case(n):
+    params = dict(g=[9.81], yf=[-4.0], dx=[2 * np.pi / n])
+    opts = dict(max_iter=20, w_pen_init_l=40.0, w_pen_init_f=40.0, w_pen_fact2=2.0)
+    return params, opts, np.array([-np.finfo(float).eps]), -np.ones((n, 1))
+
+
+# ... with a running inequality constraint, reference examples/Brachistochrone/testBrachi_hli.m:7-27
+def brachi_hli_case(n=500):
+    params = dict(g=[9.81], dx=[2 * np.pi / n], ymin=np.concatenate([np.linspace(-1.0, -5.0, n), [-4.0]]))
+    opts = dict(max_iter=20, w_pen_init_l=40.0, w_pen_init_f=1e-5, w_pen_max_f=1.0, w_pen_fact2=1.0)
+    return params, opts, np.array([-np.finfo(float).eps]), -np.ones((n, 1))
+
+
 def lib_path(kind, problem="carparking", full_ddp=0):
     """kind: 'ref' (reference sources) or 'oracle' (CPU restatement)"""
     if kind == "ref":
@@ -95,6 +109,9 @@ def _bind(lib):
     lib.drv_get_scalars.argtypes = [C.c_void_p, _dp]
     lib.drv_get_log_linesearch.argtypes = [C.c_void_p, C.c_int]
     lib.drv_get_trace.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
+    if hasattr(lib, "drv_get_multipliers"):
+        lib.drv_multiplier_dims.argtypes = [_ip]
+        lib.drv_get_multipliers.argtypes = [C.c_void_p, _dp, _dp, _dp]
     if hasattr(lib, "drv_solve_many"):
         lib.drv_solve_many.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _ip, _ip]
     return lib
@@ -212,6 +229,16 @@ class Driver:
         out = np.zeros(9)
         self.lib.drv_get_scalars(self.h, out)
         return dict(zip(self.SCALARS, out.tolist()))
+
+    def multipliers(self):
+        """(running [N, el], final [fin], (w_pen_l, w_pen_f)): the multiplier structs member by member"""
+        dims = np.zeros(2, dtype=np.int32)
+        self.lib.drv_multiplier_dims(dims)
+        el = np.zeros((self.N, max(int(dims[0]), 1)))
+        fin = np.zeros(max(int(dims[1]), 1))
+        w = np.zeros(2)
+        self.lib.drv_get_multipliers(self.h, el, fin, w)
+        return el[:, :dims[0]], fin[:dims[1]], (float(w[0]), float(w[1]))
 
     def log_linesearch(self, it=0):
         return self.lib.drv_get_log_linesearch(self.h, it)

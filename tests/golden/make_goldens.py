@@ -26,8 +26,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT as SYN_PARAMS, Driver, Kernels, hx_inputs, lib_path,  # noqa: E402
-                            syn_inputs)
+from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT as SYN_PARAMS, Driver, Kernels, brachi_case,  # noqa: E402
+                            brachi_hli_case, hx_inputs, lib_path, syn_inputs)
 
 spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "ddp-generator_amd", "synth.py"))
 synth = importlib.util.module_from_spec(spec)
@@ -362,8 +362,34 @@ def regtype2_goldens():
     print("regType 2: rc", out["fd0_rc"], out["fd1_rc"])
 
 
+def brachi_goldens():
+    """problems with augmented-Lagrangian multipliers: the reference's Brachistochrone demos
+    (examples/Brachistochrone/testBrachi.m, testBrachi_hli.m), full solves with every iteration's scalars,
+    final multipliers and penalty weights"""
+    out = {}
+    for tag, problem, case in (("fe5_", "brachi", brachi_case(5)), ("fe500_", "brachi", brachi_case(500)),
+                               ("li500_", "brachi_hli", brachi_hli_case(500))):
+        params, opts, x0, u0 = case
+        d = Driver(lib_path("ref", problem, 0), len(u0), params, opts)
+        assert d.init(x0, u0) == 1
+        out[tag + "init_cost"] = d.scalars()["cost"]
+        rc = d.solve()
+        x, u = d.traj(0)
+        el, fin, w = d.multipliers()
+        tr = d.trace()
+        out.update({tag + "rc": rc, tag + "x": x, tag + "u": u, tag + "mul": el, tag + "mul_fin": fin,
+                    tag + "w_pen": np.array(w), tag + "cost": d.scalars()["cost"],
+                    tag + "iterations": int(d.scalars()["iterations"])})
+        out.update({tag + "trace_" + k: v for k, v in tr.items()})
+        print("%s: rc %d, %d iterations, cost %.12g, y_N %.9g, w_pen %s" % (tag, rc, out[tag + "iterations"], out[tag + "cost"],
+                                                                           x[-1, 0], w))
+        d.close()
+    np.savez_compressed(os.path.join(HERE, "brachi.npz"), **out)
+
+
 def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    brachi_goldens()
     kernel_goldens(Kernels(lib_path("ref", full_ddp=0)))
     for fd in (0, 1):
         single_pass_goldens(fd)

@@ -1,0 +1,141 @@
+"""GPU parity tests of the augmented-Lagrangian path: problems with hfe / hli constraints (the reference's
+Brachistochrone demos, examples/Brachistochrone/) through the batch C-ABI against the golden fixtures recorded
+from the reference and against the CPU oracle.
+
+The Brachistochrone callbacks use nothing but +, -, *, / and sqrt, all IEEE-exact on the device, so the
+-ffp-contract=off build must reproduce the reference BIT FOR BIT over a whole solve, multipliers and penalty
+weights included; the product build (FMA contraction) is held to the tolerances of test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle.harness import Driver, brachi_case, brachi_hli_case, lib_path
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("fe5_", "brachi", brachi_case(5)), ("fe500_", "brachi", brachi_case(500)),
+         ("li500_", "brachi_hli", brachi_hli_case(500))]
+
+
+def close(a, b, tol=1e-10):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return bool(np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def ilqg():
+    import __graft_entry__ as g
+    g.build()
+    from ddp_generator_amd import ilqg as m
+    if m.Problem("brachi", 0).device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")
+    return m
+
+
+def solver(ilqg, problem, case, batch=1, strict=False, **extra):
+    params, opts, x0, u0 = case
+    s = ilqg.BatchSolver(problem, 0, batch=batch, n_hor=len(u0), params=params, opts=dict(opts, **extra), strict=strict)
+    return s
+
+
+@pytest.mark.parametrize("tag,problem,case", CASES)
+def test_solve_bit_exact_without_fma(ilqg, tag, problem, case):
+    g = golden("brachi.npz")
+    _, opts, x0, u0 = case
+    s = solver(ilqg, problem, case, strict=True)
+    assert s.multiplier_dims() == (g[tag + "mul"].shape[1], g[tag + "mul_fin"].shape[0])
+    s.init(x0[None], u0[None])
+    assert s.scalar("cost")[0] == g[tag + "init_cost"]  # rolled out with zero penalty weights (iLQG_mex.c:23,116)
+    its = int(g[tag + "iterations"])
+    for it in range(its):
+        s.iterate(1)
+        # the trace holds the state at the end of the line search of every iteration
+        assert s.scalar("new_cost")[0] == g[tag + "trace_new_cost"][it], it
+        assert s.ints("alpha_idx")[0] == g[tag + "trace_alpha_idx"][it], it
+        assert s.scalar("g_norm")[0] == g[tag + "trace_g_norm"][it], it
+    assert s.ints("iterations")[0] == its
+    assert s.success()[0] == bool(g[tag + "rc"])
+    assert s.scalar("cost")[0] == g[tag + "cost"]
+    assert np.array_equal(s.x()[0], g[tag + "x"]) and np.array_equal(s.u()[0], g[tag + "u"])
+    run, fin = s.multipliers()
+    assert np.array_equal(run[0], g[tag + "mul"]) and np.array_equal(fin[0], g[tag + "mul_fin"])
+    assert s.scalar("w_pen_l")[0] == g[tag + "w_pen"][0] and s.scalar("w_pen_f")[0] == g[tag + "w_pen"][1]
+    s.close()
+
+
+@pytest.mark.parametrize("tag,problem,case", CASES)
+def test_solve_product_build(ilqg, tag, problem, case):
+    g = golden("brachi.npz")
+    _, opts, x0, u0 = case
+    s = solver(ilqg, problem, case)
+    s.init(x0[None], u0[None])
+    assert close(s.scalar("cost")[0], g[tag + "init_cost"])
+    s.solve()
+    assert s.ints("iterations")[0] == int(g[tag + "iterations"])
+    assert s.success()[0] == bool(g[tag + "rc"])
+    assert close(s.scalar("cost")[0], g[tag + "cost"], 1e-6)
+    assert np.abs(s.x()[0] - g[tag + "x"]).max() < 1e-4
+    assert s.scalar("w_pen_l")[0] == g[tag + "w_pen"][0] and s.scalar("w_pen_f")[0] == g[tag + "w_pen"][1]
+    run, fin = s.multipliers()
+    assert close(fin[0], g[tag + "mul_fin"], 1e-5)
+    s.close()
+
+
+def test_batch_of_different_starts_against_the_oracle(ilqg, oracle_built):
+    """every trajectory carries its own multipliers and penalty weights: a batch that spans several wavefronts,
+    solved in lock step (strict build: bitwise) against one oracle solve per trajectory"""
+    B, n = 150, 60
+    params, opts, x0, u0 = brachi_hli_case(n)
+    rng = np.random.default_rng(11)
+    x0s = -10.0 ** rng.uniform(-16, -1, (B, 1))
+    u0s = -np.ones((B, n, 1)) * rng.uniform(0.3, 2.0, (B, 1, 1)) + 0.05 * rng.standard_normal((B, n, 1))
+    s = ilqg.BatchSolver("brachi_hli", 0, batch=B, n_hor=n, params=params, opts=opts, strict=True)
+    s.init(x0s, u0s)
+    s.solve()
+    cost, iters, ok = s.scalar("cost"), s.ints("iterations"), s.success()
+    x, (run, fin), wl, wf = s.x(), s.multipliers(), s.scalar("w_pen_l"), s.scalar("w_pen_f")
+    s.close()
+    seen = set()
+    for b in range(B):
+        d = Driver(lib_path("oracle", "brachi_hli", 0), n, params, opts)
+        assert d.init(x0s[b], u0s[b]) == 1
+        rc = d.solve()
+        el, fn, w = d.multipliers()
+        assert (rc == 1) == bool(ok[b]) and int(d.scalars()["iterations"]) == iters[b], b
+        assert d.scalars()["cost"] == cost[b], b
+        assert np.array_equal(d.traj(0)[0], x[b]), b
+        assert np.array_equal(el, run[b]) and np.array_equal(fn, fin[b]), b
+        assert (wl[b], wf[b]) == w, b
+        seen.add(w)
+        d.close()
+    assert len(seen) > 1  # the penalty-weight schedules differ between trajectories
+
+
+def test_dropin_line_search_uses_the_callers_multipliers(ilqg, oracle_built):
+    """the drop-in iLQG() of the product library (host loop + device back_pass / line_search) on a problem with
+    multipliers: same iterations and result as the oracle's"""
+    import ctypes as C
+    params, opts, x0, u0 = brachi_case(50)
+    out = []
+    for path in (lib_path("oracle", "brachi", 0), "hip"):
+        if path == "hip":
+            import os
+            path = os.path.join(os.path.dirname(lib_path("oracle")), "libdrv_brachi_fd0_hip.so")
+        d = Driver(path, 50, params, opts)
+        assert d.init(x0, u0) == 1
+        rc = d.solve()
+        out.append((rc, d.scalars(), d.traj(0)[0], d.multipliers()))
+        d.close()
+    a, b = out
+    assert a[0] == b[0] and a[1]["iterations"] == b[1]["iterations"]
+    assert close(b[1]["cost"], a[1]["cost"], 1e-6) and np.abs(a[2] - b[2]).max() < 1e-4
+    assert a[3][2] == b[3][2]  # penalty weights
+
+
+def test_fused_derivatives_are_refused(ilqg):
+    params, opts, x0, u0 = brachi_case(5)
+    s = solver(ilqg, "brachi", brachi_case(5))
+    s.init(x0[None], u0[None])
+    with pytest.raises(RuntimeError):
+        s.back_pass(fused=True)
+    s.close()

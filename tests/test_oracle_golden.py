@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver, Kernels, lib_path
+from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver, Kernels, brachi_case, brachi_hli_case,
+                            lib_path)
 
 
 @pytest.fixture(scope="module")
@@ -174,6 +175,29 @@ def test_regtype2_literal(oracle_built):
         l, L = d.gains()
         assert np.array_equal(l, g["fd%d_l" % fd]) and np.array_equal(L, g["fd%d_L" % fd])
         d.close()
+
+
+@pytest.mark.parametrize("tag,problem,case", [("fe5_", "brachi", brachi_case(5)), ("fe500_", "brachi", brachi_case(500)),
+                                              ("li500_", "brachi_hli", brachi_hli_case(500))])
+def test_multiplier_problems(oracle_built, tag, problem, case):
+    """augmented-Lagrangian path (update_multipliers, penalty-weight schedule, cost re-sweeps, iLQG.c:233-237,
+    337-349) on the reference's Brachistochrone demos: every iteration's scalars, the final trajectory,
+    multipliers and penalty weights"""
+    g = golden("brachi.npz")
+    params, opts, x0, u0 = case
+    d = Driver(lib_path("oracle", problem, 0), len(u0), params, opts)
+    assert d.init(x0, u0) == 1
+    assert d.scalars()["cost"] == g[tag + "init_cost"]
+    assert d.solve() == int(g[tag + "rc"])
+    x, u = d.traj(0)
+    el, fin, w = d.multipliers()
+    assert np.array_equal(x, g[tag + "x"]) and np.array_equal(u, g[tag + "u"])
+    assert np.array_equal(el, g[tag + "mul"]) and np.array_equal(fin, g[tag + "mul_fin"])
+    assert np.array_equal(np.array(w), g[tag + "w_pen"])
+    assert d.scalars()["cost"] == g[tag + "cost"] and int(d.scalars()["iterations"]) == int(g[tag + "iterations"])
+    for k, v in d.trace().items():
+        assert np.array_equal(v, g[tag + "trace_" + k]), k
+    d.close()
 
 
 def test_options_follow_reference_rules(oracle_built):
