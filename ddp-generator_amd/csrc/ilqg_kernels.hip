@@ -1385,7 +1385,11 @@ __global__ void k_select(DevPtrs P, ilqg_dev_opts_t O, int a0, int a1, int from_
 // iLQG.c:311-361 and the loop bookkeeping of iLQG.c:239,365-378
 __global__ void k_update(DevPtrs P, ilqg_dev_opts_t O) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
+    if(b >= P.B) return;
+    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) {  // finished, possibly in this iteration's backward pass
+        P.i[ILQG_I_RESWEEP][b] = 0;
+        return;
+    }
     double lambda = P.f[ILQG_F_LAMBDA][b], dlambda = P.f[ILQG_F_DLAMBDA][b];
     int iter = P.i[ILQG_I_ITER][b];
     int status = ILQG_ST_ACTIVE;

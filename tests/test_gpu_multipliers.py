@@ -53,6 +53,7 @@ def test_solve_bit_exact_without_fma(ilqg, tag, problem, case):
         assert s.scalar("new_cost")[0] == g[tag + "trace_new_cost"][it], it
         assert s.ints("alpha_idx")[0] == g[tag + "trace_alpha_idx"][it], it
         assert s.scalar("g_norm")[0] == g[tag + "trace_g_norm"][it], it
+    s.solve()  # the exit test that ends the solve (gradient test at the start of the next iteration, or none)
     assert s.ints("iterations")[0] == its
     assert s.success()[0] == bool(g[tag + "rc"])
     assert s.scalar("cost")[0] == g[tag + "cost"]
