@@ -979,8 +979,7 @@ __device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const Dev
 #else
     Prof *pf = nullptr;
 #endif
-    for(int k = N - 1; k >= 0; k--) {
-        if(pf) pf->probe(7);
+    auto fields = [&](int k) {
         const trajEl_t *t = P.work + (size_t)bw * N + k;
         StepFields<NX, NU> F;
         F.cx = t->cx; F.cxx = t->cxx; F.cu = t->cu; F.cuu = t->cuu; F.cxu = t->cxu;
@@ -993,9 +992,19 @@ __device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const Dev
         F.lower_sign = t->lower_sign; F.upper_sign = t->upper_sign;
         F.lower_hx = t->lower_hx; F.upper_hx = t->upper_hx;
         F.u = nomp(P, k, b) + NOM_U;
-        const int rc = back_step_wave<NX, NU, FULL, HX>(S, F, nomp(P, k, b) + NOM_L,
+        return F;
+    };
+    StepRegs<NX, NU, FULL> R;
+    StepFields<NX, NU> F = fields(N - 1);
+    load_step<NX, NU, FULL>(R, F);
+    drain_memory_ops();
+    for(int k = N - 1; k >= 0; k--) {
+        if(pf) pf->probe(7);
+        const StepFields<NX, NU> Fnext = fields(k > 0 ? k - 1 : 0);
+        const int rc = back_step_wave<NX, NU, FULL, HX>(S, R, F, Fnext, k > 0, nomp(P, k, b) + NOM_L,
                                                         nomp(P, k, b) + NOM_K, lambda, regType, dV0,
                                                         dV1, gsum, pf);
+        F = Fnext;
         if(rc < 1) return 1;
     }
 #ifdef ILQG_PROFILE_SECTIONS
@@ -1008,7 +1017,15 @@ __device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const Dev
 
 // back_pass + retry loop, one wavefront (= one block) per trajectory of the chunk.  single_sweep: 1 = the
 // drop-in back_pass() (caller owns the retry loop)
-__global__ __launch_bounds__(64, 1) void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep,
+#ifndef ILQG_WAVE_OCC
+#define ILQG_WAVE_OCC 1
+#endif
+#ifdef ILQG_WAVE_OCC_MAX
+#define ILQG_WAVE_ATTR __attribute__((amdgpu_waves_per_eu(ILQG_WAVE_OCC, ILQG_WAVE_OCC_MAX)))
+#else
+#define ILQG_WAVE_ATTR
+#endif
+__global__ __launch_bounds__(64, ILQG_WAVE_OCC) ILQG_WAVE_ATTR void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep,
                                                          int chunk_first, int chunk_count) {
     __shared__ WaveLds<NX, NU> S;
     const int bw = blockIdx.x;
@@ -1625,6 +1642,34 @@ __global__ __launch_bounds__(64, 1) void k_boxqp_test(int count, const double *H
     }
 #pragma unroll
     for(int i = 0; i < T; i++) invH[(size_t)t * T + i] = inv[i];
+}
+
+// unit-test kernel for box_qp_rows<M> (wave mapping): one problem per wavefront
+template <int M>
+__global__ __launch_bounds__(64) void k_boxqp_rows_test(int count, const double *H, const double *g, const double *lower,
+                                                        const double *upper, double *x, int *clamp, int *n_free, double *invH,
+                                                        int *rc) {
+    constexpr int T = tri(M);
+    __shared__ double sH[T], sl[M], sinv[T];
+    __shared__ int scl[M];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if(t >= count) return;
+    for(int i = lane; i < T; i += 64) sH[i] = H[(size_t)t * T + i];
+    if(lane < M) sl[lane] = x[(size_t)t * M + lane];
+    __syncthreads();
+    const int me = lane % M;
+    int nf;
+    const int r = box_qp_rows<M>(sH, g[(size_t)t * M + me], lower[(size_t)t * M + me], upper[(size_t)t * M + me], sl, scl, sinv, nf);
+    __syncthreads();
+    if(lane == 0) {
+        rc[t] = r;
+        n_free[t] = nf;
+    }
+    if(lane < M) {
+        x[(size_t)t * M + lane] = sl[lane];
+        clamp[t * M + lane] = scl[lane];
+    }
+    for(int i = lane; i < T; i += 64) invH[(size_t)t * T + i] = sinv[i];
 }
 
 }  // namespace
@@ -2372,8 +2417,8 @@ int ilqg_dev_sincos_batch(int device, int n, const double *x, double *s, double 
     return 0;
 }
 
-int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
-                         const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
+static int boxqp_batch(int rows, int device, int n, int count, const double *H, const double *g, const double *lower,
+                       const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
     if(n != 2 && n != 8 && n != NU) {
         g_err = "ilqg_dev_boxqp_batch: n must be 2, 8 or N_U";
         return 1;
@@ -2396,8 +2441,14 @@ int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const do
     HIP_TRY(hipMemcpy(dlo, lower, count * n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dup, upper, count * n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dx, x, count * n * 8, hipMemcpyHostToDevice));
-    const dim3 grid = grid1(count, 64), block(64);
-    if(n == 2)
+    const dim3 grid = rows ? dim3(count) : grid1(count, 64), block(64);
+    if(rows && n == 2)
+        hipLaunchKernelGGL(k_boxqp_rows_test<2>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
+    else if(rows && n == 8)
+        hipLaunchKernelGGL(k_boxqp_rows_test<8>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
+    else if(rows)
+        hipLaunchKernelGGL(k_boxqp_rows_test<NU>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
+    else if(n == 2)
         hipLaunchKernelGGL(k_boxqp_test<2>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
     else if(n == 8)
         hipLaunchKernelGGL(k_boxqp_test<8>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
@@ -2413,6 +2464,16 @@ int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const do
     hipFree(dH); hipFree(dinv); hipFree(dg); hipFree(dlo); hipFree(dup); hipFree(dx);
     hipFree(dcl); hipFree(dnf); hipFree(drc);
     return 0;
+}
+
+int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                         const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
+    return boxqp_batch(0, device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);
+}
+
+int ilqg_dev_boxqp_wave_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                              const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
+    return boxqp_batch(1, device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);
 }
 
 }  // extern "C"

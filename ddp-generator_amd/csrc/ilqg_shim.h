@@ -162,6 +162,10 @@ const char *ilqg_dev_kernel_name(int kernel);
 int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
                          const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
 
+/* the same for the wave mapping's cooperative form (one problem per wavefront, one lane per variable) */
+int ilqg_dev_boxqp_wave_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                              const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
+
 /* the reference's small dense helpers on the device (one problem): op 0 addMulVec, 1 addSquareTri, 2 addMul2Tri
  * (shape 0 = (N_X,N_U), 1 = (N_X,N_X), 2 = (N_U,N_X[,1])), 3 cholesky_tri, 4 cholesky_tri_inv (shape = n).
  * flag: 1 ok, 0 Cholesky pivot <= 0, -1 size not built */

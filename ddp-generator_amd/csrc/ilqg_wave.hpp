@@ -45,6 +45,187 @@ struct WaveLds {
     int clamp[NU];
 };
 
+// ---------------------------------------------------------------------------
+// boxQP.c:39-238 for the wave mapping, cooperative: lane i < M owns variable i — its x, g, limits, clamp flag,
+// row i of H and of the inverse, column i of the Cholesky factor — and lanes >= M mirror lane (lane mod M), so
+// every lane takes part in every broadcast.  (The first version solved the whole problem redundantly on every
+// lane: for M = 8 that is four packed M x M matrices per lane, 512 registers and one wavefront per SIMD.)
+//
+// Every scalar of the reference is computed by ONE expression tree in the reference's own operand order —
+// a row sum runs j = 0..M-1 on the row's lane with x[j] broadcast (v_readlane), a sum over the variables
+// (value, gradient norm, search'grad) runs i = 0..M-1 on broadcast operands, uniformly on all lanes — so
+// the results are those of box_qp_uniform bit for bit (asserted by a unit test on the reference's goldens).
+// Sums over a subset (free or clamped variables) skip the others through wave-uniform masks, as the
+// reference's loops do; where the reference's loop bounds depend on the row (Cholesky, inverse) the extra
+// terms are exact zeros.
+// Results: x -> S_l[i], flags -> S_clamp[i], inverse of the free Hessian (full-index form, packed) -> S_invH,
+// all in LDS, where the gain formula reads them.  Returns the reference's code, wave-uniform.
+// ---------------------------------------------------------------------------
+ILQG_DEV double lane_bcast(double v, int src) {  // src: wave-uniform lane number
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+template <int M>
+ILQG_DEV int box_qp_rows(const double *Hpacked /* LDS */, const double g, const double lower, const double upper,
+                         double *S_l, int *S_clamp, double *S_invH, int &n_free_out) {
+    static_assert(M <= 32, "one lane per variable, masks in 32 bits");
+    constexpr int T = tri(M);
+    const int lane = threadIdx.x & 63, me = lane % M;
+    const unsigned all = (M == 32) ? 0xffffffffu : ((1u << M) - 1u);
+    const int max_iter = 100;
+    const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+
+    double Hrow[M], invrow[M], Ucol[M];
+#pragma unroll
+    for(int j = 0; j < M; j++) {
+        Hrow[j] = Hpacked[sy(me, j)];
+        invrow[j] = 0.0;
+        Ucol[j] = 0.0;
+    }
+    double x = S_l[me];  // warm start
+    if(x > upper) x = upper;
+    if(x < lower) x = lower;
+    int clamp = 0;
+    for(int e = lane; e < T; e += 64) S_invH[e] = 0.0;
+    n_free_out = 0;
+
+    // value(y) = sum_i y_i (g_i + 0.5 (H y)_i), boxQP.c:17-37
+    auto qp_value_rows = [&](double y) {
+        double hx = 0.0;
+#pragma unroll
+        for(int j = 0; j < M; j++) hx += Hrow[j] * lane_bcast(y, j);
+        const double w = g + 0.5 * hx;
+        double v = 0.0;
+#pragma unroll
+        for(int i = 0; i < M; i++) v += lane_bcast(y, i) * lane_bcast(w, i);
+        return v;
+    };
+
+    double value = qp_value_rows(x), oldvalue = 0.0;
+    int rc = 1;  // max_iter iterations (boxQP.c:237)
+    for(int iter = 0; iter < max_iter; iter++) {
+        if(iter > 0 && (oldvalue - value) < min_rel_improve * fabs(oldvalue)) { rc = 4; break; }
+        oldvalue = value;
+
+        // gradient and clamped set (boxQP.c:101-124)
+        double hx = 0.0;
+#pragma unroll
+        for(int j = 0; j < M; j++) hx += Hrow[j] * lane_bcast(x, j);
+        const double grad = g + hx;
+        const int was = clamp;
+        if(x <= lower && grad > 0)
+            clamp = 1;
+        else if(x >= upper && grad < 0)
+            clamp = 2;
+        else
+            clamp = 0;
+        const unsigned cm = (unsigned)__ballot(clamp != 0) & all;               // clamped variables
+        const bool changed = ((unsigned)__ballot((!was) != (!clamp)) & all) != 0;
+        const int n_free = M - __popc(cm);
+        n_free_out = n_free;
+        if(cm == all) { rc = 6; break; }
+        double gnorm = 0.0;
+#pragma unroll
+        for(int i = 0; i < M; i++) {
+            const double gi = lane_bcast(grad, i);
+            if(!((cm >> i) & 1u)) gnorm += gi * gi;
+        }
+
+        if(iter == 0 || changed) {
+            // Cholesky of the Hessian with clamped rows and columns replaced by identity (boxQP.c:131-160,
+            // cholesky.c:6-27): lane i computes column i of U, row j in step j
+            bool pd = true;
+#pragma unroll
+            for(int j = 0; j < M; j++) {
+                double dot = 0.0;
+#pragma unroll
+                for(int k = 0; k < j; k++) dot += Ucol[k] * lane_bcast(Ucol[k], j);
+                const bool masked = clamp != 0 || ((cm >> j) & 1u);
+                const double a = masked ? ((me == j) ? 1.0 : 0.0) : Hrow[j];
+                const double sv = a - dot;
+                const double piv = lane_bcast(sv, j);
+                if(piv <= 0.0) pd = false;
+                const double d = sqrt(piv);
+                Ucol[j] = (me == j) ? d : ((me > j) ? 1.0 / d * sv : 0.0);
+            }
+            if(!pd) { rc = -1; break; }
+            // explicit inverse (cholesky.c:51-74): lane l solves U'U y = e_l; y[k] for k >= l is row l of the inverse
+            double y[M];
+#pragma unroll
+            for(int k = 0; k < M; k++) {
+                double v = (k == me) ? 1.0 : 0.0;
+#pragma unroll
+                for(int i = 0; i < k; i++) v -= y[i] * lane_bcast(Ucol[i], k);  // y[i] = 0 for i < l: exact zeros
+                y[k] = v / lane_bcast(Ucol[k], k);
+            }
+#pragma unroll
+            for(int k = M - 1; k >= 0; k--) {
+                double v = y[k];
+#pragma unroll
+                for(int i = k + 1; i < M; i++) v -= y[i] * lane_bcast(Ucol[k], i);
+                y[k] = v / lane_bcast(Ucol[k], k);
+            }
+            __syncthreads();
+            if(lane < M) {
+#pragma unroll
+                for(int k = 0; k < M; k++)
+                    if(k >= me) S_invH[ut(me, k)] = y[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for(int j = 0; j < M; j++) invrow[j] = S_invH[sy(me, j)];
+        }
+
+        if(gnorm < min_grad * min_grad) { rc = 5; break; }
+
+        // search(free) = -invH(free,free) (g + H x_clamped)(free) - x(free); search(clamped) = 0 (boxQP.c:170-196)
+        double hc = 0.0;
+#pragma unroll
+        for(int j = 0; j < M; j++) {
+            const double xj = lane_bcast(x, j);
+            if((cm >> j) & 1u) hc += Hrow[j] * xj;
+        }
+        const double gc = g + hc;
+        double sr = -x;
+#pragma unroll
+        for(int j = 0; j < M; j++) {
+            const double gj = lane_bcast(gc, j);
+            if(!((cm >> j) & 1u)) sr -= invrow[j] * gj;
+        }
+        const double search = clamp ? 0.0 : sr;
+
+        double sdotg = 0.0;
+#pragma unroll
+        for(int i = 0; i < M; i++) sdotg += lane_bcast(search, i) * lane_bcast(grad, i);
+        if(sdotg >= 0.0) { rc = -2; break; }
+
+        // Armijo line search (boxQP.c:203-228)
+        double step = 1.0, vc, xc;
+        bool tiny = false;
+        for(;;) {
+            xc = x + step * search;
+            if(xc > upper) xc = upper;
+            if(xc < lower) xc = lower;
+            vc = qp_value_rows(xc);
+            if(((vc - oldvalue) / (step * sdotg)) >= armijo) break;
+            step = step * step_dec;
+            if(step < min_step) { tiny = true; break; }
+        }
+        if(tiny) { rc = 2; break; }
+        x = xc;
+        value = vc;
+    }
+    __syncthreads();
+    if(lane < M) {
+        S_l[me] = x;
+        S_clamp[me] = clamp;
+    }
+    __syncthreads();
+    return rc;
+}
+
 // rec: this step's trajEl_t in global memory (fields read through the pointers below)
 template <int NX, int NU>
 struct StepFields {
@@ -52,32 +233,116 @@ struct StepFields {
     const double *lower_sign, *upper_sign, *lower_hx, *upper_hx, *u;
 };
 
-// One backward step on a wave.  S: LDS block of this wave; F: global fields of the step;
+// Everything a lane reads of a step's record, in registers.  With one wavefront per SIMD nothing else hides the
+// latency of a global load, and a step used to expose it about eight times (one load-then-use per section).  The
+// whole set is loaded in one go instead — for the NEXT step, as soon as the Q assembly of the current one has
+// consumed the registers — and is in flight during the box QP, the gains and the V update.
+template <int NX, int NU, bool FULL>
+struct StepRegs {
+    static constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
+    static constexpr int NFX = (NX * NX + 63) / 64, NFU = (NXU + 63) / 64, NC = (NU + NX + 63) / 64;
+    static constexpr int NJ = (NXU + 63) / 64, NQ = (SUU + SXX + 63) / 64;
+    double fx[NFX], fu[NFU], c1[NC];      // this lane's elements of fx, fu, (cu | cx)
+    double cxu[NJ], txu[NJ][FULL ? NX : 1];  // of cxu and the NX slices of fxu
+    double cq[NQ], tq[NQ][FULL ? NX : 1];    // of (cuu | cxx) and the NX slices of (fuu | fxx)
+    double lo, up;                        // limits of input (lane mod NU)
+    double u[NU];                         // nominal inputs (gradient norm)
+};
+
+template <int NX, int NU, bool FULL>
+__device__ __forceinline__ void load_step(StepRegs<NX, NU, FULL> &R, const StepFields<NX, NU> &F) {
+    using SR = StepRegs<NX, NU, FULL>;
+    constexpr int SXX = SR::SXX, SUU = SR::SUU, NXU = SR::NXU;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for(int a = 0; a < SR::NFX; a++) {
+        const int i = lane + 64 * a;
+        R.fx[a] = (i < NX * NX) ? F.fx[i] : 0.0;
+    }
+#pragma unroll
+    for(int a = 0; a < SR::NFU; a++) {
+        const int i = lane + 64 * a;
+        R.fu[a] = (i < NXU) ? F.fu[i] : 0.0;
+    }
+#pragma unroll
+    for(int a = 0; a < SR::NC; a++) {
+        const int c = lane + 64 * a;
+        R.c1[a] = (c < NU) ? F.cu[c] : ((c < NU + NX) ? F.cx[c - NU] : 0.0);
+    }
+#pragma unroll
+    for(int a = 0; a < SR::NJ; a++) {
+        const int j = lane + 64 * a;
+        R.cxu[a] = (j < NXU) ? F.cxu[j] : 0.0;
+        if(FULL) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) R.txu[a][i] = (j < NXU) ? F.fxu[j + i * NXU] : 0.0;
+        }
+    }
+#pragma unroll
+    for(int a = 0; a < SR::NQ; a++) {
+        const int o = lane + 64 * a;
+        const bool in = o < SUU + SXX, isxx = o >= SUU;
+        const int e = isxx ? o - SUU : o;
+        R.cq[a] = in ? (isxx ? F.cxx[e] : F.cuu[e]) : 0.0;
+        if(FULL) {
+            const double *ten = isxx ? F.fxx : F.fuu;
+            const int stride = isxx ? SXX : SUU;
+#pragma unroll
+            for(int i = 0; i < NX; i++) R.tq[a][i] = in ? ten[e + i * stride] : 0.0;
+        }
+    }
+    R.lo = F.lower[lane % NU];
+    R.up = F.upper[lane % NU];
+#pragma unroll
+    for(int i = 0; i < NU; i++) R.u[i] = F.u[i];
+}
+
+// One backward step on a wave.  S: LDS block of this wave; R: the step's record in registers (load_step);
+// F: global fields of the step (state-dependent limits only); Fnext: the step processed next, whose record is
+// loaded into R once R has been consumed (has_next = 0: none);
 // lout/Kout: where the step's gains go in global memory (trajectory-major).
 // Returns the box-QP code (wave-uniform); < 1 aborts the sweep.
 template <int NX, int NU, bool FULL, bool HX>
-__device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFields<NX, NU> &F, double *lout,
+__device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, StepRegs<NX, NU, FULL> &R, const StepFields<NX, NU> &F,
+                                              const StepFields<NX, NU> &Fnext, const bool has_next, double *lout,
                                               double *Kout, const double lambda, const int regType, double &dV0,
                                               double &dV1, double &gsum, Prof *pf = nullptr) {
+    using SR = StepRegs<NX, NU, FULL>;
     constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
     constexpr int LDX = NX + 1, LDU = NU + 1;  // padded leading dimensions of the LDS copies
     const int lane = threadIdx.x & 63;
 
     // stage fx, fu (read NX resp. NU times each) in LDS
-    for(int i = lane; i < NX * NX; i += 64) S.fx[(i % NX) + (i / NX) * LDX] = F.fx[i];
-    for(int i = lane; i < NXU; i += 64) S.fu[(i % NX) + (i / NX) * LDX] = F.fu[i];
+#pragma unroll
+    for(int a = 0; a < SR::NFX; a++) {
+        const int i = lane + 64 * a;
+        if(i < NX * NX) S.fx[(i % NX) + (i / NX) * LDX] = R.fx[a];
+    }
+#pragma unroll
+    for(int a = 0; a < SR::NFU; a++) {
+        const int i = lane + 64 * a;
+        if(i < NXU) S.fu[(i % NX) + (i / NX) * LDX] = R.fu[a];
+    }
+    // what the later sections need of this step's record
+    const double lo_k = R.lo, up_k = R.up;
+    double u_k[NU];
+#pragma unroll
+    for(int i = 0; i < NU; i++) u_k[i] = R.u[i];
     __syncthreads();
 
     // Qu = cu + fu'Vx ; Qx = cx + fx'Vx   (addMulVec, matMult.c:3-12)
-    for(int c = lane; c < NU + NX; c += 64) {
+#pragma unroll
+    for(int a = 0; a < SR::NC; a++) {
+        const int c = lane + 64 * a;
+        if(c >= NU + NX) continue;
         if(c < NU) {
-            double acc = F.cu[c];
+            double acc = R.c1[a];
             #pragma unroll
             for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fu[r + c * LDX];
             S.Qu[c] = acc;
         } else {
             const int cc = c - NU;
-            double acc = F.cx[cc];
+            double acc = R.c1[a];
             #pragma unroll
             for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fx[r + cc * LDX];
             S.Qx[cc] = acc;
@@ -98,22 +363,28 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
 
     if(pf) pf->probe(0);
     // Qxu = cxu + fx' T2 (+ sum_i Vx_i fxu_i)        (back_pass.c:90-102)
-    for(int j = lane; j < NXU; j += 64) {
+#pragma unroll
+    for(int a = 0; a < SR::NJ; a++) {
+        const int j = lane + 64 * a;
+        if(j >= NXU) continue;
         const int r = j % NX, q = j / NX;
         double d = 0.0;
         #pragma unroll
         for(int s = 0; s < NX; s++) d += S.fx[s + r * LDX] * S.T2[s + q * LDX];
-        double v = F.cxu[j] + d;
+        double v = R.cxu[a] + d;
         if(FULL) {
             double d1 = 0.0;
             #pragma unroll
-            for(int i = 0; i < NX; i++) d1 += S.Vx[i] * F.fxu[j + i * NXU];
+            for(int i = 0; i < NX; i++) d1 += S.Vx[i] * R.txu[a][i];
             v += d1;
         }
         S.Qxu[j] = v;
     }
     // Quu = cuu + fu' T2 symmetrised (+ sum_i Vx_i fuu_i) ; Qxx likewise with fx, T1   (back_pass.c:104-131)
-    for(int o = lane; o < SUU + SXX; o += 64) {
+#pragma unroll
+    for(int a = 0; a < SR::NQ; a++) {
+        const int o = lane + 64 * a;
+        if(o >= SUU + SXX) continue;
         const bool isxx = o >= SUU;
         const int e = isxx ? o - SUU : o;
         int r, c;
@@ -128,17 +399,17 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             for(int s = 0; s < NX; s++) acc += A[s + c * LDX] * T[s + r * LDX];
             acc *= 0.5;
         }
-        double v = (isxx ? F.cxx[e] : F.cuu[e]) + acc;
+        double v = R.cq[a] + acc;
         if(FULL) {
-            const double *ten = isxx ? F.fxx : F.fuu;
-            const int stride = isxx ? SXX : SUU;
             double d1 = 0.0;
             #pragma unroll
-            for(int i = 0; i < NX; i++) d1 += S.Vx[i] * ten[e + i * stride];
+            for(int i = 0; i < NX; i++) d1 += S.Vx[i] * R.tq[a][i];
             v += d1;
         }
         (isxx ? S.Qxx : S.Quu)[e] = v;
     }
+    // R has been consumed: the next step's record into the same registers, in flight from here on
+    if(has_next) load_step<NX, NU, FULL>(R, Fnext);
     __syncthreads();
 
     if(pf) pf->probe(1);
@@ -170,33 +441,9 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     __syncthreads();
 
     if(pf) pf->probe(2);
-    // box QP, redundantly on every lane (wave-uniform data)
-    int rc;
-    {
-        double H[SUU], g[NU], lo[NU], up[NU], x[NU], inv[SUU];
-        int cl[NU], nf;
-#pragma unroll
-        for(int i = 0; i < SUU; i++) H[i] = S.QuuF[i];
-        #pragma unroll
-        for(int i = 0; i < NU; i++) {
-            g[i] = S.Qu[i];
-            lo[i] = F.lower[i];
-            up[i] = F.upper[i];
-            x[i] = S.l[i];  // warm start: the later step's solution (back_pass.c:163-166)
-        }
-        rc = box_qp_uniform<NU>(H, g, lo, up, x, cl, nf, inv);
-        __syncthreads();
-        if(lane == 0) {
-            #pragma unroll
-            for(int i = 0; i < NU; i++) {
-                S.l[i] = x[i];
-                S.clamp[i] = cl[i];
-            }
-#pragma unroll
-            for(int i = 0; i < SUU; i++) S.invH[i] = inv[i];
-        }
-        __syncthreads();
-    }
+    // box QP, one lane per input (box_qp_rows); warm start: the later step's solution in S.l (back_pass.c:163-166)
+    int rc, nf;
+    rc = box_qp_rows<NU>(S.QuuF, S.Qu[lane % NU], lo_k, up_k, S.l, S.clamp, S.invH, nf);
     if(pf) pf->probe(3);
     if(rc < 1) return rc;
 
@@ -306,7 +553,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     double gmax = 0.0;
     #pragma unroll
     for(int i = 0; i < NU; i++) {
-        const double gi = fabs(S.l[i]) / (fabs(F.u[i]) + 1.0);
+        const double gi = fabs(S.l[i]) / (fabs(u_k[i]) + 1.0);
         if(gi > gmax) gmax = gi;
     }
     gsum += gmax;

@@ -97,6 +97,7 @@ def load_library(problem="carparking", full_ddp=0, strict=False):
     lib.ilqg_batch_kernel_name.argtypes = [C.c_int]
     lib.ilqg_batch_get_timing.argtypes = [v, C.c_int, _ip, _dp]
     lib.ilqg_boxqp_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _ip]
+    lib.ilqg_boxqp_wave_batch.argtypes = lib.ilqg_boxqp_batch.argtypes
     lib.ilqg_sincos_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
     _libs[path] = lib
     return lib
@@ -311,8 +312,9 @@ class BatchSolver:
         return out
 
 
-def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, device=0, strict=False):
-    """device box-QP on `count` independent problems (arrays [count, ...]); unit-test entry"""
+def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, device=0, strict=False, cooperative=False):
+    """device box-QP on `count` independent problems (arrays [count, ...]); unit-test entry.
+    cooperative: the form of the one-wavefront-per-trajectory mapping (one lane per variable)"""
     lib = load_library(problem, full_ddp, strict)
     H = np.ascontiguousarray(H, dtype=np.float64)
     count = H.shape[0]
@@ -322,9 +324,10 @@ def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, dev
     nfree = np.zeros(count, dtype=np.int32)
     invH = np.zeros((count, t))
     rc = np.zeros(count, dtype=np.int32)
-    r = lib.ilqg_boxqp_batch(device, n, count, H.reshape(count, t), np.ascontiguousarray(g, dtype=np.float64),
-                             np.ascontiguousarray(lower, dtype=np.float64), np.ascontiguousarray(upper, dtype=np.float64),
-                             x, clamp, nfree, invH, rc)
+    fn = lib.ilqg_boxqp_wave_batch if cooperative else lib.ilqg_boxqp_batch
+    r = fn(device, n, count, H.reshape(count, t), np.ascontiguousarray(g, dtype=np.float64),
+           np.ascontiguousarray(lower, dtype=np.float64), np.ascontiguousarray(upper, dtype=np.float64),
+           x, clamp, nfree, invH, rc)
     if r:
         raise IlqgError("ilqg_boxqp_batch failed")
     return dict(rc=rc, x=x, clamp=clamp, n_free=nfree, invH=invH)

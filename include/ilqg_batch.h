@@ -137,6 +137,11 @@ int ilqg_batch_get_timing(ilqg_batch_t *c, int kernel, int *launches, double *to
 int ilqg_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
                      const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
 
+/* the same problems through the cooperative form the one-wavefront-per-trajectory mapping uses
+ * (one problem per wavefront, one lane per variable); same results bit for bit */
+int ilqg_boxqp_wave_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                          const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
+
 /* device sin/cos as the generated callbacks see them, on n arguments (unit tests) */
 int ilqg_sincos_batch(int device, int n, const double *x, double *s, double *c);
 

@@ -99,6 +99,43 @@ def test_boxqp_golden(ilqg, n, strict):
                 assert np.all(np.abs(r["x"][j] - g["qp_x"][i][:n]) <= 1e-7 * scale), (i, rc)
 
 
+@pytest.mark.parametrize("n", [2, 8])
+@pytest.mark.parametrize("strict", [False, True])
+def test_cooperative_boxqp_equals_the_per_lane_one(ilqg, n, strict):
+    """box_qp_rows (wave mapping: one lane per variable, operands broadcast) computes every scalar by the same
+    expression tree as the per-lane template: identical results bit for bit in the -ffp-contract=off build, on the
+    reference's goldens (every exit) and on random problems"""
+    g = golden("kernels.npz")
+    sel = np.nonzero(g["qp_n"] == n)[0]
+    t = tri(n)
+    rng = np.random.default_rng(3 + n)
+    R = 400
+    A = rng.standard_normal((R, n, n))
+    Mx = A @ np.transpose(A, (0, 2, 1)) + (10.0 ** rng.uniform(-8, 0, R))[:, None, None] * np.eye(n)
+    H = np.concatenate([g["qp_H"][sel][:, :t], np.array([[m[r, c] for c in range(n) for r in range(c + 1)] for m in Mx])])
+    gg = np.concatenate([g["qp_g"][sel][:, :n], rng.standard_normal((R, n))])
+    lo = np.concatenate([g["qp_lo"][sel][:, :n], -np.abs(rng.standard_normal((R, n)))])
+    hi = np.concatenate([g["qp_hi"][sel][:, :n], np.abs(rng.standard_normal((R, n)))])
+    x0 = np.concatenate([g["qp_x0"][sel][:, :n], rng.standard_normal((R, n))])
+    a = ilqg.boxqp_batch(n, H, gg, lo, hi, x0, strict=strict)
+    b = ilqg.boxqp_batch(n, H, gg, lo, hi, x0, strict=strict, cooperative=True)
+    assert len(set(a["rc"].tolist())) >= 4
+    if strict:
+        assert np.array_equal(a["rc"], b["rc"]) and np.array_equal(a["n_free"], b["n_free"])
+        assert np.array_equal(a["clamp"], b["clamp"])
+        assert np.array_equal(a["x"], b["x"], equal_nan=True)
+        ok = a["rc"] != -1  # a failed factorisation leaves the inverse of the previous one (or zeros) in both
+        assert np.array_equal(a["invH"][ok], b["invH"][ok], equal_nan=True)
+        return
+    # product build: the compiler contracts the two code shapes into FMAs differently, so values agree to rounding
+    # and an exit taken at rounding resolution (see test_boxqp_golden) may differ
+    same = (a["rc"] == b["rc"]) & np.all(a["clamp"] == b["clamp"], axis=1)
+    assert same.mean() > 0.97, same.mean()
+    reg = same & (a["rc"] >= 1)
+    scale = np.maximum(1.0, np.abs(a["x"][reg]).max(axis=1, keepdims=True))
+    assert np.all(np.abs(a["x"][reg] - b["x"][reg]) <= 1e-7 * scale)
+
+
 def test_device_sincos_accuracy(ilqg):
     """the straight-line sincos the callbacks' sin()/cos() are routed through: within 2 ulp of the host
     libm below 8e5 (small, medium, large arguments and next to multiples of pi/2); beyond that, for NaN
