@@ -994,17 +994,11 @@ __device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const Dev
         F.u = nomp(P, k, b) + NOM_U;
         return F;
     };
-    StepRegs<NX, NU, FULL> R;
-    StepFields<NX, NU> F = fields(N - 1);
-    load_step<NX, NU, FULL>(R, F);
-    drain_memory_ops();
     for(int k = N - 1; k >= 0; k--) {
         if(pf) pf->probe(7);
-        const StepFields<NX, NU> Fnext = fields(k > 0 ? k - 1 : 0);
-        const int rc = back_step_wave<NX, NU, FULL, HX>(S, R, F, Fnext, k > 0, nomp(P, k, b) + NOM_L,
-                                                        nomp(P, k, b) + NOM_K, lambda, regType, dV0,
-                                                        dV1, gsum, pf);
-        F = Fnext;
+        const StepFields<NX, NU> F = fields(k);
+        const int rc = back_step_wave<NX, NU, FULL, HX>(S, F, nomp(P, k, b) + NOM_L, nomp(P, k, b) + NOM_K, lambda,
+                                                        regType, dV0, dV1, gsum, pf);
         if(rc < 1) return 1;
     }
 #ifdef ILQG_PROFILE_SECTIONS

@@ -235,8 +235,9 @@ struct StepFields {
 
 // Everything a lane reads of a step's record, in registers.  With one wavefront per SIMD nothing else hides the
 // latency of a global load, and a step used to expose it about eight times (one load-then-use per section).  The
-// whole set is loaded in one go instead — for the NEXT step, as soon as the Q assembly of the current one has
-// consumed the registers — and is in flight during the box QP, the gains and the V update.
+// whole set is loaded in one go at the start of the step instead.  (Loading the NEXT step's set as soon as the Q
+// assembly has consumed the registers, in flight during the box QP, was measured as well: the 100 doubles then live
+// across the whole step push the kernel over 512 registers and the spills cost what the overlap gains.)
 template <int NX, int NU, bool FULL>
 struct StepRegs {
     static constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
@@ -297,20 +298,19 @@ __device__ __forceinline__ void load_step(StepRegs<NX, NU, FULL> &R, const StepF
     for(int i = 0; i < NU; i++) R.u[i] = F.u[i];
 }
 
-// One backward step on a wave.  S: LDS block of this wave; R: the step's record in registers (load_step);
-// F: global fields of the step (state-dependent limits only); Fnext: the step processed next, whose record is
-// loaded into R once R has been consumed (has_next = 0: none);
+// One backward step on a wave.  S: LDS block of this wave; F: global fields of the step;
 // lout/Kout: where the step's gains go in global memory (trajectory-major).
 // Returns the box-QP code (wave-uniform); < 1 aborts the sweep.
 template <int NX, int NU, bool FULL, bool HX>
-__device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, StepRegs<NX, NU, FULL> &R, const StepFields<NX, NU> &F,
-                                              const StepFields<NX, NU> &Fnext, const bool has_next, double *lout,
+__device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFields<NX, NU> &F, double *lout,
                                               double *Kout, const double lambda, const int regType, double &dV0,
                                               double &dV1, double &gsum, Prof *pf = nullptr) {
     using SR = StepRegs<NX, NU, FULL>;
     constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
     constexpr int LDX = NX + 1, LDU = NU + 1;  // padded leading dimensions of the LDS copies
     const int lane = threadIdx.x & 63;
+    StepRegs<NX, NU, FULL> R;
+    load_step<NX, NU, FULL>(R, F);
 
     // stage fx, fu (read NX resp. NU times each) in LDS
 #pragma unroll
@@ -408,8 +408,6 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, StepRegs<NX, N
         }
         (isxx ? S.Qxx : S.Quu)[e] = v;
     }
-    // R has been consumed: the next step's record into the same registers, in flight from here on
-    if(has_next) load_step<NX, NU, FULL>(R, Fnext);
     __syncthreads();
 
     if(pf) pf->probe(1);
