@@ -73,6 +73,23 @@ def brachi_hli_case(n=500):
     return params, opts, np.array([-np.finfo(float).eps]), -np.ones((n, 1))
 
 
+# all four constraint kinds at once (problems/defs/almix.py): velocity bound, input limit, final position bound and
+# both final equalities end up active; the first iteration is rejected (weights raised by w_pen_fact2, iLQG.c:345-349)
+ALMIX_N = 80
+
+
+def almix_case(batch=None, seed=3):
+    n = ALMIX_N
+    params = dict(h=[0.1], cu=[0.05, 0.02], cx=[0.3, 0.05, 0.02], cf=[4.0, 1.0, 2.0], lim=[-1.1, 1.1],
+                  tgt=[2.0, 1.55, 0.45], vref=0.8 + 0.4 * np.sin(np.arange(n + 1) * 0.2))
+    opts = dict(max_iter=80, w_pen_init_l=2.0, w_pen_init_f=2.0, w_pen_fact2=2.0, w_pen_max_l=200.0, w_pen_max_f=200.0)
+    rng = np.random.default_rng(seed)
+    if batch is None:
+        return params, opts, np.array([0.0, 0.2, -0.3]), 0.1 * rng.standard_normal((n, 2))
+    x0 = np.array([0.0, 0.2, -0.3]) + 0.2 * rng.standard_normal((batch, 3))
+    return params, opts, x0, 0.1 * rng.standard_normal((batch, n, 2))
+
+
 def lib_path(kind, problem="carparking", full_ddp=0):
     """kind: 'ref' (reference sources) or 'oracle' (CPU restatement)"""
     if kind == "ref":

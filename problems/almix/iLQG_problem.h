@@ -1,0 +1,121 @@
+/* Problem header for 'AlMix' emitted by tools/gen_problem.py. Do not edit.
+ * Layout contract: reference iLQG_problem.tem:16-89. */
+#ifndef ILQG_PROBLEM_H
+#define ILQG_PROBLEM_H
+
+#include <math.h>
+#include "mex.h"
+#ifndef  HAVE_OCTAVE
+#include "matrix.h"
+#endif
+
+#define isNANorINF(v) (mxIsNaN(v) || mxIsInf(v))
+#define INF mxGetInf()
+
+#define N_X 3
+#define N_U 2
+
+#define sizeofQxx 6
+#define sizeofQuu 3
+#define sizeofQxu 6
+
+/* additive hints for the batched backend (absent in Maxima-generated headers,
+ * which are then treated as the general case) */
+#define ILQG_PROBLEM_NAME "AlMix"
+#define ILQG_STATE_DEPENDENT_LIMITS 0
+
+typedef struct {
+    double x[N_X];
+    double u[N_U];
+    double lower[N_U];
+    double upper[N_U];
+    double lower_sign[N_U];
+    double upper_sign[N_U];
+    double lower_hx[N_X*N_U];
+    double upper_hx[N_X*N_U];
+
+    double l[N_U];
+    double L[N_U*N_X];
+    double c;
+    double cx[N_X];
+    double cxx[sizeofQxx];
+    double cu[N_U];
+    double cuu[sizeofQuu];
+    double cxu[sizeofQxu];
+    double fx[N_X*N_X];
+    double fu[N_X*N_U];
+#if FULL_DDP
+    double fxx[N_X*sizeofQxx];
+    double fuu[N_X*sizeofQuu];
+    double fxu[N_X*sizeofQxu];
+#endif
+    double gap;
+    double hle_1;
+    double ple_1;
+    double hli_1;
+    double pli_1;
+    double hli_2;
+    double pli_2;
+    double dpli_2_x1;
+    double dpli_1_x1;
+    double dhle_1_x1;
+    double dple_1_x1;
+    double dple_1_u1;
+    double dpli_2_x1x1;
+    double dple_1_x1x1;
+    double dpli_1_x1x1;
+    double dple_1_u1u1;
+    double dple_1_u1x1;
+#if FULL_DDP
+#endif
+} trajEl_t;
+
+typedef struct {
+    double x[N_X];
+
+    double c;
+    double cx[N_X];
+    double cxx[sizeofQxx];
+    double gap;
+    double hfe_1;
+    double pfe_1;
+    double hfe_2;
+    double pfe_2;
+    double hfi_1;
+    double pfi_1;
+    double dpfi_1_x0;
+    double dpfe_2_x0;
+    double dpfe_1_x1;
+    double dpfe_2_x2;
+    double dpfi_1_x0x0;
+    double dpfe_2_x0x0;
+    double dpfe_2_x0x2;
+    double dpfe_1_x1x1;
+    double dpfe_2_x2x2;
+} trajFin_t;
+
+typedef struct {
+    trajEl_t* t;
+    trajFin_t f;
+} traj_t;
+
+typedef struct {
+    double mu_le[1];
+    double last_hle[1];
+    double mu_li[2];
+    double last_hli[2];
+} multipliersEl_t;
+
+typedef struct {
+    double mu_fe[2];
+    double last_hfe[2];
+    double mu_fi[1];
+    double last_hfi[1];
+} multipliersFin_t;
+
+typedef struct {
+    multipliersEl_t* t;
+    multipliersFin_t f;
+} multipliers_t;
+
+#endif // ILQG_PROBLEM_H

@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT as SYN_PARAMS, Driver, Kernels, brachi_case,  # noqa: E402
+from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT as SYN_PARAMS, Driver, Kernels, almix_case, brachi_case,  # noqa: E402
                             brachi_hli_case, hx_inputs, lib_path, syn_inputs)
 
 spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "ddp-generator_amd", "synth.py"))
@@ -387,9 +387,33 @@ def brachi_goldens():
     np.savez_compressed(os.path.join(HERE, "brachi.npz"), **out)
 
 
+def almix_goldens():
+    """all four constraint kinds at once (problems/defs/almix.py), both FULL_DDP settings"""
+    out = {}
+    params, opts, x0, u0 = almix_case()
+    for fd in (0, 1):
+        tag = "fd%d_" % fd
+        d = Driver(lib_path("ref", "almix", fd), len(u0), params, opts)
+        assert d.init(x0, u0) == 1
+        out[tag + "init_cost"] = d.scalars()["cost"]
+        rc = d.solve()
+        x, u = d.traj(0)
+        el, fin, w = d.multipliers()
+        tr = d.trace()
+        out.update({tag + "rc": rc, tag + "x": x, tag + "u": u, tag + "mul": el, tag + "mul_fin": fin,
+                    tag + "w_pen": np.array(w), tag + "cost": d.scalars()["cost"],
+                    tag + "iterations": int(d.scalars()["iterations"])})
+        out.update({tag + "trace_" + k: v for k, v in tr.items()})
+        print("almix fd%d: rc %d, %d iterations, cost %.12g, x_N %s, w_pen %s, rejected iterations %d" %
+              (fd, rc, out[tag + "iterations"], out[tag + "cost"], x[-1], w, int(np.sum(tr["alpha_idx"] > 8))))
+        d.close()
+    np.savez_compressed(os.path.join(HERE, "almix.npz"), **out)
+
+
 def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     brachi_goldens()
+    almix_goldens()
     kernel_goldens(Kernels(lib_path("ref", full_ddp=0)))
     for fd in (0, 1):
         single_pass_goldens(fd)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from oracle.harness import Driver, brachi_case, brachi_hli_case, lib_path
+from oracle.harness import Driver, almix_case, brachi_case, brachi_hli_case, lib_path
 
 pytestmark = pytest.mark.gpu
 
@@ -110,6 +110,62 @@ def test_batch_of_different_starts_against_the_oracle(ilqg, oracle_built):
         seen.add(w)
         d.close()
     assert len(seen) > 1  # the penalty-weight schedules differ between trajectories
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_all_constraint_kinds_bit_exact_without_fma(ilqg, fd):
+    """hle, hli, hfe, hfi at once, arrays of multipliers, a clamped input, a rejected first iteration (weights raised
+    by w_pen_fact2 and cost re-swept, iLQG.c:345-349): iteration by iteration against the reference's fixture"""
+    g = golden("almix.npz")
+    tag = "fd%d_" % fd
+    params, opts, x0, u0 = almix_case()
+    s = ilqg.BatchSolver("almix", fd, batch=1, n_hor=len(u0), params=params, opts=opts, strict=True)
+    assert s.multiplier_dims() == (g[tag + "mul"].shape[1], g[tag + "mul_fin"].shape[0]) == (6, 6)
+    s.init(x0[None], u0[None])
+    assert s.scalar("cost")[0] == g[tag + "init_cost"]
+    its = int(g[tag + "iterations"])
+    for it in range(its):
+        s.iterate(1)
+        assert s.scalar("new_cost")[0] == g[tag + "trace_new_cost"][it], it
+        assert s.ints("alpha_idx")[0] == g[tag + "trace_alpha_idx"][it], it
+        assert s.scalar("g_norm")[0] == g[tag + "trace_g_norm"][it], it
+    s.solve()
+    assert s.ints("iterations")[0] == its and s.success()[0] == bool(g[tag + "rc"])
+    assert s.scalar("cost")[0] == g[tag + "cost"]
+    assert np.array_equal(s.x()[0], g[tag + "x"]) and np.array_equal(s.u()[0], g[tag + "u"])
+    run, fin = s.multipliers()
+    assert np.array_equal(run[0], g[tag + "mul"]) and np.array_equal(fin[0], g[tag + "mul_fin"])
+    assert s.scalar("w_pen_l")[0] == g[tag + "w_pen"][0] and s.scalar("w_pen_f")[0] == g[tag + "w_pen"][1]
+    s.close()
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_all_constraint_kinds_batch_against_the_oracle(ilqg, oracle_built, fd):
+    """product build, 70 different starts in lock step: same iteration counts and exits as the oracle, costs and
+    trajectories within the full-solve tolerances of test_gpu_parity.py"""
+    B = 70
+    params, opts, x0, u0 = almix_case(batch=B)
+    s = ilqg.BatchSolver("almix", fd, batch=B, n_hor=u0.shape[1], params=params, opts=opts)
+    s.init(x0, u0)
+    s.solve()
+    cost, iters, ok, x = s.scalar("cost"), s.ints("iterations"), s.success(), s.x()
+    wl = s.scalar("w_pen_l")
+    s.close()
+    same = 0
+    for b in range(B):
+        d = Driver(lib_path("oracle", "almix", fd), u0.shape[1], params, opts)
+        assert d.init(x0[b], u0[b]) == 1
+        rc = d.solve()
+        if int(d.scalars()["iterations"]) == iters[b]:
+            same += 1
+            assert (rc == 1) == bool(ok[b]), b
+            assert close(cost[b], d.scalars()["cost"], 1e-6), b
+            assert np.abs(d.traj(0)[0] - x[b]).max() < 1e-4, b
+            assert d.multipliers()[2][0] == wl[b], b
+        else:  # a tolerance exit taken one iteration earlier or later: same optimum
+            assert close(cost[b], d.scalars()["cost"], 1e-5), b
+        d.close()
+    assert same >= B - 3, same
 
 
 def test_dropin_line_search_uses_the_callers_multipliers(ilqg, oracle_built):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver, Kernels, brachi_case, brachi_hli_case,
+from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver, Kernels, almix_case, brachi_case, brachi_hli_case,
                             lib_path)
 
 
@@ -197,6 +197,31 @@ def test_multiplier_problems(oracle_built, tag, problem, case):
     assert d.scalars()["cost"] == g[tag + "cost"] and int(d.scalars()["iterations"]) == int(g[tag + "iterations"])
     for k, v in d.trace().items():
         assert np.array_equal(v, g[tag + "trace_" + k]), k
+    d.close()
+
+
+@pytest.mark.parametrize("fd", [0, 1])
+def test_all_constraint_kinds(oracle_built, fd):
+    """hle, hli, hfe, hfi together with a clamped input and a rejected first iteration (problems/defs/almix.py)"""
+    g = golden("almix.npz")
+    tag = "fd%d_" % fd
+    params, opts, x0, u0 = almix_case()
+    d = Driver(lib_path("oracle", "almix", fd), len(u0), params, opts)
+    assert d.init(x0, u0) == 1
+    assert d.scalars()["cost"] == g[tag + "init_cost"]
+    assert d.solve() == int(g[tag + "rc"])
+    x, u = d.traj(0)
+    el, fin, w = d.multipliers()
+    assert np.array_equal(x, g[tag + "x"]) and np.array_equal(u, g[tag + "u"])
+    assert np.array_equal(el, g[tag + "mul"]) and np.array_equal(fin, g[tag + "mul_fin"])
+    assert np.array_equal(np.array(w), g[tag + "w_pen"])
+    assert d.scalars()["cost"] == g[tag + "cost"] and int(d.scalars()["iterations"]) == int(g[tag + "iterations"])
+    for k, v in d.trace().items():
+        assert np.array_equal(v, g[tag + "trace_" + k]), k
+    # every kind did something: non-trivial multipliers of all four kinds, an input on its limit
+    assert np.abs(el[:, 0]).max() > 1e-3 and np.abs(el[:, 2] - 1.0).max() > 1e-3   # mu_le, mu_li
+    assert np.abs(fin[0]) > 1e-3 and np.abs(fin[4] - 1.0) > 1e-6                 # mu_fe, mu_fi
+    assert np.isclose(u[:, 0].max(), 1.1)
     d.close()
 
 
