@@ -79,6 +79,21 @@ __device__ __forceinline__ int ilqg_note_nonfinite(double **p, double v) {
 #undef mxIsInf
 #define mxIsNaN(v) ilqg_note_nonfinite(p, (v))
 #define mxIsInf(v) 0
+#define ILQG_UNIFORM_GUARDS 0
+#else
+// What those files get instead is a guard whose condition is WAVE-UNIFORM: "some active lane's value is NaN or
+// Inf".  A literal per-lane guard is a divergent early return; 5 000 of them in one function leave the compiler
+// with more saved exec masks than scalar registers, and it spills them through vector-register lanes that are
+// spilled themselves: a scratch load, a wait and a scratch store around EVERY assignment (measured: the device
+// copy of bp_derivsL of the n = 16 problem was 223 000 lines of ISA).  A uniform condition is a compare and a
+// scalar branch.  When it fires, all active lanes leave the callback together; the caller then repeats the call
+// lane by lane (run_alone below: one active lane, so the condition is exactly that lane's), which restores the
+// per-lane result of the reference.  Lanes that have failed stay out of later calls.
+#undef mxIsNaN
+#undef mxIsInf
+#define mxIsNaN(v) (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(v) < __builtin_inf())) != 0ull)
+#define mxIsInf(v) 0
+#define ILQG_UNIFORM_GUARDS 1
 #endif
 
 // The generated callbacks call sin(x) and cos(x) of the same few arguments many times, spread
@@ -218,6 +233,8 @@ constexpr int MF = std::is_empty<multipliersFin_t>::value ? 0 : (int)(sizeof(mul
 constexpr bool HAS_MUL = ME + MF > 0;
 constexpr int MEW = ME > 0 ? ME : 1, MFW = MF > 0 ? MF : 1;  // widths of the (possibly unused) device fields
 static_assert(!(WAVE_MAP && HAS_MUL), "multipliers are implemented for the lane mapping only");
+static_assert(!ILQG_UNIFORM_GUARDS || WAVE_MAP, "wave-uniform guards (large generated files): the lane mapping's "
+              "derivative and backward kernels have no lane-by-lane repetition");
 
 thread_local std::string g_err;
 
@@ -251,6 +268,19 @@ __device__ __forceinline__ void drain_memory_ops() { __builtin_amdgcn_s_waitcnt(
 
 // "this value is needed HERE": keeps the optimiser from sinking its computation into a later block
 __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
+
+// Builds with wave-uniform guards (ILQG_UNIFORM_GUARDS): f() for all active lanes together; if that fails (for all
+// of them, see the guard), once more with one lane active at a time.  ONE call site for both, so that the repetition
+// is the same machine code and a healthy lane gets the same bits either way.
+template <class Fn>
+__device__ __forceinline__ int run_guarded(Fn &&f) {
+    int r = 1;
+    for(int a = 0; a <= 64; a++) {
+        if(a == 0 || (int)(threadIdx.x & 63) == a - 1) r = f();
+        if(a == 0 && __builtin_amdgcn_ballot_w64(r == 0) == 0ull) break;
+    }
+    return r;
+}
 
 // Layout of the derivative-record fields (DER, FIN) of width W (doubles per step and trajectory):
 //   lane mapping: [step][tile of 64 trajectories][component][trajectory in tile] — k_derivs, lane = (trajectory,
@@ -931,12 +961,16 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
             ok &= bp_derivsL(t, k, o.p);
             limitsU(t, k, o.p, P.N);
         };
+#if ILQG_UNIFORM_GUARDS
+        ok = run_guarded([&]() { body(); return ok; });
+#else
         body();
         if(H.huge != 0.0) {  // an argument beyond the fast sin/cos reduction: once more through the library
             H.nonfinite = 0.0;
             H.slow = 1.0;
             body();
         }
+#endif
     } else {
         trajFin_t fin;
         init_final(&fin, &o);
@@ -946,12 +980,16 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
             ok &= calcFAuxDeriv(&fin, nullptr, &o);
             ok &= bp_derivsF(&fin, P.N, o.p);
         };
+#if ILQG_UNIFORM_GUARDS
+        ok = run_guarded([&]() { body(); return ok; });
+#else
         body();
         if(H.huge != 0.0) {
             H.nonfinite = 0.0;
             H.slow = 1.0;
             body();
         }
+#endif
         double *out = P.f[ILQG_F_FIN] + (size_t)b * FIN;
         for(int i = 0; i < NX; i++) out[i] = fin.cx[i];
         for(int i = 0; i < SXX; i++) out[NX + i] = fin.cxx[i];
@@ -1261,13 +1299,18 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
             r &= ddpL(&ct, k, &C.o);
             return r;
         };
-        int r = step();
+        int r = 1;
+#if ILQG_UNIFORM_GUARDS
+        if(okc) r = run_guarded(step);  // a lane that has failed stays out: its guards would fail the wavefront again
+#else
+        r = step();
         if(H.huge != 0.0) {  // an argument beyond the fast sin/cos reduction: once more through the library
             H.nonfinite = nf0;
             H.slow = 1.0;
             r = step();
             H.slow = 0.0;
         }
+#endif
         okc &= r;
         csum += ct.c;
         // The step's results are stored right away, i.e. BEHIND the prefetch of the next step in issue order: the
@@ -1320,13 +1363,18 @@ __global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, i
             r &= ddpF(&cf, &C.o);
             return r;
         };
-        int r = fin();
+        int r = 1;
+#if ILQG_UNIFORM_GUARDS
+        if(okc) r = run_guarded(fin);
+#else
+        r = fin();
         if(H.huge != 0.0) {
             H.nonfinite = nf0;
             H.slow = 1.0;
             r = fin();
             H.slow = 0.0;
         }
+#endif
         okc &= r;
         csum += cf.c;
         if(store) {

@@ -799,6 +799,38 @@ def test_failure_paths_are_per_trajectory(ilqg, synth):
     s.close(); clean.close()
 
 
+@pytest.mark.parametrize("fd", [0, 1])
+def test_failure_paths_are_per_trajectory_with_uniform_guards(ilqg, fd):
+    """the large generated file (n = 16) is compiled with wave-uniform NaN/Inf guards: when one lane's value is not
+    finite every lane of the wavefront leaves the callback, and the kernel repeats the call lane by lane.  A NaN
+    in one trajectory's inputs (initial roll-out) and an Inf planted in another one's state (derivatives) must fail
+    exactly those two and leave every other trajectory's results bit-identical to a clean run (the repetition runs
+    the same machine code as the first attempt)."""
+    B, N, iters = 70, 32, 2
+    x0, u0 = syn_inputs(B, N)
+    runs = []
+    for poison in (False, True):
+        u = u0.copy()
+        if poison:
+            u[5, 10, 3] = np.nan
+        s = ilqg.BatchSolver("synth16x8", fd, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters + 1))
+        s.init(x0, u)
+        if poison:
+            st = s.ints("status")
+            assert st[5] == 7 and np.all(np.delete(st, 5) == 0)
+            x = s.x()
+            x[40, 7, 2] = np.inf
+            s.set_x(x)
+        s.iterate(iters)
+        runs.append((s.ints("status"), s.scalar("cost"), s.x(), s.u(), s.ints("iterations")))
+        s.close()
+    clean, bad = runs
+    ok = np.ones(B, dtype=bool); ok[[5, 40]] = False
+    assert bad[0][5] == 7 and bad[0][40] == 6
+    for a, b in zip(clean, bad):
+        assert np.array_equal(a[ok], b[ok])
+
+
 # all inside the first 8 iterations, before free-running paths can drift apart (test_lockstep20_teacher_forced)
 @pytest.mark.parametrize("opts", [dict(max_iter=0), dict(max_iter=8, alpha=[1.0], zMin=0.99, lambdaMax=3.0), dict(max_iter=6, lambdaInit=1e9),
                                   dict(max_iter=8, tolFun=0.5), dict(max_iter=8, alpha=[1.0, 0.5]), dict(max_iter=8, zMin=0.6)])
