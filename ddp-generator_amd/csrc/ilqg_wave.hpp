@@ -226,6 +226,23 @@ ILQG_DEV int box_qp_rows(const double *Hpacked /* LDS */, const double g, const 
     return rc;
 }
 
+// The operands of a lane's dot product, LDS -> registers, ALL reads issued before the first multiply-add.  Left to
+// itself the scheduler (minimising registers in a kernel this large) issues one read, waits for it, does two
+// multiply-adds, issues the next: 8 exposed LDS latencies per 16-term sum, with nothing else on the SIMD to hide
+// them (measured: 191 full LDS waits in the step).  The summation order is untouched.
+template <int N>
+ILQG_DEV void lds_fetch(double (&dst)[N], const double *src, int stride = 1) {
+#pragma unroll
+    for(int i = 0; i < N; i++) dst[i] = src[i * stride];
+}
+ILQG_DEV void reads_before_math() { __builtin_amdgcn_sched_barrier(0); }
+template <int N>
+ILQG_DEV double dot_acc(double acc, const double (&a)[N], const double (&b)[N]) {
+#pragma unroll
+    for(int i = 0; i < N; i++) acc += a[i] * b[i];
+    return acc;
+}
+
 // rec: this step's trajEl_t in global memory (fields read through the pointers below)
 template <int NX, int NU>
 struct StepFields {
@@ -354,10 +371,12 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         const int oo = second ? o - NXU : o;
         const int r = oo % NX, q = oo / NX;
         const double *A = second ? S.fx : S.fu;
-        double acc = 0.0;
-        #pragma unroll
-        for(int s = 0; s < NX; s++) acc += S.Vxx[sy(r, s)] * A[s + q * LDX];
-        (second ? S.T1 : S.T2)[r + q * LDX] = acc;
+        double row[NX], col[NX];
+#pragma unroll
+        for(int s = 0; s < NX; s++) row[s] = S.Vxx[sy(r, s)];
+        lds_fetch(col, A + q * LDX);
+        reads_before_math();
+        (second ? S.T1 : S.T2)[r + q * LDX] = dot_acc(0.0, row, col);
     }
     __syncthreads();
 
@@ -368,9 +387,11 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         const int j = lane + 64 * a;
         if(j >= NXU) continue;
         const int r = j % NX, q = j / NX;
-        double d = 0.0;
-        #pragma unroll
-        for(int s = 0; s < NX; s++) d += S.fx[s + r * LDX] * S.T2[s + q * LDX];
+        double ca[NX], cb[NX];
+        lds_fetch(ca, S.fx + r * LDX);
+        lds_fetch(cb, S.T2 + q * LDX);
+        reads_before_math();
+        const double d = dot_acc(0.0, ca, cb);
         double v = R.cxu[a] + d;
         if(FULL) {
             double d1 = 0.0;
@@ -391,12 +412,15 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         tri_rc(e, r, c);
         const double *A = isxx ? S.fx : S.fu;
         const double *T = isxx ? S.T1 : S.T2;
-        double acc = 0.0;
-        #pragma unroll
-        for(int s = 0; s < NX; s++) acc += A[s + r * LDX] * T[s + c * LDX];
+        double ar[NX], tc[NX], ac[NX], tr[NX];
+        lds_fetch(ar, A + r * LDX);
+        lds_fetch(tc, T + c * LDX);
+        lds_fetch(ac, A + c * LDX);  // (diagonal entries do not use these two)
+        lds_fetch(tr, T + r * LDX);
+        reads_before_math();
+        double acc = dot_acc(0.0, ar, tc);
         if(r != c) {
-            #pragma unroll
-            for(int s = 0; s < NX; s++) acc += A[s + c * LDX] * T[s + r * LDX];
+            acc = dot_acc(acc, ac, tr);
             acc *= 0.5;
         }
         double v = R.cq[a] + acc;
@@ -498,10 +522,12 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             S.bc[o] = acc;
         } else {
             const int oo = o - NU, r = oo % NU, c = oo / NU;
-            double acc = 0.0;
-            #pragma unroll
-            for(int s = 0; s < NU; s++) acc += S.Quu[sy(r, s)] * S.K[s + c * LDU];
-            S.ba[r + c * LDU] = acc;
+            double qrow[NU], kcol[NU];
+#pragma unroll
+            for(int s = 0; s < NU; s++) qrow[s] = S.Quu[sy(r, s)];
+            lds_fetch(kcol, S.K + c * LDU);
+            reads_before_math();
+            S.ba[r + c * LDU] = dot_acc(0.0, qrow, kcol);
         }
     }
     __syncthreads();
@@ -511,37 +537,45 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     for(int o = lane; o < NX + SXX; o += 64) {
         if(o < NX) {
             const int i = o;
-            double d = 0.0;
-            #pragma unroll
-            for(int s = 0; s < NU; s++) d += S.K[s + i * LDU] * S.bc[s];
-            double v = S.Qx[i] + d;
-            #pragma unroll
-            for(int j = 0; j < NU; j++) v += S.K[j + i * LDU] * S.Qu[j];
-            #pragma unroll
-            for(int j = 0; j < NU; j++) v += S.Qxu[i + j * NX] * S.l[j];
+            double ki[NU], bcv[NU], quv[NU], qi[NU], lv[NU];
+            lds_fetch(ki, S.K + i * LDU);
+            lds_fetch(bcv, S.bc);
+            lds_fetch(quv, S.Qu);
+            lds_fetch(qi, S.Qxu + i, NX);
+            lds_fetch(lv, S.l);
+            const double qx = S.Qx[i];
+            reads_before_math();
+            const double d = dot_acc(0.0, ki, bcv);
+            double v = qx + d;
+            v = dot_acc(v, ki, quv);
+            v = dot_acc(v, qi, lv);
             S.Vx[i] = v;
         } else {
             const int e = o - NX;
             int r, c;
             tri_rc(e, r, c);
-            double acc = 0.0;
-            #pragma unroll
-            for(int s = 0; s < NU; s++) acc += S.K[s + r * LDU] * S.ba[s + c * LDU];
+            double kr[NU], kc[NU], bar[NU], bac[NU], qr[NU], qc[NU];
+            lds_fetch(kr, S.K + r * LDU);
+            lds_fetch(kc, S.K + c * LDU);
+            lds_fetch(bac, S.ba + c * LDU);
+            lds_fetch(bar, S.ba + r * LDU);
+            lds_fetch(qr, S.Qxu + r, NX);
+            lds_fetch(qc, S.Qxu + c, NX);
+            const double qxx = S.Qxx[e];
+            reads_before_math();
+            double acc = dot_acc(0.0, kr, bac);
             if(r != c) {
-                #pragma unroll
-                for(int s = 0; s < NU; s++) acc += S.K[s + c * LDU] * S.ba[s + r * LDU];
+                acc = dot_acc(acc, kc, bar);
                 acc *= 0.5;
             }
-            double v = S.Qxx[e] + acc;
+            double v = qxx + acc;
             // the reference's i-major loop touches packed entry (r,c) first as (i=r,j=c), then as (i=c,j=r)
             if(r == c) {
                 #pragma unroll
-                for(int q = 0; q < NU; q++) v += (S.K[q + r * LDU] * S.Qxu[r + q * NX]) * 2.0;
+                for(int q = 0; q < NU; q++) v += (kr[q] * qr[q]) * 2.0;
             } else {
-                #pragma unroll
-                for(int q = 0; q < NU; q++) v += S.K[q + r * LDU] * S.Qxu[c + q * NX];
-                #pragma unroll
-                for(int q = 0; q < NU; q++) v += S.K[q + c * LDU] * S.Qxu[r + q * NX];
+                v = dot_acc(v, kr, qc);
+                v = dot_acc(v, kc, qr);
             }
             S.Vxx[e] = v;
         }
