@@ -352,18 +352,15 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     for(int a = 0; a < SR::NC; a++) {
         const int c = lane + 64 * a;
         if(c >= NU + NX) continue;
-        if(c < NU) {
-            double acc = R.c1[a];
-            #pragma unroll
-            for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fu[r + c * LDX];
+        double vx[NX], col[NX];
+        lds_fetch(vx, S.Vx);
+        lds_fetch(col, (c < NU) ? S.fu + c * LDX : S.fx + (c - NU) * LDX);
+        reads_before_math();
+        const double acc = dot_acc(R.c1[a], vx, col);
+        if(c < NU)
             S.Qu[c] = acc;
-        } else {
-            const int cc = c - NU;
-            double acc = R.c1[a];
-            #pragma unroll
-            for(int r = 0; r < NX; r++) acc += S.Vx[r] * S.fx[r + cc * LDX];
-            S.Qx[cc] = acc;
-        }
+        else
+            S.Qx[c - NU] = acc;
     }
     // T2 = Vxx fu (the `bc` of addMul2Tri and the `ba` of addSquareTri for Quu), T1 = Vxx fx
     for(int o = lane; o < NXU + NX * NX; o += 64) {
@@ -473,6 +470,15 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     for(int o = lane; o < NXU; o += 64) {
         const int i = o % NU, q = o / NU;  // K[i + q*NU]
         double v = 0.0;
+        int cl[NU];
+        double ih[NU], qx[NU];
+#pragma unroll
+        for(int j = 0; j < NU; j++) {
+            cl[j] = S.clamp[j];
+            ih[j] = S.invH[sy(i, j)];
+        }
+        lds_fetch(qx, S.Qxur + q, NX);
+        reads_before_math();
         if(S.clamp[i]) {
             if(HX) {
                 const double sg = (S.clamp[i] == 1) ? F.lower_sign[i] : F.upper_sign[i];
@@ -482,8 +488,8 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         } else {
             #pragma unroll
             for(int j = 0; j < NU; j++) {
-                if(!S.clamp[j]) {
-                    v -= S.invH[sy(i, j)] * S.Qxur[q + j * NX];
+                if(!cl[j]) {
+                    v -= ih[j] * qx[j];
                 } else if(HX) {
                     double w = 0.0;
                     #pragma unroll
@@ -503,14 +509,20 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
 
     if(pf) pf->probe(4);
     // expected cost change, redundantly on every lane (back_pass.c:205-214)
-    #pragma unroll
-    for(int i = 0; i < NU; i++) dV0 += S.Qu[i] * S.l[i];
-    #pragma unroll
-    for(int i = 0; i < NU; i++) {
-        double acc = 0.0;
+    {
+        double quv[NU], lv[NU], quu[SUU];
+        lds_fetch(quv, S.Qu);
+        lds_fetch(lv, S.l);
+        lds_fetch(quu, S.Quu);
+        reads_before_math();
+        dV0 = dot_acc(dV0, quv, lv);
         #pragma unroll
-        for(int j = 0; j < NU; j++) acc += S.l[j] * S.Quu[sy(j, i)];
-        dV1 += 0.5 * S.l[i] * acc;
+        for(int i = 0; i < NU; i++) {
+            double acc = 0.0;
+            #pragma unroll
+            for(int j = 0; j < NU; j++) acc += lv[j] * quu[sy(j, i)];
+            dV1 += 0.5 * lv[i] * acc;
+        }
     }
 
     // Quu*l and Quu*K (the `bc` / `ba` temporaries of addMul2Tri / addSquareTri)
