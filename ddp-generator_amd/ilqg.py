@@ -256,8 +256,10 @@ class BatchSolver:
 
     def set_multipliers(self, running, final):
         me, mf = self.multiplier_dims()
-        run = np.ascontiguousarray(running, dtype=np.float64).reshape(self.B, self.N, max(me, 1))
-        fin = np.ascontiguousarray(final, dtype=np.float64).reshape(self.B, max(mf, 1))
+        # a part the problem does not have is not read by the library: any buffer will do
+        run = (np.ascontiguousarray(running, dtype=np.float64).reshape(self.B, self.N, me) if me
+               else np.zeros((self.B, self.N, 1)))
+        fin = np.ascontiguousarray(final, dtype=np.float64).reshape(self.B, mf) if mf else np.zeros((self.B, 1))
         self._ck(self.lib.ilqg_batch_set_multipliers(self.h, run, fin))
 
     def scalar(self, name):

@@ -189,6 +189,32 @@ def test_dropin_line_search_uses_the_callers_multipliers(ilqg, oracle_built):
     assert a[3][2] == b[3][2]  # penalty weights
 
 
+def test_multipliers_can_be_read_and_set(ilqg):
+    """ilqg_batch_get/set_multipliers: member-by-member round trip, and a solve that starts from the multipliers
+    and weights another solve ended with needs fewer iterations than the cold one"""
+    params, opts, x0, u0 = brachi_case(50)
+    a = solver(ilqg, "brachi", brachi_case(50))
+    a.init(x0[None], u0[None])
+    run0, fin0 = a.multipliers()
+    assert run0.shape == (1, 50, 0) and fin0.shape == (1, 2)
+    # mu_fe = 0 (init_multipliers); last_hfe = the constraint value of the initial roll-out (update_multipliers(o, 1))
+    assert fin0[0, 0] == 0.0 and fin0[0, 1] == a.x()[0, -1, 0] - params["yf"][0]
+    a.solve()
+    run1, fin1 = a.multipliers()
+    assert fin1[0, 0] != 0.0
+    cold = int(a.ints("iterations")[0])
+    xa, ua = a.x(), a.u()
+    b = solver(ilqg, "brachi", brachi_case(50))
+    b.init(x0[None], ua)                                 # the solved controls ...
+    b.set_multipliers(run1, fin1)                        # ... and the multipliers they were found with
+    r2, f2 = b.multipliers()
+    assert np.array_equal(f2, fin1)
+    b.solve()
+    assert int(b.ints("iterations")[0]) < cold
+    assert abs(b.x()[0, -1, 0] - xa[0, -1, 0]) < 1e-5
+    a.close(); b.close()
+
+
 def test_fused_derivatives_are_refused(ilqg):
     params, opts, x0, u0 = brachi_case(5)
     s = solver(ilqg, "brachi", brachi_case(5))
