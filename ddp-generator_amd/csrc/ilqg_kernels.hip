@@ -232,7 +232,6 @@ constexpr int ME = std::is_empty<multipliersEl_t>::value ? 0 : (int)(sizeof(mult
 constexpr int MF = std::is_empty<multipliersFin_t>::value ? 0 : (int)(sizeof(multipliersFin_t) / sizeof(double));
 constexpr bool HAS_MUL = ME + MF > 0;
 constexpr int MEW = ME > 0 ? ME : 1, MFW = MF > 0 ? MF : 1;  // widths of the (possibly unused) device fields
-static_assert(!(WAVE_MAP && HAS_MUL), "multipliers are implemented for the lane mapping only");
 static_assert(!ILQG_UNIFORM_GUARDS || WAVE_MAP, "wave-uniform guards (large generated files): the lane mapping's "
               "derivative and backward kernels have no lane-by-lane repetition");
 
@@ -331,14 +330,17 @@ __device__ __forceinline__ double *cur_u(const DevPtrs &P, int k, int b) {
 __device__ __forceinline__ size_t cur_xstride(const DevPtrs &P) { return WAVE_MAP ? (size_t)RN : (size_t)NX * P.Bp; }
 __device__ __forceinline__ size_t cur_ustride(const DevPtrs &P) { return WAVE_MAP ? (size_t)RN : (size_t)NU * P.Bp; }
 
-// Multipliers of (trajectory b, step k) resp. the final ones: tiled like the derivative records,
-// [step][tile of 64][component][trajectory in tile].  The structs travel as arrays of doubles.
+// Multipliers of (trajectory b, step k) resp. the final ones: [step][tile of 64][component][trajectory in tile]
+// in both mappings (what the host copies produce).  The structs travel as arrays of doubles.
+__device__ __forceinline__ size_t mul_ix(const DevPtrs &P, int W, int k, int b) {
+    return (size_t)k * W * P.Bp + (size_t)(b >> 6) * (W * WAVE) + (b & 63);
+}
 __device__ __forceinline__ void load_mul(const DevPtrs &P, int k, int b, multipliersEl_t &m) {
     if(ME > 0) {
         double v[MEW];
-        const double *s = P.f[ILQG_F_MUL] + ix(P, ME, P.N, k, 0, b);
+        const double *s = P.f[ILQG_F_MUL] + mul_ix(P, ME, k, b);
 #pragma unroll
-        for(int i = 0; i < ME; i++) v[i] = s[i * SI];
+        for(int i = 0; i < ME; i++) v[i] = s[i * WAVE];
         __builtin_memcpy(&m, v, sizeof(double) * ME);
     }
 }
@@ -346,17 +348,17 @@ __device__ __forceinline__ void store_mul(const DevPtrs &P, int k, int b, const 
     if(ME > 0) {
         double v[MEW];
         __builtin_memcpy(v, &m, sizeof(double) * ME);
-        double *s = P.f[ILQG_F_MUL] + ix(P, ME, P.N, k, 0, b);
+        double *s = P.f[ILQG_F_MUL] + mul_ix(P, ME, k, b);
 #pragma unroll
-        for(int i = 0; i < ME; i++) s[i * SI] = v[i];
+        for(int i = 0; i < ME; i++) s[i * WAVE] = v[i];
     }
 }
 __device__ __forceinline__ void load_mul_fin(const DevPtrs &P, int b, multipliersFin_t &m) {
     if(MF > 0) {
         double v[MFW];
-        const double *s = P.f[ILQG_F_MULF] + ix(P, MF, 1, 0, 0, b);
+        const double *s = P.f[ILQG_F_MULF] + mul_ix(P, MF, 0, b);
 #pragma unroll
-        for(int i = 0; i < MF; i++) v[i] = s[i * SI];
+        for(int i = 0; i < MF; i++) v[i] = s[i * WAVE];
         __builtin_memcpy(&m, v, sizeof(double) * MF);
     }
 }
@@ -364,9 +366,9 @@ __device__ __forceinline__ void store_mul_fin(const DevPtrs &P, int b, const mul
     if(MF > 0) {
         double v[MFW];
         __builtin_memcpy(v, &m, sizeof(double) * MF);
-        double *s = P.f[ILQG_F_MULF] + ix(P, MF, 1, 0, 0, b);
+        double *s = P.f[ILQG_F_MULF] + mul_ix(P, MF, 0, b);
 #pragma unroll
-        for(int i = 0; i < MF; i++) s[i * SI] = v[i];
+        for(int i = 0; i < MF; i++) s[i * WAVE] = v[i];
     }
 }
 
@@ -436,6 +438,12 @@ __device__ __forceinline__ void set_penalty_weights(Callbacks &C, double w_l, do
 }
 __device__ __forceinline__ void load_penalty_weights(Callbacks &C, const DevPtrs &P, int b) {
     if(HAS_MUL) set_penalty_weights(C, P.f[ILQG_F_WPEN_L][b], P.f[ILQG_F_WPEN_F][b]);
+}
+// for the derivatives: the weights of the last accepted step.  A rejected step may raise the current ones
+// (iLQG.c:345-349) while the reference sweeps again over the derivatives it has; kernels that re-evaluate
+// derivatives instead of keeping them (fused backward pass, wave mapping) reproduce those with these weights.
+__device__ __forceinline__ void load_penalty_weights_der(Callbacks &C, const DevPtrs &P, int b) {
+    if(HAS_MUL) set_penalty_weights(C, P.f[ILQG_F_WPEN_L_DER][b], P.f[ILQG_F_WPEN_F_DER][b]);
 }
 // declares the callback context C and the lane's hooks H of a kernel with arguments (P, O, A)
 #define ILQG_CALLBACKS(C, H) \
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(256) void k_derivs(DevPtrs P, ilqg_dev_opts_t O, Pa
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_NEED_DERIVS][b]) return;
 
     ILQG_CALLBACKS(C, H);
-    load_penalty_weights(C, P, b);
+    load_penalty_weights_der(C, P, b);
     int ok = 1;
     if(k < P.N) {
         trajEl_t t;
@@ -716,7 +724,9 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
 #pragma unroll
             for(int i = 0; i < NX; i++) recN[NOM_X + i] = fin.x[i];
         }
-        const int ok = derivs_final(fin, nullptr, C, H, N);  // no multipliers on this path (see ilqg_dev_set_opts)
+        multipliersFin_t mf;
+        load_mul_fin(P, b, mf);
+        const int ok = derivs_final(fin, HAS_MUL ? &mf : nullptr, C, H, N);
         if(!ok || H.nonfinite != 0.0) return 2;
 #pragma unroll
         for(int i = 0; i < NX; i++) Vx[i] = fin.cx[i];
@@ -744,7 +754,9 @@ __device__ __forceinline__ int backward_sweep_fused(const DevPtrs &P, Callbacks 
         for(int i = 0; i < NX; i++) t.x[i] = xv[i];
 #pragma unroll
         for(int i = 0; i < NU; i++) t.u[i] = uv[i];
-        const int ok = derivs_step(t, nullptr, C, H, k, N, overlapped);
+        multipliersEl_t m;
+        load_mul(P, k, b, m);
+        const int ok = derivs_step(t, HAS_MUL ? &m : nullptr, C, H, k, N, overlapped);
         REC_COPY(GETF, t)
         return ok;
     };
@@ -852,6 +864,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
         return;
     }
     ILQG_CALLBACKS(C, H);
+    load_penalty_weights_der(C, P, b);
     double lambda = P.f[ILQG_F_LAMBDA][b], dlambda = P.f[ILQG_F_DLAMBDA][b];
     double dV0 = 0.0, dV1 = 0.0, g_norm = P.f[ILQG_F_GNORM][b];
     int calls = 0, rc;
@@ -947,17 +960,21 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
     if(bw >= chunk_count || b >= P.B) return;
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
     ILQG_CALLBACKS(C, H);
+    load_penalty_weights_der(C, P, b);
     tOptSet &o = C.o;
     int ok = 1;
     if(k < P.N) {
+        multipliersEl_t mk;
+        load_mul(P, k, b, mk);
+        multipliersEl_t *const mp = HAS_MUL ? &mk : nullptr;
         trajEl_t *t = P.work + (size_t)bw * P.N + k;
         if(init_consts) init_running(t, &C.o1);  // constant entries, once per buffer (init_opt, iLQG_func.tem:402-415)
         auto body = [&]() {
             for(int i = 0; i < NX; i++) t->x[i] = nomp(P, k, b)[NOM_X + i];
             for(int i = 0; i < NU; i++) t->u[i] = nomp(P, k, b)[NOM_U + i];
-            ok = calcXVariableAux(t, nullptr, k, &o);
-            ok &= calcXUVariableAux(t, nullptr, k, &o);
-            ok &= calcLAuxDeriv(t, nullptr, k, &o);
+            ok = calcXVariableAux(t, mp, k, &o);
+            ok &= calcXUVariableAux(t, mp, k, &o);
+            ok &= calcLAuxDeriv(t, mp, k, &o);
             ok &= bp_derivsL(t, k, o.p);
             limitsU(t, k, o.p, P.N);
         };
@@ -973,11 +990,14 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
 #endif
     } else {
         trajFin_t fin;
+        multipliersFin_t mfin;
+        load_mul_fin(P, b, mfin);
+        multipliersFin_t *const mfp = HAS_MUL ? &mfin : nullptr;
         init_final(&fin, &o);
         auto body = [&]() {
             for(int i = 0; i < NX; i++) fin.x[i] = nomp(P, P.N, b)[NOM_X + i];
-            ok = calcFVariableAux(&fin, nullptr, &o);
-            ok &= calcFAuxDeriv(&fin, nullptr, &o);
+            ok = calcFVariableAux(&fin, mfp, &o);
+            ok &= calcFAuxDeriv(&fin, mfp, &o);
             ok &= bp_derivsF(&fin, P.N, o.p);
         };
 #if ILQG_UNIFORM_GUARDS
@@ -1560,10 +1580,15 @@ __global__ __launch_bounds__(WAVE) void k_multipliers(DevPtrs P, ilqg_dev_opts_t
         store_mul_fin(P, b, C.o.multipliers.f);
         P.f[ILQG_F_WPEN_F][b] = C.o.w_pen_f;
     }
+    double wl_new = wl;
     if(raise) {
         const double w = wl * O.w_pen_fact1;
-        P.f[ILQG_F_WPEN_L][b] = (O.w_pen_max_l < w) ? O.w_pen_max_l : w;
+        wl_new = (O.w_pen_max_l < w) ? O.w_pen_max_l : w;
+        P.f[ILQG_F_WPEN_L][b] = wl_new;
     }
+    // the derivatives evaluated next (this trajectory was accepted, or the solve starts) see these weights
+    P.f[ILQG_F_WPEN_L_DER][b] = wl_new;
+    P.f[ILQG_F_WPEN_F_DER][b] = (MF > 0) ? C.o.w_pen_f : P.f[ILQG_F_WPEN_F][b];
 }
 
 // solver entry state (iLQG.c:226-237)
@@ -1581,6 +1606,8 @@ __global__ void k_reset(DevPtrs P, ilqg_dev_opts_t O) {
     P.i[ILQG_I_RESWEEP][b] = 0;
     P.f[ILQG_F_WPEN_L][b] = O.w_pen_init_l;
     P.f[ILQG_F_WPEN_F][b] = O.w_pen_init_f;
+    P.f[ILQG_F_WPEN_L_DER][b] = O.w_pen_init_l;
+    P.f[ILQG_F_WPEN_F_DER][b] = O.w_pen_init_f;
     if(live) P.i[ILQG_I_STATUS][b] = (O.max_iter > 0) ? ILQG_ST_ACTIVE : ILQG_ST_MAX_ITER;
 }
 
@@ -2274,12 +2301,7 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
         return 1;
     }
     if(mode == 2) NEED_PARAMS(d);
-    if(mode == 2 && HAS_MUL) {
-        // a rejected step may raise the penalty weights while the derivatives stay those of the last accepted
-        // trajectory (iLQG.c:345-349): they have to be kept, not re-evaluated
-        g_err = "ilqg_dev_backward: problems with multipliers keep their derivative records (modes 0 and 1)";
-        return 1;
-    }
+
 #if ILQG_WAVE_MAP
     if(mode != 2 && d->B > d->chunk) {
         g_err = "ilqg_dev_backward: stored records need the whole batch in the work buffer; use mode 2";
@@ -2357,7 +2379,7 @@ int ilqg_dev_update(ilqg_dev_t *d) {
 
 int ilqg_dev_iterate(ilqg_dev_t *d, int n) {
     for(int it = 0; it < n; it++) {
-        if((d->O.fuse_derivs && !HAS_MUL) || WAVE_MAP) {  // wave mapping: derivatives + sweep chunk by chunk
+        if(d->O.fuse_derivs || WAVE_MAP) {  // wave mapping: derivatives + sweep chunk by chunk
             if(ilqg_dev_backward(d, 2)) return 1;
         } else {
             if(ilqg_dev_derivs(d)) return 1;

@@ -68,6 +68,8 @@ enum {
     ILQG_F_DV1,
     ILQG_F_WPEN_L,   /* current penalty weights o->w_pen_l / o->w_pen_f (iLQG.h:78) */
     ILQG_F_WPEN_F,
+    ILQG_F_WPEN_L_DER, /* the weights the current derivatives were evaluated with: a rejected step may raise  */
+    ILQG_F_WPEN_F_DER, /* w_pen_* (iLQG.c:345-349) while the derivatives stay those of the last accepted step */
     ILQG_F_ALPHA_COST, /* [n_alpha] cost of every step size of the last line search */
     ILQG_F_COUNT
 };

@@ -58,8 +58,9 @@ const char *ilqg_batch_error(const ilqg_batch_t *c);
  *   "resweep"     0/1: repeat the reference's cost-only sweep after each accepted step
  *                 (iLQG.c:338).  Default 1 for problems with multipliers, 0 otherwise: without
  *                 multipliers that sweep returns the cost of the accepted roll-out bit for bit.
- *   "fuse_derivs" 0/1, default 1: ilqg_batch_iterate/solve evaluate the derivatives inside the
- *                 backward kernel instead of materialising the records in HBM.
+ *   "fuse_derivs" 0/1: ilqg_batch_iterate/solve evaluate the derivatives inside the backward
+ *                 kernel instead of materialising the records in HBM.  Default 1, 0 for problems
+ *                 with multipliers (measured faster there); same results either way.
  *   "ls_split"    default 3: step sizes alpha[0..ls_split) are rolled out for every trajectory,
  *                 the remaining ones only for trajectories that found none acceptable among
  *                 them; 0 = all step sizes for every trajectory.  The accepted step size is the

@@ -215,10 +215,43 @@ def test_multipliers_can_be_read_and_set(ilqg):
     a.close(); b.close()
 
 
-def test_fused_derivatives_are_refused(ilqg):
-    params, opts, x0, u0 = brachi_case(5)
-    s = solver(ilqg, "brachi", brachi_case(5))
-    s.init(x0[None], u0[None])
-    with pytest.raises(RuntimeError):
-        s.back_pass(fused=True)
+@pytest.mark.parametrize("problem,case", [("brachi_hli", brachi_hli_case(500)), ("almix", almix_case())])
+def test_fused_and_stored_derivatives_agree(ilqg, problem, case):
+    """derivatives evaluated inside the backward kernel (the default) or kept as records in HBM: identical solves.
+    The fused kernel re-evaluates them in every sweep, also after a rejected step that raised the penalty weights
+    (almix: first iteration), and must then use the weights of the last accepted step, as the reference's kept
+    derivatives do (iLQG.c:345-349)."""
+    params, opts, x0, u0 = case
+    out = []
+    for fuse in (1, 0):
+        s = ilqg.BatchSolver(problem, 0, batch=1, n_hor=len(u0), params=params, opts=dict(opts, fuse_derivs=fuse), strict=True)
+        s.init(x0[None], u0[None])
+        hist = []
+        for _ in range(opts["max_iter"]):
+            s.iterate(1)
+            hist.append((s.scalar("cost")[0], s.scalar("new_cost")[0], int(s.ints("alpha_idx")[0]), s.scalar("w_pen_l")[0],
+                         s.scalar("g_norm")[0], int(s.ints("status")[0])))
+        out.append((hist, s.x(), s.multipliers()))
+        s.close()
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2][0], out[1][2][0]) and np.array_equal(out[0][2][1], out[1][2][1])
+    assert any(h[2] > 8 for h in out[0][0]) or problem != "almix"  # the rejected iteration is part of it
+
+
+def test_wave_mapping_with_multipliers(ilqg):
+    """the one-wavefront-per-trajectory build of the hli problem (it re-evaluates derivatives chunk by chunk in every
+    iteration) against the reference's fixture"""
+    g = golden("brachi.npz")
+    tag = "li500_"
+    params, opts, x0, u0 = brachi_hli_case(500)
+    s = ilqg.BatchSolver("brachi_hli", 0, batch=3, n_hor=500, params=params, opts=opts, strict="wave")
+    assert s.problem.wave_mapping
+    s.init(np.repeat(x0[None], 3, axis=0), np.repeat(u0[None], 3, axis=0))
+    assert close(s.scalar("cost"), g[tag + "init_cost"])
+    s.solve()
+    assert np.all(s.ints("iterations") == int(g[tag + "iterations"]))
+    assert close(s.scalar("cost"), g[tag + "cost"], 1e-6)
+    assert np.abs(s.x() - g[tag + "x"]).max() < 1e-4
+    assert np.all(s.scalar("w_pen_l") == g[tag + "w_pen"][0])
     s.close()
