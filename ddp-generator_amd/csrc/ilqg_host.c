@@ -235,7 +235,9 @@ const char *ilqg_batch_error(const ilqg_batch_t *c) { return c ? c->err : g_crea
 
 static int param_len(const ilqg_batch_t *c, int i) { return paramdesc[i]->size == -1 ? c->N + 1 : paramdesc[i]->size; }
 
-/* groups = 0: automatic (ILQG_GROUPS in the environment, else 3 for large batches in the lane mapping) */
+/* groups = 0: automatic (ILQG_GROUPS in the environment, else 3 for large batches in the lane mapping: measured
+ * 128-131 it/s with 1 group, 136.6 with 3, 136-140 with 4 depending on the box; beyond the 4 hardware queues of a
+ * process the streams share queues and it collapses to 94) */
 ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int groups) {
     int i, g, per, dims[8];
     ilqg_batch_t *c = (ilqg_batch_t *)calloc(1, sizeof(*c));
