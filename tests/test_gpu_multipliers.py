@@ -239,6 +239,31 @@ def test_fused_and_stored_derivatives_agree(ilqg, problem, case):
     assert any(h[2] > 8 for h in out[0][0]) or problem != "almix"  # the rejected iteration is part of it
 
 
+def test_multipliers_across_stream_groups(ilqg):
+    """the batch split into groups on separate streams (ragged sizes): per-trajectory multipliers and weights land
+    where they belong — bit-identical to one group, reads and writes of the multiplier arrays included"""
+    B = 300  # groups are whole tiles of 64: 128 + 128 + 44
+    params, opts, x0, u0 = almix_case(batch=B)
+    ref = None
+    for groups in (1, 3):
+        s = ilqg.BatchSolver("almix", 1, batch=B, n_hor=u0.shape[1], params=params, opts=dict(opts, max_iter=12), groups=groups)
+        assert s.groups() == groups
+        s.init(x0, u0)
+        s.iterate(6)
+        run, fin = s.multipliers()
+        s.set_multipliers(run, fin)  # write back what was read: a no-op if the group offsets are right
+        s.iterate(6)
+        run, fin = s.multipliers()
+        out = (s.scalar("cost"), s.x(), run, fin, s.scalar("w_pen_l"), s.scalar("w_pen_f"), s.ints("iterations"))
+        s.close()
+        if ref is None:
+            ref = out
+        else:
+            for a, r in zip(out, ref):
+                assert np.array_equal(a, r)
+    assert np.ptp(ref[3][:, 0]) > 0  # the trajectories differ, so a misplaced group would show
+
+
 def test_wave_mapping_with_multipliers(ilqg):
     """the one-wavefront-per-trajectory build of the hli problem (it re-evaluates derivatives chunk by chunk in every
     iteration) against the reference's fixture"""
