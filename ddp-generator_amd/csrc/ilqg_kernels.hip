@@ -208,6 +208,7 @@ extern "C" {
 
 #include "ilqg_device.hpp"
 #include "ilqg_wave.hpp"
+#include "ilqg_row.hpp"
 #include "ilqg_shim.h"
 
 namespace {
@@ -226,6 +227,12 @@ constexpr int SXX = RL::SXX, SUU = RL::SUU, NXU = RL::NXU, REC = RL::SIZE, REC_H
 constexpr int FIN = NX + SXX;
 constexpr int WAVE = 64;
 constexpr bool WAVE_MAP = ILQG_WAVE_MAP;
+// the backward step of the wave mapping: row mapping (ilqg_row.hpp: products by row broadcast, no LDS operands) for
+// everything that fits one 16-lane row per block of matrix rows, else one output element per lane (ilqg_wave.hpp)
+#ifndef ILQG_ROW_STEP
+#define ILQG_ROW_STEP (N_X <= 16 && N_U <= 16)
+#endif
+constexpr bool ROW_STEP = ILQG_ROW_STEP;
 // Augmented-Lagrangian multipliers (iLQG_problem.tem:70-89): the generated structs hold nothing but doubles
 // (mu and the constraint value of the last update per constraint); empty for a problem without hle/hli/hfe/hfi.
 constexpr int ME = std::is_empty<multipliersEl_t>::value ? 0 : (int)(sizeof(multipliersEl_t) / sizeof(double));
@@ -1017,8 +1024,22 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
     if(!ok || H.nonfinite != 0.0) P.derivs_failed[b] = 1;
 }
 
+using StepLds = std::conditional_t<ROW_STEP, RowLds<(ROW_STEP ? NX : 1), (ROW_STEP ? NU : 1)>, WaveLds<NX, NU>>;
+
+// one backward step in the form that goes with the LDS block (a template, so that only that form is instantiated)
+template <class Lds>
+__device__ __forceinline__ int step_of_wave(Lds &S, const StepFields<NX, NU> &F, double *lout, double *Kout, double lambda,
+                                            int regType, double &dV0, double &dV1, double &gsum, Prof *pf) {
+    if constexpr(std::is_same<Lds, WaveLds<NX, NU>>::value) {
+        return back_step_wave<NX, NU, FULL, HX>(S, F, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
+    } else {
+        const RecordSource<NX, NU, FULL> D{F};
+        return back_step_row<NX, NU, FULL, HX>(S, D, F, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
+    }
+}
+
 // one sweep of one trajectory on one wave; returns 0 ok, 1 box-QP failed (wave-uniform)
-__device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const DevPtrs &P, int b, int bw, double lambda,
+__device__ __forceinline__ int backward_sweep_wave(StepLds &S, const DevPtrs &P, int b, int bw, double lambda,
                                                    int regType, double &dV0, double &dV1, double &g_norm) {
     const int lane = threadIdx.x & 63;
     const int N = P.N;
@@ -1055,8 +1076,7 @@ __device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const Dev
     for(int k = N - 1; k >= 0; k--) {
         if(pf) pf->probe(7);
         const StepFields<NX, NU> F = fields(k);
-        const int rc = back_step_wave<NX, NU, FULL, HX>(S, F, nomp(P, k, b) + NOM_L, nomp(P, k, b) + NOM_K, lambda,
-                                                        regType, dV0, dV1, gsum, pf);
+        const int rc = step_of_wave(S, F, nomp(P, k, b) + NOM_L, nomp(P, k, b) + NOM_K, lambda, regType, dV0, dV1, gsum, pf);
         if(rc < 1) return 1;
     }
 #ifdef ILQG_PROFILE_SECTIONS
@@ -1079,7 +1099,7 @@ __device__ __forceinline__ int backward_sweep_wave(WaveLds<NX, NU> &S, const Dev
 #endif
 __global__ __launch_bounds__(64, ILQG_WAVE_OCC) ILQG_WAVE_ATTR void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep,
                                                          int chunk_first, int chunk_count) {
-    __shared__ WaveLds<NX, NU> S;
+    __shared__ StepLds S;
     const int bw = blockIdx.x;
     const int b = chunk_first + bw;
     const int lane = threadIdx.x & 63;
