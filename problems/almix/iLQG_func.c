@@ -34,17 +34,17 @@ tParamDesc *paramdesc[]= {&p_name1, &p_name2, &p_name3, &p_name4, &p_name5, &p_n
 #define aux_hfi_1 t->hfi_1
 #define aux_pfi_1 t->pfi_1
 #define daux_dpli_2_x1 t->dpli_2_x1
-#define daux_dpli_1_x1 t->dpli_1_x1
 #define daux_dhle_1_x1 t->dhle_1_x1
 #define daux_dple_1_x1 t->dple_1_x1
+#define daux_dpli_1_x1 t->dpli_1_x1
 #define daux_dple_1_u1 t->dple_1_u1
-#define daux_dpli_2_x1x1 t->dpli_2_x1x1
 #define daux_dple_1_x1x1 t->dple_1_x1x1
+#define daux_dpli_2_x1x1 t->dpli_2_x1x1
 #define daux_dpli_1_x1x1 t->dpli_1_x1x1
 #define daux_dple_1_u1u1 t->dple_1_u1u1
 #define daux_dple_1_u1x1 t->dple_1_u1x1
-#define daux_dpfi_1_x0 t->dpfi_1_x0
 #define daux_dpfe_2_x0 t->dpfe_2_x0
+#define daux_dpfi_1_x0 t->dpfi_1_x0
 #define daux_dpfe_1_x1 t->dpfe_1_x1
 #define daux_dpfe_2_x2 t->dpfe_2_x2
 #define daux_dpfi_1_x0x0 t->dpfi_1_x0x0
@@ -61,31 +61,30 @@ static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o);
 static int bp_derivsL(trajEl_t *t, int k, double **p);
 static int bp_derivsF(trajFin_t *t, int k, double **p);
 
+/* running cost of one step, final cost, one step of the dynamics */
 static int ddpL(trajEl_t *t, int k, tOptSet *o) {
-    const double *x= t->x;
-    const double *u= t->u;
-    double **p= o->p;
+    const double *const x= t->x;
+    const double *const u= t->u;
+    double **const p= o->p;
 
     t->c= aux_ple_1 + aux_pli_1 + aux_pli_2 + p[1][0]*(u[0]*u[0]) + p[1][1]*(u[1]*u[1]) + p[2][0]*(sqrt((aux_gap*aux_gap) + 1.0) - 1.0) + p[2][1]*(x[1]*x[1]) + p[2][2]*(x[2]*x[2]);
     if(isNANorINF(t->c)) { PRNT("    @k %d: t->c in line %d is nan or inf: %g\n", k, __LINE__-1, t->c); return 0; }
-
     return 1;
 }
 
 static int ddpF(trajFin_t *t, tOptSet *o) {
-    const double *x= t->x;
+    const double *const x= t->x;
     const int k= o->n_hor;
-    double **p= o->p;
+    double **const p= o->p;
 
     t->c= aux_pfe_1 + aux_pfe_2 + aux_pfi_1 + p[0][0]*((-p[5][0] + x[0])*(-p[5][0] + x[0])) + p[0][1]*(x[1]*x[1]) + p[0][2]*((-p[5][0] + x[2])*(-p[5][0] + x[2]));
     if(isNANorINF(t->c)) { PRNT("    @k %d: t->c in line %d is nan or inf: %g\n", k, __LINE__-1, t->c); return 0; }
-
     return 1;
 }
 
 static int ddpf(double x_next[], trajEl_t *t, int k, double **p, int N) {
-    const double *x= t->x;
-    const double *u= t->u;
+    const double *const x= t->x;
+    const double *const u= t->u;
 
     x_next[0]= p[3][0]*x[1] + x[0];
     if(isNANorINF(x_next[0])) { PRNT("    @k %d: x_next[0] in line %d is nan or inf: %g\n", k, __LINE__-1, x_next[0]); return 0; }
@@ -97,162 +96,136 @@ static int ddpf(double x_next[], trajEl_t *t, int k, double **p, int N) {
 }
 
 void clampU(double *u, trajEl_t *t, int k, double **p, int N) {
-    double limit;
-    const double *x= t->x;
+    const double *const x= t->x;
+    double bound;
 
-    // constraint h[1]= a - lim[1]
-    limit= p[4][1];
-    if(u[0]>limit) u[0]= limit;
-
-    // constraint h[2]= -a + lim[0]
-    limit= p[4][0];
-    if(u[0]<limit) u[0]= limit;
-
+    /* h[1]= a - lim[1] */
+    bound= p[4][1];
+    if(u[0]>bound) u[0]= bound;
+    /* h[2]= -a + lim[0] */
+    bound= p[4][0];
+    if(u[0]<bound) u[0]= bound;
 }
 
 static void limitsU(trajEl_t *t, int k, double **p, int N) {
-    int i, j;
-    int lower_idx[N_U], upper_idx[N_U], *idx_;
-    double limit;
-    const double *x= t->x;
-    double *hx_, *h_sign;
+    const double *const x= t->x;
+    int active[2][N_U];  /* constraint that bounds input iu from below [0] / from above [1]; -1: none */
+    double bound;
+    int iu, side;
 
-    for(i= 0; i<N_U; i++) {
-        lower_idx[i]= -1;
-        upper_idx[i]= -1;
-        t->lower[i]= -INF;
-        t->upper[i]= INF;
+    for(iu= 0; iu<N_U; iu++) {
+        active[0][iu]= active[1][iu]= -1;
+        t->lower[iu]= -INF;
+        t->upper[iu]= INF;
     }
 
-    // constraint h[1]= a - lim[1]
-    limit= p[4][1];
-    if(t->upper[0]>limit) { t->upper[0]= limit; upper_idx[0]= 0; }
+    /* h[1]= a - lim[1] */
+    bound= p[4][1];
+    if(t->upper[0]>bound) { t->upper[0]= bound; active[1][0]= 0; }
+    /* h[2]= -a + lim[0] */
+    bound= p[4][0];
+    if(t->lower[0]<bound) { t->lower[0]= bound; active[0][0]= 1; }
 
-    // constraint h[2]= -a + lim[0]
-    limit= p[4][0];
-    if(t->lower[0]<limit) { t->lower[0]= limit; lower_idx[0]= 1; }
-
-    for(i= 0; i<N_U; i++) {
-        t->lower[i]-= t->u[i];
-        t->upper[i]-= t->u[i];
+    /* the solver works with the change of u */
+    for(iu= 0; iu<N_U; iu++) {
+        t->lower[iu]-= t->u[iu];
+        t->upper[iu]-= t->u[iu];
     }
 
-    for(j= 0; j<2; j++) {
-        if(j==0) {
-            idx_= lower_idx;
-            hx_= t->lower_hx;
-            h_sign= t->lower_sign;
-        } else {
-            idx_= upper_idx;
-            hx_= t->upper_hx;
-            h_sign= t->upper_sign;
-        }
-        for(i= 0; i<N_U; i++, hx_+= N_X, h_sign++) {
-            switch(idx_[i]) {
-                case -1:
-                    h_sign[0]= 0.0;
-                    break;
+    for(side= 0; side<2; side++) {
+        double *const sign= side? t->upper_sign: t->lower_sign;
+        double *const grad= side? t->upper_hx: t->lower_hx;
+        for(iu= 0; iu<N_U; iu++) {
+            double *const hx_= grad + iu*N_X;
+            switch(active[side][iu]) {
                 case 0:
                     hx_[0]= 0.0;
                     hx_[1]= 0.0;
                     hx_[2]= 0.0;
-                    h_sign[0]= 1.0;
+                    sign[iu]= 1.0;
                     break;
                 case 1:
                     hx_[0]= 0.0;
                     hx_[1]= 0.0;
                     hx_[2]= 0.0;
-                    h_sign[0]= -1.0;
+                    sign[iu]= -1.0;
                     break;
+                default:  /* unbounded on this side: the gradient is not used */
+                    sign[iu]= 0.0;
             }
         }
     }
 }
 
+/* Roll-out of candidate trajectory c (line_search.c:40, iLQG.c:338, iLQG_mex.c:116).
+ * alpha != 0: u = u_nom + alpha*l + L (x - x_nom) with the gains of the nominal trajectory, accumulated state by
+ * state; alpha == 0: the nominal inputs as they are.  cost_only: x and u of c are kept, only the cost is summed.
+ * csum[0] holds the cost summed so far also when a NaN/Inf guard ends the sweep (return 0). */
 int forward_pass(traj_t *c, tOptSet *o, double alpha, double *csum, int cost_only) {
-    int i, k, j;
-    double dx;
-    double *x0= o->x0;
-    int N= o->n_hor;
-    double **params= o->p;
-
-    trajEl_t *t= o->nominal->t;
-    trajEl_t *ct= c->t;
-    trajFin_t *cf= &c->f;
-
-    multipliersEl_t *m= o->multipliers.t;
-    multipliersFin_t *mf= &o->multipliers.f;
-
-    double *x_next;
+    const int n_steps= o->n_hor;
+    const int rollout= !cost_only;
+    int k, ix, iu;
 
     csum[0]= 0.0;
+    if(rollout)
+        for(ix= 0; ix<N_X; ix++) c->t[0].x[ix]= o->x0[ix];
 
-    if(!cost_only)
-        for(i= 0; i<N_X; i++) ct->x[i]= x0[i];
+    for(k= 0; k<n_steps; k++) {
+        const trajEl_t *const ref= o->nominal->t + k;
+        trajEl_t *const cur= c->t + k;
+        multipliersEl_t *const mul= o->multipliers.t + k;
 
-    for(k= 0; k<N; k++, t++, ct++, m++) {
-        if(!cost_only) {
+        if(rollout) {
             if(alpha) {
-                /* u = u_nom + alpha*l + L*(x - x_nom), accumulated state by state */
-                for(j= 0; j<N_U; j++)
-                    ct->u[j]= t->u[j] + t->l[j]*alpha;
-                for(i= 0; i<N_X; i++) {
-                    dx= ct->x[i] - t->x[i];
-                    for(j= 0; j<N_U; j++)
-                        ct->u[j]+= t->L[MAT_IDX(j, i, N_U)]*dx;
+                for(iu= 0; iu<N_U; iu++)
+                    cur->u[iu]= ref->u[iu] + ref->l[iu]*alpha;
+                for(ix= 0; ix<N_X; ix++) {
+                    const double dev= cur->x[ix] - ref->x[ix];
+                    for(iu= 0; iu<N_U; iu++)
+                        cur->u[iu]+= ref->L[MAT_IDX(iu, ix, N_U)]*dev;
                 }
             } else {
-                for(j= 0; j<N_U; j++)
-                    ct->u[j]= t->u[j];
+                for(iu= 0; iu<N_U; iu++)
+                    cur->u[iu]= ref->u[iu];
             }
         }
-        if(!calcXVariableAux(ct, m, k, o)) return 0;
-
-        if(!cost_only)
-            clampU(ct->u, ct, k, params, N);
-        if(!calcXUVariableAux(ct, m, k, o)) return 0;
-
-        if(!cost_only) {
-            x_next= (k>=N-1)? cf->x: (ct+1)->x;
-            if(!ddpf(x_next, ct, k, params, N)) return 0;
-        }
-
-        if(!ddpL(ct, k, o)) return 0;
-        csum[0]+= ct->c;
+        if(!calcXVariableAux(cur, mul, k, o)) return 0;
+        if(rollout) clampU(cur->u, cur, k, o->p, n_steps);
+        if(!calcXUVariableAux(cur, mul, k, o)) return 0;
+        if(rollout && !ddpf((k+1<n_steps)? c->t[k+1].x: c->f.x, cur, k, o->p, n_steps)) return 0;
+        if(!ddpL(cur, k, o)) return 0;
+        csum[0]+= cur->c;
     }
 
-    if(!calcFVariableAux(cf, mf, o)) return 0;
-    if(!ddpF(cf, o)) return 0;
-    csum[0]+= cf->c;
-
+    if(!calcFVariableAux(&c->f, &o->multipliers.f, o)) return 0;
+    if(!ddpF(&c->f, o)) return 0;
+    csum[0]+= c->f.c;
     return 1;
 }
 
+/* Derivatives along the nominal trajectory (iLQG.c:247): the final step, then the running steps from the end of
+ * the horizon to its start, each with the box its input constraints leave around the nominal input. */
 int calc_derivs(tOptSet *o) {
+    const int n_steps= o->n_hor;
+    traj_t *const nom= o->nominal;
     int k;
-    int N= o->n_hor;
 
-    trajEl_t *t= o->nominal->t + N - 1;
-    trajFin_t *f= &o->nominal->f;
+    if(!calcFAuxDeriv(&nom->f, &o->multipliers.f, o)) return 0;
+    if(!bp_derivsF(&nom->f, n_steps, o->p)) return 0;
 
-    multipliersEl_t *m= o->multipliers.t + N - 1;
-    multipliersFin_t *mf= &o->multipliers.f;
-
-    if(!calcFAuxDeriv(f, mf, o)) return 0;
-    if(!bp_derivsF(f, N, o->p)) return 0;
-
-    for(k= N-1; k>=0; k--, t--, m--) {
-        if(!calcLAuxDeriv(t, m, k, o)) return 0;
-        if(!bp_derivsL(t, k, o->p)) return 0;
-
-        limitsU(t, k, o->p, N);
+    for(k= n_steps; k-->0; ) {
+        trajEl_t *const el= nom->t + k;
+        if(!calcLAuxDeriv(el, o->multipliers.t + k, k, o)) return 0;
+        if(!bp_derivsL(el, k, o->p)) return 0;
+        limitsU(el, k, o->p, n_steps);
     }
     return 1;
 }
 
+/* auxiliary variables: members of the step's element, evaluated once and reused by everything that follows */
 static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
-    const double *x= t->x;
-    double **p= o->p;
+    const double *const x= t->x;
+    double **const p= o->p;
     const double w_pen= o->w_pen_l;
 
     aux_gap= x[0] - x[2];
@@ -279,9 +252,9 @@ static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) 
 }
 
 static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
-    const double *x= t->x;
-    const double *u= t->u;
-    double **p= o->p;
+    const double *const x= t->x;
+    const double *const u= t->u;
+    double **const p= o->p;
     const double w_pen= o->w_pen_l;
 
     aux_hle_1= -1.0/2.0*p[6][k]*x[1] + u[1];
@@ -292,8 +265,8 @@ static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o)
 }
 
 static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
-    const double *x= t->x;
-    double **p= o->p;
+    const double *const x= t->x;
+    double **const p= o->p;
     const double w_pen= o->w_pen_f;
     const int k= o->n_hor;
 
@@ -320,10 +293,10 @@ static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
 }
 
 static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
-    const double *x= t->x;
-    const double *u= t->u;
+    const double *const x= t->x;
+    const double *const u= t->u;
     const double w_pen= o->w_pen_l;
-    double **p= o->p;
+    double **const p= o->p;
 
     daux_dpli_2_x1= -((aux_hli_2 >= 0.0) ? (
    aux_hli_2*m->mu_li[1]*w_pen + m->mu_li[1]*(aux_hli_2*w_pen + 1.0)
@@ -332,6 +305,10 @@ static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
    aux_hli_2*m->mu_li[1]*w_pen/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0)) + m->mu_li[1]/(-aux_hli_2*w_pen + 1.0)
 ));
     if(isNANorINF(daux_dpli_2_x1)) { PRNT("    @k %d: daux_dpli_2_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpli_2_x1); return 0; }
+    daux_dhle_1_x1= -1.0/2.0*p[6][k];
+    if(isNANorINF(daux_dhle_1_x1)) { PRNT("    @k %d: daux_dhle_1_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dhle_1_x1); return 0; }
+    daux_dple_1_x1= daux_dhle_1_x1*(1.0*aux_hle_1*w_pen + m->mu_le[0]);
+    if(isNANorINF(daux_dple_1_x1)) { PRNT("    @k %d: daux_dple_1_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dple_1_x1); return 0; }
     daux_dpli_1_x1= ((aux_hli_1 >= 0.0) ? (
    aux_hli_1*m->mu_li[0]*w_pen + m->mu_li[0]*(aux_hli_1*w_pen + 1.0)
 )
@@ -339,12 +316,10 @@ static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
    aux_hli_1*m->mu_li[0]*w_pen/((-aux_hli_1*w_pen + 1.0)*(-aux_hli_1*w_pen + 1.0)) + m->mu_li[0]/(-aux_hli_1*w_pen + 1.0)
 ));
     if(isNANorINF(daux_dpli_1_x1)) { PRNT("    @k %d: daux_dpli_1_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpli_1_x1); return 0; }
-    daux_dhle_1_x1= -1.0/2.0*p[6][k];
-    if(isNANorINF(daux_dhle_1_x1)) { PRNT("    @k %d: daux_dhle_1_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dhle_1_x1); return 0; }
-    daux_dple_1_x1= daux_dhle_1_x1*(1.0*aux_hle_1*w_pen + m->mu_le[0]);
-    if(isNANorINF(daux_dple_1_x1)) { PRNT("    @k %d: daux_dple_1_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dple_1_x1); return 0; }
     daux_dple_1_u1= 1.0*aux_hle_1*w_pen + m->mu_le[0];
     if(isNANorINF(daux_dple_1_u1)) { PRNT("    @k %d: daux_dple_1_u1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dple_1_u1); return 0; }
+    daux_dple_1_x1x1= 1.0*(daux_dhle_1_x1*daux_dhle_1_x1)*w_pen;
+    if(isNANorINF(daux_dple_1_x1x1)) { PRNT("    @k %d: daux_dple_1_x1x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dple_1_x1x1); return 0; }
     daux_dpli_2_x1x1= ((aux_hli_2 >= 0.0) ? (
    2.0*m->mu_li[1]*w_pen
 )
@@ -352,8 +327,6 @@ static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
    2.0*aux_hli_2*m->mu_li[1]*(w_pen*w_pen)/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0)) + 2.0*m->mu_li[1]*w_pen/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0))
 ));
     if(isNANorINF(daux_dpli_2_x1x1)) { PRNT("    @k %d: daux_dpli_2_x1x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpli_2_x1x1); return 0; }
-    daux_dple_1_x1x1= 1.0*(daux_dhle_1_x1*daux_dhle_1_x1)*w_pen;
-    if(isNANorINF(daux_dple_1_x1x1)) { PRNT("    @k %d: daux_dple_1_x1x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dple_1_x1x1); return 0; }
     daux_dpli_1_x1x1= ((aux_hli_1 >= 0.0) ? (
    2.0*m->mu_li[0]*w_pen
 )
@@ -371,10 +344,10 @@ static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
 }
 
 static int bp_derivsL(trajEl_t *t, int k, double **p) {
-    const double *x= t->x;
-    const double *u= t->u;
+    const double *const x= t->x;
+    const double *const u= t->u;
 
-// derivatives of f
+    /* dynamics */
     t->fx[4]= -3.0/2.0*p[3][0]*(x[1]*x[1]) + 1.0;
     if(isNANorINF(t->fx[4])) { PRNT("    @k %d: t->fx[4] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fx[4]); return 0; }
 
@@ -384,8 +357,7 @@ static int bp_derivsL(trajEl_t *t, int k, double **p) {
     if(isNANorINF(t->fxx[8])) { PRNT("    @k %d: t->fxx[8] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fxx[8]); return 0; }
 
 #endif
-
-// derivatives of L
+    /* cost */
     t->cx[0]= aux_gap*p[2][0]/sqrt((aux_gap*aux_gap) + 1.0);
     if(isNANorINF(t->cx[0])) { PRNT("    @k %d: t->cx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[0]); return 0; }
     t->cx[1]= daux_dple_1_x1 + daux_dpli_1_x1 + daux_dpli_2_x1 + 2.0*p[2][1]*x[1];
@@ -417,11 +389,13 @@ static int bp_derivsL(trajEl_t *t, int k, double **p) {
 }
 
 static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
-    const double *x= t->x;
+    const double *const x= t->x;
     const double w_pen= o->w_pen_f;
-    double **p= o->p;
+    double **const p= o->p;
     const int k= o->n_hor;
 
+    daux_dpfe_2_x0= 1.0*aux_hfe_2*w_pen + m->mu_fe[1];
+    if(isNANorINF(daux_dpfe_2_x0)) { PRNT("    @k %d: daux_dpfe_2_x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_2_x0); return 0; }
     daux_dpfi_1_x0= ((aux_hfi_1 >= 0.0) ? (
    aux_hfi_1*m->mu_fi[0]*w_pen + m->mu_fi[0]*(aux_hfi_1*w_pen + 1.0)
 )
@@ -429,8 +403,6 @@ static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
    aux_hfi_1*m->mu_fi[0]*w_pen/((-aux_hfi_1*w_pen + 1.0)*(-aux_hfi_1*w_pen + 1.0)) + m->mu_fi[0]/(-aux_hfi_1*w_pen + 1.0)
 ));
     if(isNANorINF(daux_dpfi_1_x0)) { PRNT("    @k %d: daux_dpfi_1_x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfi_1_x0); return 0; }
-    daux_dpfe_2_x0= 1.0*aux_hfe_2*w_pen + m->mu_fe[1];
-    if(isNANorINF(daux_dpfe_2_x0)) { PRNT("    @k %d: daux_dpfe_2_x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_2_x0); return 0; }
     daux_dpfe_1_x1= 1.0*aux_hfe_1*w_pen + m->mu_fe[0];
     if(isNANorINF(daux_dpfe_1_x1)) { PRNT("    @k %d: daux_dpfe_1_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_1_x1); return 0; }
     daux_dpfe_2_x2= -1.0*aux_hfe_2*w_pen - m->mu_fe[1];
@@ -454,7 +426,7 @@ static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
 }
 
 static int bp_derivsF(trajFin_t *t, int k, double **p) {
-    const double *x= t->x;
+    const double *const x= t->x;
 
     t->cx[0]= daux_dpfe_2_x0 + daux_dpfi_1_x0 + p[0][0]*(-2.0*p[5][0] + 2.0*x[0]);
     if(isNANorINF(t->cx[0])) { PRNT("    @k %d: t->cx[0] in line %d is nan or inf: %g\n", k, __LINE__-1, t->cx[0]); return 0; }
@@ -474,15 +446,16 @@ static int bp_derivsF(trajFin_t *t, int k, double **p) {
     return 1;
 }
 
+/* constant entries of every element of a trajectory buffer */
 static int init_running(trajEl_t *t, tOptSet *o) {
-    int k;
-    double **p= o->p;
+    double **const p= o->p;
+    trajEl_t *const end= t + o->n_hor;
+    int k= 0;
 
-    for(k= 0; k<o->n_hor; k++, t++) {
+    for(; t<end; t++, k++) {
 #if FULL_DDP
 #endif
-
-// derivatives of L
+        /* cost */
 
         t->cxx[1]= 0.0;
         t->cxx[4]= 0.0;
@@ -498,7 +471,7 @@ static int init_running(trajEl_t *t, tOptSet *o) {
         t->cxu[3]= 0.0;
         t->cxu[5]= 0.0;
 
-// derivatives of f
+        /* dynamics */
         t->fx[0]= 1.0;
         t->fx[1]= -1.0/4.0*p[3][0];
         if(isNANorINF(t->fx[1])) { PRNT("    @k %d: t->fx[1] in line %d is nan or inf: %g\n", k, __LINE__-1, t->fx[1]); return 0; }
@@ -541,97 +514,87 @@ static int init_running(trajEl_t *t, tOptSet *o) {
         t->fxx[16]= 0.0;
         t->fxx[17]= 0.0;
 
-        { int i_; for(i_= 0; i_<N_X*sizeofQuu; i_++) t->fuu[i_]= 0.0; }
+        { int e_; for(e_= 0; e_<N_X*sizeofQuu; e_++) t->fuu[e_]= 0.0; }
 
-        { int i_; for(i_= 0; i_<N_X*sizeofQxu; i_++) t->fxu[i_]= 0.0; }
+        { int e_; for(e_= 0; e_<N_X*sizeofQxu; e_++) t->fxu[e_]= 0.0; }
 
 #endif
     }
-
     return 1;
 }
 
 static int init_final(trajFin_t *t, tOptSet *o) {
-    double **p= o->p;
+    double **const p= o->p;
     const int k= o->n_hor;
 
 
     t->cxx[1]= 0.0;
     t->cxx[4]= 0.0;
-
     return 1;
 }
 
 int init_trajectory(traj_t *t, tOptSet *o) {
-    if(!init_running(t->t, o)) return 0;
-    if(!init_final(&t->f, o)) return 0;
-
-    return 1;
+    return init_running(t->t, o) && init_final(&t->f, o);
 }
 
 static int init_multipliers_running(tOptSet *o) {
     multipliersEl_t *m= o->multipliers.t;
-    int k, i;
+    multipliersEl_t *const end= m + o->n_hor;
+    int i;
 
-    for(k= 0; k<o->n_hor; k++, m++) {
+    for(; m<end; m++) {
         for(i= 0; i<1; i++) { m->mu_le[i]= 0.0; m->last_hle[i]= 0.0; }
         for(i= 0; i<2; i++) { m->mu_li[i]= 1.0; m->last_hli[i]= 0.0; }
     }
-
     return 1;
 }
 
 static int init_multipliers_final(tOptSet *o) {
-    multipliersFin_t *m= &o->multipliers.f;
+    multipliersFin_t *const m= &o->multipliers.f;
     int i;
 
     for(i= 0; i<2; i++) { m->mu_fe[i]= 0.0; m->last_hfe[i]= 0.0; }
     for(i= 0; i<1; i++) { m->mu_fi[i]= 1.0; m->last_hfi[i]= 0.0; }
-
     return 1;
 }
 
 int init_multipliers(tOptSet *o) {
-    if(!init_multipliers_running(o)) return 0;
-    if(!init_multipliers_final(o)) return 0;
-
-    return 1;
+    return init_multipliers_running(o) && init_multipliers_final(o);
 }
 
+/* iLQG_mex.c:108: constants of every trajectory buffer; buffer 0 starts as the nominal trajectory, the
+ * others as line-search candidates; multipliers at their start values */
 int init_opt(tOptSet *o) {
-    int i;
+    int b;
 
-    for(i= 0; i<NUMBER_OF_THREADS+1; i++)
-        if(!init_trajectory(&o->trajectories[i], o)) return 0;
+    for(b= 0; b<=NUMBER_OF_THREADS; b++) {
+        if(!init_trajectory(&o->trajectories[b], o)) return 0;
+        if(b==0) o->nominal= &o->trajectories[0];
+        else o->candidates[b-1]= &o->trajectories[b];
+    }
+    return init_multipliers(o);
+}
 
-    o->nominal= &o->trajectories[0];
-    for(i= 1; i<NUMBER_OF_THREADS+1; i++)
-        o->candidates[i-1]= &o->trajectories[i];
-
-    if(!init_multipliers(o)) return 0;
-
-    return 1;
+/* a violation v stalls: above the tolerance and not smaller than 1/w_pen_fact1 of the one remembered */
+static int violation_stalls(double v, double last, const tOptSet *o) {
+    return v>o->tolConstraint && o->w_pen_fact1*v>last;
 }
 
 static int update_multipliers_running(tOptSet *o, int init) {
     trajEl_t *t= o->nominal->t;
     multipliersEl_t *m= o->multipliers.t;
     const double w_pen= o->w_pen_l;
-    double **p= o->p;
-    int increase_pen= 0;
-    int k;
+    double **const p= o->p;
+    int stalled= 0, k;
 
-    for(k= 0; k<o->n_hor; k++, m++, t++) {
-        if(fabs(aux_hle_1)>o->tolConstraint && o->w_pen_fact1*fabs(aux_hle_1)>fabs(m->last_hle[0])) increase_pen= 1;
+    for(k= 0; k<o->n_hor; k++, t++, m++) {
+        stalled|= violation_stalls(fabs(aux_hle_1), fabs(m->last_hle[0]), o);
         m->last_hle[0]= aux_hle_1;
-
-        if(aux_hli_1>o->tolConstraint && o->w_pen_fact1*aux_hli_1>m->last_hli[0]) increase_pen= 1;
+        stalled|= violation_stalls(aux_hli_1, m->last_hli[0], o);
         m->last_hli[0]= aux_hli_1;
-
-        if(aux_hli_2>o->tolConstraint && o->w_pen_fact1*aux_hli_2>m->last_hli[1]) increase_pen= 1;
+        stalled|= violation_stalls(aux_hli_2, m->last_hli[1], o);
         m->last_hli[1]= aux_hli_2;
-
-        if(init) return 1;
+        if(init) return 1;  /* solver entry: the violations of the first element are remembered, nothing else */
         m->mu_le[0]= aux_hle_1*w_pen + m->mu_le[0];
         if(isNANorINF(m->mu_le[0])) { PRNT("    @k %d: m->mu_le[0] in line %d is nan or inf: %g\n", k, __LINE__-1, m->mu_le[0]); return 0; }
         if(aux_hli_1>=0) {
@@ -641,7 +604,6 @@ static int update_multipliers_running(tOptSet *o, int init) {
             m->mu_li[0]= m->mu_li[0]/((-aux_hli_1*w_pen + 1.0)*(-aux_hli_1*w_pen + 1.0));
             if(isNANorINF(m->mu_li[0])) { PRNT("    @k %d: m->mu_li[0] in line %d is nan or inf: %g\n", k, __LINE__-1, m->mu_li[0]); return 0; }
         }
-
         if(aux_hli_2>=0) {
             m->mu_li[1]= m->mu_li[1]*(2.0*aux_hli_2*w_pen + 1.0);
             if(isNANorINF(m->mu_li[1])) { PRNT("    @k %d: m->mu_li[1] in line %d is nan or inf: %g\n", k, __LINE__-1, m->mu_li[1]); return 0; }
@@ -649,35 +611,28 @@ static int update_multipliers_running(tOptSet *o, int init) {
             m->mu_li[1]= m->mu_li[1]/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0));
             if(isNANorINF(m->mu_li[1])) { PRNT("    @k %d: m->mu_li[1] in line %d is nan or inf: %g\n", k, __LINE__-1, m->mu_li[1]); return 0; }
         }
-
     }
-
-    if(!init && increase_pen)
+    if(!init && stalled)
         o->w_pen_l= min(o->w_pen_max_l, o->w_pen_l*o->w_pen_fact1);
-
     return 1;
 }
 
 static int update_multipliers_final(tOptSet *o, int init) {
-    trajFin_t *t= &o->nominal->f;
-    multipliersFin_t *m= &o->multipliers.f;
+    trajFin_t *const t= &o->nominal->f;
+    multipliersFin_t *const m= &o->multipliers.f;
     const double w_pen= o->w_pen_f;
-    double **p= o->p;
-    int increase_pen= 0;
-    int k= o->n_hor;
+    double **const p= o->p;
+    const int k= o->n_hor;
+    int stalled= 0;
 
-    if(fabs(aux_hfe_1)>o->tolConstraint && o->w_pen_fact1*fabs(aux_hfe_1)>fabs(m->last_hfe[0])) increase_pen= 1;
+    stalled|= violation_stalls(fabs(aux_hfe_1), fabs(m->last_hfe[0]), o);
     m->last_hfe[0]= aux_hfe_1;
-
-    if(fabs(aux_hfe_2)>o->tolConstraint && o->w_pen_fact1*fabs(aux_hfe_2)>fabs(m->last_hfe[1])) increase_pen= 1;
+    stalled|= violation_stalls(fabs(aux_hfe_2), fabs(m->last_hfe[1]), o);
     m->last_hfe[1]= aux_hfe_2;
-
-    if(aux_hfi_1>o->tolConstraint && o->w_pen_fact1*aux_hfi_1>m->last_hfi[0]) increase_pen= 1;
+    stalled|= violation_stalls(aux_hfi_1, m->last_hfi[0], o);
     m->last_hfi[0]= aux_hfi_1;
-
-    if(!init && increase_pen)
+    if(!init && stalled)
         o->w_pen_f= min(o->w_pen_max_f, o->w_pen_f*o->w_pen_fact1);
-
     if(init) return 1;
     m->mu_fe[0]= aux_hfe_1*w_pen + m->mu_fe[0];
     if(isNANorINF(m->mu_fe[0])) { PRNT("    @k %d: m->mu_fe[0] in line %d is nan or inf: %g\n", k, __LINE__-1, m->mu_fe[0]); return 0; }
@@ -690,21 +645,15 @@ static int update_multipliers_final(tOptSet *o, int init) {
         m->mu_fi[0]= m->mu_fi[0]/((-aux_hfi_1*w_pen + 1.0)*(-aux_hfi_1*w_pen + 1.0));
         if(isNANorINF(m->mu_fi[0])) { PRNT("    @k %d: m->mu_fi[0] in line %d is nan or inf: %g\n", k, __LINE__-1, m->mu_fi[0]); return 0; }
     }
-
     return 1;
 }
 
+/* iLQG.c:236,337: multipliers of the running constraints, then of the final ones */
 int update_multipliers(tOptSet *o, int init) {
-    if(!update_multipliers_running(o, init)) return 0;
-    if(!update_multipliers_final(o, init)) return 0;
-
-    return 1;
+    return update_multipliers_running(o, init) && update_multipliers_final(o, init);
 }
 
-int get_g_size() {
-    return(0);
-}
+/* no outputs g are defined by this generator (iLQG_func.tem:511-521) */
+int get_g_size() { return 0; }
 
-int calcG(double g[], trajEl_t *t, int k, double **p) {
-    return(1);
-}
+int calcG(double g[], trajEl_t *t, int k, double **p) { return 1; }

@@ -23,6 +23,7 @@
  * which are then treated as the general case) */
 #define ILQG_PROBLEM_NAME "AlMix"
 #define ILQG_STATE_DEPENDENT_LIMITS 0
+#define ILQG_TENSOR_NBASIS 0  /* > 0: iLQG_func.c has the factored tensor tables */
 
 typedef struct {
     double x[N_X];
@@ -57,12 +58,12 @@ typedef struct {
     double hli_2;
     double pli_2;
     double dpli_2_x1;
-    double dpli_1_x1;
     double dhle_1_x1;
     double dple_1_x1;
+    double dpli_1_x1;
     double dple_1_u1;
-    double dpli_2_x1x1;
     double dple_1_x1x1;
+    double dpli_2_x1x1;
     double dpli_1_x1x1;
     double dple_1_u1u1;
     double dple_1_u1x1;
@@ -83,8 +84,8 @@ typedef struct {
     double pfe_2;
     double hfi_1;
     double pfi_1;
-    double dpfi_1_x0;
     double dpfe_2_x0;
+    double dpfi_1_x0;
     double dpfe_1_x1;
     double dpfe_2_x2;
     double dpfi_1_x0x0;

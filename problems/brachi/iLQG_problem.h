@@ -23,6 +23,7 @@
  * which are then treated as the general case) */
 #define ILQG_PROBLEM_NAME "Brachi"
 #define ILQG_STATE_DEPENDENT_LIMITS 0
+#define ILQG_TENSOR_NBASIS 0  /* > 0: iLQG_func.c has the factored tensor tables */
 
 typedef struct {
     double x[N_X];

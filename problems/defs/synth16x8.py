@@ -17,6 +17,7 @@ N_X, N_U = 16, 8
 def build(Problem):
     P = Problem("Synth16x8")
     P.fast = True  # skip sympy.simplify on the ~5 000 tensor entries
+    P.cse = True   # name the products the entries share; factored tensor tables for the batched back-end
     x = P.states(" ".join("x%d" % i for i in range(N_X)))
     u = P.inputs(" ".join("u%d" % i for i in range(N_U)))
     h = P.scalar("h")

@@ -410,21 +410,22 @@ def almix_goldens():
     np.savez_compressed(os.path.join(HERE, "almix.npz"), **out)
 
 
-def main():
+def main(argv):
+    """all fixtures, or only the named groups: brachi almix kernels car lockstep hx regtype2 synth"""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    brachi_goldens()
-    almix_goldens()
-    kernel_goldens(Kernels(lib_path("ref", full_ddp=0)))
-    for fd in (0, 1):
-        single_pass_goldens(fd)
-        solve_goldens(fd)
-    lockstep_goldens(0)
-    for fd in (0, 1):
-        hx_goldens(fd)
-    regtype2_goldens()
-    for fd in (0, 1):
-        synth_goldens(fd)
+    groups = {
+        "brachi": brachi_goldens,
+        "almix": almix_goldens,
+        "kernels": lambda: kernel_goldens(Kernels(lib_path("ref", full_ddp=0))),
+        "car": lambda: [(single_pass_goldens(fd), solve_goldens(fd)) for fd in (0, 1)],
+        "lockstep": lambda: lockstep_goldens(0),
+        "hx": lambda: [hx_goldens(fd) for fd in (0, 1)],
+        "regtype2": regtype2_goldens,
+        "synth": lambda: [synth_goldens(fd) for fd in (0, 1)],
+    }
+    for name in (argv or list(groups)):
+        groups[name]()
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

@@ -60,6 +60,7 @@ class Problem:
         # final equality / inequality; may depend on x (running ones also on u) and parameters
         self.hle, self.hli, self.hfe, self.hfi = [], [], [], []
         self.fast = False # True: skip sympy.simplify (large generated problems)
+        self.cse = False  # True: name the products shared by derivative entries (SharedTerms), factored tensor tables
 
     def states(self, names):
         self.x = list(sp.symbols(names, real=True, seq=True))
@@ -267,6 +268,35 @@ class Emitter:
             if prob.params[nm] == -1:
                 self.time_syms.add(sp.Symbol("%s[k]" % nm, real=True))
         self._derive()
+        self.cse = SharedTerms(self) if prob.cse else None
+        self.tensor_tables = self._factor_tensors() if prob.cse else None
+
+    def _factor_tensors(self):
+        """{'basis': [products], 'xx': (coefficients, basis numbers), 'uu': ..., 'xu': ...} in the array order of
+        fxx / fuu / fxu if every entry is one number times one product (or zero), else None"""
+        st = SharedTerms(self)
+        basis, number, tables = [], {}, {}
+        for nm, ten in (("xx", self.fxx), ("uu", self.fuu), ("xu", self.fxu)):
+            coefs, bases = [], []
+            for lhs, e in self.jaco2_items("f" + nm, ten):
+                terms = st.split(e) if e != 0 else []
+                if len(terms) > 1 or (terms and terms[0][1] is None):
+                    return None
+                if not terms:
+                    coefs.append(0.0)
+                    bases.append(0)
+                    continue
+                coef, prod = terms[0]
+                if prod not in number:
+                    number[prod] = len(basis)
+                    basis.append(prod)
+                coefs.append(float(coef))
+                bases.append(number[prod])
+            tables[nm] = (coefs, bases)
+        if not basis or len(basis) > 255:
+            return None
+        tables["basis"] = basis
+        return tables
 
     # ---- augmented-Lagrangian terms (genenerator_main.mac:46-124) ----------
     def _constraints(self):
@@ -389,22 +419,26 @@ class Emitter:
         return len(sp.sympify(e).free_symbols) == 0
 
     # ---- statement printers ---------------------------------------------
-    def assign(self, lhs, e, ind=4, ret="0", guard=True):
+    def assign(self, lhs, e, ind=4, ret="0", guard=True, lhs_name=None):
+        """lhs= e; followed by the NaN/Inf guard of genenerator_main.mac:189-199 unless e is a plain number
+        (lhs_name: what the guard tests and prints when lhs is a declaration)"""
         pad = " " * ind
         e = sp.sympify(e)
         rhs = cexpr(self.csub(e, None))
         out = "%s%s= %s;\n" % (pad, lhs, rhs)
         if guard and not self.is_const_number(e):
+            v = lhs_name or lhs
             out += ('%sif(isNANorINF(%s)) { PRNT("    @k %%d: %s in line %%d is nan or inf: %%g\\n", k, __LINE__-1, %s); return %s; }\n'
-                    % (pad, lhs, lhs.replace('"', ""), lhs, ret))
+                    % (pad, v, v.replace('"', ""), v, ret))
         return out
 
-    def block(self, items, want_time_var, ind=4):
-        """items: list of (lhs, expr). emit those whose time-variance matches."""
+    def block(self, items, want_time_var, ind=4, cse=None):
+        """items: list of (lhs, expr). emit those whose time-variance matches; cse: a SharedTerms that names
+        the products the entries have in common"""
         out = ""
         for lhs, e in items:
             if want_time_var is None or self.is_time_var(e) == want_time_var:
-                out += self.assign(lhs, e, ind)
+                out += self.assign(lhs, cse.rewrite(e) if cse else e, ind)
         return out
 
     def jaco_items(self, name, mat):
@@ -494,6 +528,7 @@ class Emitter:
  * which are then treated as the general case) */
 #define ILQG_PROBLEM_NAME "{self.p.name}"
 #define ILQG_STATE_DEPENDENT_LIMITS {1 if self.has_hx else 0}
+#define ILQG_TENSOR_NBASIS {len(self.tensor_tables["basis"]) if self.tensor_tables else 0}  /* > 0: iLQG_func.c has the factored tensor tables */
 
 typedef struct {{
     double x[N_X];
@@ -551,6 +586,23 @@ typedef struct {{
 #endif // ILQG_PROBLEM_H
 """
 
+    # ---- iLQG_func.c ---------------------------------------------------------
+    # Function names, signatures, what each function computes and in which order are the reference's contract
+    # (iLQG_func.tem:40-521, the solver and the MEX shell call them by name); the bodies below are written for this
+    # generator.  Inside every function the expressions printed by csub() refer to x[], u[], p[][], k, m-> and w_pen,
+    # so each function that evaluates expressions declares those names first (prologue()).
+    PROLOGUE = {
+        "x": "const double *const x= t->x;",
+        "u": "const double *const u= t->u;",
+        "p": "double **const p= o->p;",
+        "wl": "const double w_pen= o->w_pen_l;",
+        "wf": "const double w_pen= o->w_pen_f;",
+        "kN": "const int k= o->n_hor;",
+    }
+
+    def prologue(self, *names):
+        return "".join("    %s\n" % self.PROLOGUE[n] for n in names) + "\n"
+
     def func_c(self):
         p, n, m = self.p, self.n, self.m
         o = []
@@ -575,352 +627,398 @@ typedef struct {{
           "static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o);\n"
           "static int bp_derivsL(trajEl_t *t, int k, double **p);\n"
           "static int bp_derivsF(trajFin_t *t, int k, double **p);\n\n")
+        w(self.emit_cost_and_dynamics())
+        w(self.emit_input_limits())
+        w(self.emit_sweeps())
+        w(self.emit_auxiliaries())
+        w(self.emit_derivatives())
+        w(self.emit_constants())
+        w(self.emit_setup())
+        w(self.multiplier_update())
+        w("/* iLQG.c:236,337: multipliers of the running constraints, then of the final ones */\n"
+          "int update_multipliers(tOptSet *o, int init) {\n"
+          "    return update_multipliers_running(o, init) && update_multipliers_final(o, init);\n}\n\n"
+          "/* no outputs g are defined by this generator (iLQG_func.tem:511-521) */\n"
+          "int get_g_size() { return 0; }\n\n"
+          "int calcG(double g[], trajEl_t *t, int k, double **p) { return 1; }\n")
+        w(self.emit_factored_tensors())
+        return "".join(o)
 
-        # --- cost and dynamics ---
-        w("static int ddpL(trajEl_t *t, int k, tOptSet *o) {\n    const double *x= t->x;\n    const double *u= t->u;\n    double **p= o->p;\n\n")
-        w(self.assign("t->c", p.L))
-        w("\n    return 1;\n}\n\n")
-        w("static int ddpF(trajFin_t *t, tOptSet *o) {\n    const double *x= t->x;\n    const int k= o->n_hor;\n    double **p= o->p;\n\n")
-        w(self.assign("t->c", p.F))
-        w("\n    return 1;\n}\n\n")
-        w("static int ddpf(double x_next[], trajEl_t *t, int k, double **p, int N) {\n    const double *x= t->x;\n    const double *u= t->u;\n\n")
+    def emit_cost_and_dynamics(self):
+        p, n = self.p, self.n
+        out = "/* running cost of one step, final cost, one step of the dynamics */\n"
+        out += "static int ddpL(trajEl_t *t, int k, tOptSet *o) {\n" + self.prologue("x", "u", "p")
+        out += self.assign("t->c", p.L) + "    return 1;\n}\n\n"
+        out += "static int ddpF(trajFin_t *t, tOptSet *o) {\n" + self.prologue("x", "kN", "p")
+        out += self.assign("t->c", p.F) + "    return 1;\n}\n\n"
+        out += "static int ddpf(double x_next[], trajEl_t *t, int k, double **p, int N) {\n" + self.prologue("x", "u")
         for r in range(n):
-            w(self.assign("x_next[%d]" % r, p.f[r]))
-        w("    return 1;\n}\n\n")
+            out += self.assign("x_next[%d]" % r, p.f[r])
+        out += "    return 1;\n}\n\n"
+        return out
 
-        # --- input constraints ---
-        w("void clampU(double *u, trajEl_t *t, int k, double **p, int N) {\n    double limit;\n    const double *x= t->x;\n\n")
-        for c in self.cons:
-            w("    // constraint h[%d]= %s\n" % (c["index"] + 1, sp.sstr(c["expr"])))
-            w(self.assign("limit", c["limit"], guard=False))
-            j = c["input"]
-            if c["sign"] > 0:
-                w("    if(u[%d]>limit) u[%d]= limit;\n\n" % (j, j))
-            else:
-                w("    if(u[%d]<limit) u[%d]= limit;\n\n" % (j, j))
-        w("}\n\n")
-
-        w("static void limitsU(trajEl_t *t, int k, double **p, int N) {\n"
-          "    int i, j;\n    int lower_idx[N_U], upper_idx[N_U], *idx_;\n    double limit;\n"
-          "    const double *x= t->x;\n    double *hx_, *h_sign;\n\n"
-          "    for(i= 0; i<N_U; i++) {\n        lower_idx[i]= -1;\n        upper_idx[i]= -1;\n"
-          "        t->lower[i]= -INF;\n        t->upper[i]= INF;\n    }\n\n")
+    def emit_input_limits(self):
+        """clampU: project u onto the input constraints, constraint by constraint in their given order;
+        limitsU: the box those constraints leave for a CHANGE of u around the nominal input, and for each side of each
+        input the constraint that is active there (sign of the input in it, its gradient with respect to x)."""
+        n = self.n
+        out = "void clampU(double *u, trajEl_t *t, int k, double **p, int N) {\n    const double *const x= t->x;\n    double bound;\n\n"
         for c in self.cons:
             j = c["input"]
-            w("    // constraint h[%d]= %s\n" % (c["index"] + 1, sp.sstr(c["expr"])))
-            w(self.assign("limit", c["limit"], guard=False))
-            if c["sign"] > 0:
-                w("    if(t->upper[%d]>limit) { t->upper[%d]= limit; upper_idx[%d]= %d; }\n\n" % (j, j, j, c["index"]))
-            else:
-                w("    if(t->lower[%d]<limit) { t->lower[%d]= limit; lower_idx[%d]= %d; }\n\n" % (j, j, j, c["index"]))
-        w("    for(i= 0; i<N_U; i++) {\n        t->lower[i]-= t->u[i];\n        t->upper[i]-= t->u[i];\n    }\n\n"
-          "    for(j= 0; j<2; j++) {\n        if(j==0) {\n            idx_= lower_idx;\n            hx_= t->lower_hx;\n            h_sign= t->lower_sign;\n"
-          "        } else {\n            idx_= upper_idx;\n            hx_= t->upper_hx;\n            h_sign= t->upper_sign;\n        }\n"
-          "        for(i= 0; i<N_U; i++, hx_+= N_X, h_sign++) {\n            switch(idx_[i]) {\n"
-          "                case -1:\n                    h_sign[0]= 0.0;\n                    break;\n")
+            out += "    /* h[%d]= %s */\n" % (c["index"] + 1, sp.sstr(c["expr"]))
+            out += self.assign("bound", c["limit"], guard=False)
+            out += "    if(u[%d]%sbound) u[%d]= bound;\n" % (j, ">" if c["sign"] > 0 else "<", j)
+        out += "}\n\n"
+
+        out += ("static void limitsU(trajEl_t *t, int k, double **p, int N) {\n"
+                "    const double *const x= t->x;\n"
+                "    int active[2][N_U];  /* constraint that bounds input iu from below [0] / from above [1]; -1: none */\n"
+                "    double bound;\n    int iu, side;\n\n"
+                "    for(iu= 0; iu<N_U; iu++) {\n        active[0][iu]= active[1][iu]= -1;\n"
+                "        t->lower[iu]= -INF;\n        t->upper[iu]= INF;\n    }\n\n")
         for c in self.cons:
-            w("                case %d:\n" % c["index"])
+            j, side = c["input"], (1 if c["sign"] > 0 else 0)
+            arr, cmp_ = ("upper", ">") if side else ("lower", "<")
+            out += "    /* h[%d]= %s */\n" % (c["index"] + 1, sp.sstr(c["expr"]))
+            out += self.assign("bound", c["limit"], guard=False)
+            out += "    if(t->%s[%d]%sbound) { t->%s[%d]= bound; active[%d][%d]= %d; }\n" % (arr, j, cmp_, arr, j, side, j, c["index"])
+        out += ("\n    /* the solver works with the change of u */\n"
+                "    for(iu= 0; iu<N_U; iu++) {\n        t->lower[iu]-= t->u[iu];\n        t->upper[iu]-= t->u[iu];\n    }\n\n"
+                "    for(side= 0; side<2; side++) {\n"
+                "        double *const sign= side? t->upper_sign: t->lower_sign;\n"
+                "        double *const grad= side? t->upper_hx: t->lower_hx;\n"
+                "        for(iu= 0; iu<N_U; iu++) {\n"
+                "            double *const hx_= grad + iu*N_X;\n"
+                "            switch(active[side][iu]) {\n")
+        for c in self.cons:
+            out += "                case %d:\n" % c["index"]
             for jx in range(n):
-                w(self.assign("hx_[%d]" % jx, c["hx"][jx], ind=20, guard=False))
-            w("                    h_sign[0]= %d.0;\n                    break;\n" % c["sign"])
-        w("            }\n        }\n    }\n}\n\n")
+                out += self.assign("hx_[%d]" % jx, c["hx"][jx], ind=20, guard=False)
+            out += "                    sign[iu]= %d.0;\n                    break;\n" % c["sign"]
+        out += ("                default:  /* unbounded on this side: the gradient is not used */\n"
+                "                    sign[iu]= 0.0;\n            }\n        }\n    }\n}\n\n")
+        return out
 
-        # --- forward pass ---
-        w("""int forward_pass(traj_t *c, tOptSet *o, double alpha, double *csum, int cost_only) {
-    int i, k, j;
-    double dx;
-    double *x0= o->x0;
-    int N= o->n_hor;
-    double **params= o->p;
-
-    trajEl_t *t= o->nominal->t;
-    trajEl_t *ct= c->t;
-    trajFin_t *cf= &c->f;
-
-    multipliersEl_t *m= o->multipliers.t;
-    multipliersFin_t *mf= &o->multipliers.f;
-
-    double *x_next;
+    def emit_sweeps(self):
+        return """/* Roll-out of candidate trajectory c (line_search.c:40, iLQG.c:338, iLQG_mex.c:116).
+ * alpha != 0: u = u_nom + alpha*l + L (x - x_nom) with the gains of the nominal trajectory, accumulated state by
+ * state; alpha == 0: the nominal inputs as they are.  cost_only: x and u of c are kept, only the cost is summed.
+ * csum[0] holds the cost summed so far also when a NaN/Inf guard ends the sweep (return 0). */
+int forward_pass(traj_t *c, tOptSet *o, double alpha, double *csum, int cost_only) {
+    const int n_steps= o->n_hor;
+    const int rollout= !cost_only;
+    int k, ix, iu;
 
     csum[0]= 0.0;
+    if(rollout)
+        for(ix= 0; ix<N_X; ix++) c->t[0].x[ix]= o->x0[ix];
 
-    if(!cost_only)
-        for(i= 0; i<N_X; i++) ct->x[i]= x0[i];
+    for(k= 0; k<n_steps; k++) {
+        const trajEl_t *const ref= o->nominal->t + k;
+        trajEl_t *const cur= c->t + k;
+        multipliersEl_t *const mul= o->multipliers.t + k;
 
-    for(k= 0; k<N; k++, t++, ct++, m++) {
-        if(!cost_only) {
+        if(rollout) {
             if(alpha) {
-                /* u = u_nom + alpha*l + L*(x - x_nom), accumulated state by state */
-                for(j= 0; j<N_U; j++)
-                    ct->u[j]= t->u[j] + t->l[j]*alpha;
-                for(i= 0; i<N_X; i++) {
-                    dx= ct->x[i] - t->x[i];
-                    for(j= 0; j<N_U; j++)
-                        ct->u[j]+= t->L[MAT_IDX(j, i, N_U)]*dx;
+                for(iu= 0; iu<N_U; iu++)
+                    cur->u[iu]= ref->u[iu] + ref->l[iu]*alpha;
+                for(ix= 0; ix<N_X; ix++) {
+                    const double dev= cur->x[ix] - ref->x[ix];
+                    for(iu= 0; iu<N_U; iu++)
+                        cur->u[iu]+= ref->L[MAT_IDX(iu, ix, N_U)]*dev;
                 }
             } else {
-                for(j= 0; j<N_U; j++)
-                    ct->u[j]= t->u[j];
+                for(iu= 0; iu<N_U; iu++)
+                    cur->u[iu]= ref->u[iu];
             }
         }
-        if(!calcXVariableAux(ct, m, k, o)) return 0;
-
-        if(!cost_only)
-            clampU(ct->u, ct, k, params, N);
-        if(!calcXUVariableAux(ct, m, k, o)) return 0;
-
-        if(!cost_only) {
-            x_next= (k>=N-1)? cf->x: (ct+1)->x;
-            if(!ddpf(x_next, ct, k, params, N)) return 0;
-        }
-
-        if(!ddpL(ct, k, o)) return 0;
-        csum[0]+= ct->c;
+        if(!calcXVariableAux(cur, mul, k, o)) return 0;
+        if(rollout) clampU(cur->u, cur, k, o->p, n_steps);
+        if(!calcXUVariableAux(cur, mul, k, o)) return 0;
+        if(rollout && !ddpf((k+1<n_steps)? c->t[k+1].x: c->f.x, cur, k, o->p, n_steps)) return 0;
+        if(!ddpL(cur, k, o)) return 0;
+        csum[0]+= cur->c;
     }
 
-    if(!calcFVariableAux(cf, mf, o)) return 0;
-    if(!ddpF(cf, o)) return 0;
-    csum[0]+= cf->c;
-
+    if(!calcFVariableAux(&c->f, &o->multipliers.f, o)) return 0;
+    if(!ddpF(&c->f, o)) return 0;
+    csum[0]+= c->f.c;
     return 1;
 }
 
+/* Derivatives along the nominal trajectory (iLQG.c:247): the final step, then the running steps from the end of
+ * the horizon to its start, each with the box its input constraints leave around the nominal input. */
 int calc_derivs(tOptSet *o) {
+    const int n_steps= o->n_hor;
+    traj_t *const nom= o->nominal;
     int k;
-    int N= o->n_hor;
 
-    trajEl_t *t= o->nominal->t + N - 1;
-    trajFin_t *f= &o->nominal->f;
+    if(!calcFAuxDeriv(&nom->f, &o->multipliers.f, o)) return 0;
+    if(!bp_derivsF(&nom->f, n_steps, o->p)) return 0;
 
-    multipliersEl_t *m= o->multipliers.t + N - 1;
-    multipliersFin_t *mf= &o->multipliers.f;
-
-    if(!calcFAuxDeriv(f, mf, o)) return 0;
-    if(!bp_derivsF(f, N, o->p)) return 0;
-
-    for(k= N-1; k>=0; k--, t--, m--) {
-        if(!calcLAuxDeriv(t, m, k, o)) return 0;
-        if(!bp_derivsL(t, k, o->p)) return 0;
-
-        limitsU(t, k, o->p, N);
+    for(k= n_steps; k-->0; ) {
+        trajEl_t *const el= nom->t + k;
+        if(!calcLAuxDeriv(el, o->multipliers.t + k, k, o)) return 0;
+        if(!bp_derivsL(el, k, o->p)) return 0;
+        limitsU(el, k, o->p, n_steps);
     }
     return 1;
 }
 
-""")
-        # --- aux evaluation ---
-        w("static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {\n    const double *x= t->x;\n    double **p= o->p;\n    const double w_pen= o->w_pen_l;\n\n")
-        w(self.aux_block(self.run_need | self.run_need_full, ("aux",), True, u_dep=False))
-        w("    return 1;\n}\n\n")
-        w("static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {\n    const double *x= t->x;\n    const double *u= t->u;\n    double **p= o->p;\n    const double w_pen= o->w_pen_l;\n\n")
-        w(self.aux_block(self.run_need | self.run_need_full, ("aux",), True, u_dep=True))
-        w("    return 1;\n}\n\n")
-        w("static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {\n    const double *x= t->x;\n    double **p= o->p;\n    const double w_pen= o->w_pen_f;\n    const int k= o->n_hor;\n\n")
-        w(self.aux_block(self.fin_need, ("aux",), True))
-        w("    return 1;\n}\n\n")
-        w("static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {\n    const double *x= t->x;\n    const double *u= t->u;\n    const double w_pen= o->w_pen_l;\n    double **p= o->p;\n\n")
-        w(self.aux_block(self.run_need, ("d1", "d2"), True))
-        w("#if FULL_DDP\n")
-        w(self.aux_block(self.run_need_full, ("d1", "d2"), True))
-        w("#endif\n    return 1;\n}\n\n")
+"""
 
-        # --- derivatives (time-varying entries) ---
-        w("static int bp_derivsL(trajEl_t *t, int k, double **p) {\n    const double *x= t->x;\n    const double *u= t->u;\n\n// derivatives of f\n")
-        w(self.block(self.jaco_items("fx", self.fx), True))
-        w("\n")
-        w(self.block(self.jaco_items("fu", self.fu), True))
-        w("\n#if FULL_DDP\n")
-        for nm, ten in (("fxx", self.fxx), ("fuu", self.fuu), ("fxu", self.fxu)):
-            if not self.all_zero(ten):
-                w(self.block(self.jaco2_items(nm, ten), True))
-                w("\n")
-        w("#endif\n\n// derivatives of L\n")
-        w(self.block(self.grad_items("cx", self.Lx), True))
-        w("\n")
-        w(self.block(self.hess_items("cxx", self.Lxx), True))
-        w("\n")
-        w(self.block(self.grad_items("cu", self.Lu), True))
-        w("\n")
-        w(self.block(self.hess_items("cuu", self.Luu), True))
-        w("\n")
-        w(self.block(self.hess_items("cxu", self.Lxu), True))
-        w("\n    return 1;\n}\n\n")
+    def emit_auxiliaries(self):
+        out = "/* auxiliary variables: members of the step's element, evaluated once and reused by everything that follows */\n"
+        out += "static int calcXVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {\n" + self.prologue("x", "p", "wl")
+        out += self.aux_block(self.run_need | self.run_need_full, ("aux",), True, u_dep=False) + "    return 1;\n}\n\n"
+        out += "static int calcXUVariableAux(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {\n" + self.prologue("x", "u", "p", "wl")
+        out += self.aux_block(self.run_need | self.run_need_full, ("aux",), True, u_dep=True) + "    return 1;\n}\n\n"
+        out += "static int calcFVariableAux(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {\n" + self.prologue("x", "p", "wf", "kN")
+        out += self.aux_block(self.fin_need, ("aux",), True) + "    return 1;\n}\n\n"
+        out += "static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {\n" + self.prologue("x", "u", "wl", "p")
+        out += self.aux_block(self.run_need, ("d1", "d2"), True)
+        out += "#if FULL_DDP\n" + self.aux_block(self.run_need_full, ("d1", "d2"), True) + "#endif\n    return 1;\n}\n\n"
+        return out
 
-        w("static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {\n    const double *x= t->x;\n    const double w_pen= o->w_pen_f;\n    double **p= o->p;\n    const int k= o->n_hor;\n\n")
-        w(self.aux_block(self.fin_need, ("d1", "d2"), True))
-        w("    return 1;\n}\n\n")
-        w("static int bp_derivsF(trajFin_t *t, int k, double **p) {\n    const double *x= t->x;\n\n")
-        w(self.block(self.grad_items("cx", self.Fx), True))
-        w("\n")
-        w(self.block(self.hess_items("cxx", self.Fxx), True))
-        w("    return 1;\n}\n\n")
-
-        # --- constants ---
-        w("static int init_running(trajEl_t *t, tOptSet *o) {\n    int k;\n    double **p= o->p;\n\n    for(k= 0; k<o->n_hor; k++, t++) {\n")
-        w(self.aux_block(self.run_need | self.run_need_full, ("aux",), False, ind=8))
-        w(self.aux_block(self.run_need, ("d1", "d2"), False, ind=8))
-        w("#if FULL_DDP\n")
-        w(self.aux_block(self.run_need_full, ("d1", "d2"), False, ind=8))
-        w("#endif\n\n// derivatives of L\n")
+    def emit_derivatives(self):
+        """time-varying entries of the derivative record of one step / of the final step"""
+        cse = self.cse
+        out = "static int bp_derivsL(trajEl_t *t, int k, double **p) {\n    const double *const x= t->x;\n    const double *const u= t->u;\n\n"
+        if cse:
+            cse.use("first")
+        first = (self.block(self.jaco_items("fx", self.fx), True, cse=cse) + "\n" +
+                 self.block(self.jaco_items("fu", self.fu), True, cse=cse) + "\n")
+        cost = ""
         for items in (self.grad_items("cx", self.Lx), self.hess_items("cxx", self.Lxx), self.grad_items("cu", self.Lu),
                       self.hess_items("cuu", self.Luu), self.hess_items("cxu", self.Lxu)):
-            w(self.block(items, False, ind=8))
-            w("\n")
-        w("// derivatives of f\n")
-        w(self.block(self.jaco_items("fx", self.fx), False, ind=8))
-        w("\n")
-        w(self.block(self.jaco_items("fu", self.fu), False, ind=8))
-        w("\n#if FULL_DDP\n")
+            cost += self.block(items, True, cse=cse) + "\n"
+        if cse:
+            cse.use("second")
+        second = ""
+        for nm, ten in (("fxx", self.fxx), ("fuu", self.fuu), ("fxu", self.fxu)):
+            if not self.all_zero(ten):
+                second += self.block(self.jaco2_items(nm, ten), True, cse=cse) + "\n"
+        if cse:
+            out += "    /* products shared by several entries */\n" + cse.declarations("first") + "\n"
+            second = "    /* products shared by the entries of the tensors */\n" + cse.declarations("second") + "\n" + second
+        out += "    /* dynamics */\n" + first + "#if FULL_DDP\n" + second + "#endif\n    /* cost */\n" + cost + "    return 1;\n}\n\n"
+
+        out += "static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {\n" + self.prologue("x", "wf", "p", "kN")
+        out += self.aux_block(self.fin_need, ("d1", "d2"), True) + "    return 1;\n}\n\n"
+        out += "static int bp_derivsF(trajFin_t *t, int k, double **p) {\n    const double *const x= t->x;\n\n"
+        out += self.block(self.grad_items("cx", self.Fx), True) + "\n" + self.block(self.hess_items("cxx", self.Fxx), True)
+        out += "    return 1;\n}\n\n"
+        return out
+
+    def emit_constants(self):
+        """entries that do not change along a trajectory are written once (init_opt), element by element"""
+        out = ("/* constant entries of every element of a trajectory buffer */\n"
+               "static int init_running(trajEl_t *t, tOptSet *o) {\n    double **const p= o->p;\n    trajEl_t *const end= t + o->n_hor;\n    int k= 0;\n\n"
+               "    for(; t<end; t++, k++) {\n")
+        out += self.aux_block(self.run_need | self.run_need_full, ("aux",), False, ind=8)
+        out += self.aux_block(self.run_need, ("d1", "d2"), False, ind=8)
+        out += "#if FULL_DDP\n" + self.aux_block(self.run_need_full, ("d1", "d2"), False, ind=8) + "#endif\n"
+        out += "        /* cost */\n"
+        for items in (self.grad_items("cx", self.Lx), self.hess_items("cxx", self.Lxx), self.grad_items("cu", self.Lu),
+                      self.hess_items("cuu", self.Luu), self.hess_items("cxu", self.Lxu)):
+            out += self.block(items, False, ind=8) + "\n"
+        out += "        /* dynamics */\n"
+        out += self.block(self.jaco_items("fx", self.fx), False, ind=8) + "\n"
+        out += self.block(self.jaco_items("fu", self.fu), False, ind=8) + "\n#if FULL_DDP\n"
         for nm, ten, sz in (("fxx", self.fxx, "N_X*sizeofQxx"), ("fuu", self.fuu, "N_X*sizeofQuu"), ("fxu", self.fxu, "N_X*sizeofQxu")):
             if self.all_zero(ten):
-                w("        { int i_; for(i_= 0; i_<%s; i_++) t->%s[i_]= 0.0; }\n" % (sz, nm))
+                out += "        { int e_; for(e_= 0; e_<%s; e_++) t->%s[e_]= 0.0; }\n" % (sz, nm)
             else:
-                w(self.block(self.jaco2_items(nm, ten), False, ind=8))
-            w("\n")
-        w("#endif\n    }\n\n    return 1;\n}\n\n")
+                out += self.block(self.jaco2_items(nm, ten), False, ind=8)
+            out += "\n"
+        out += "#endif\n    }\n    return 1;\n}\n\n"
+        out += "static int init_final(trajFin_t *t, tOptSet *o) {\n" + self.prologue("p", "kN")
+        out += self.aux_block(self.fin_need, ("aux",), False) + self.aux_block(self.fin_need, ("d1", "d2"), False)
+        out += self.block(self.grad_items("cx", self.Fx), False) + "\n" + self.block(self.hess_items("cxx", self.Fxx), False)
+        out += "    return 1;\n}\n\n"
+        return out
 
-        w("static int init_final(trajFin_t *t, tOptSet *o) {\n    double **p= o->p;\n    const int k= o->n_hor;\n\n")
-        w(self.aux_block(self.fin_need, ("aux",), False))
-        w(self.aux_block(self.fin_need, ("d1", "d2"), False))
-        w(self.block(self.grad_items("cx", self.Fx), False))
-        w("\n")
-        w(self.block(self.hess_items("cxx", self.Fxx), False))
-        w("\n    return 1;\n}\n\n")
-
-        w("""int init_trajectory(traj_t *t, tOptSet *o) {
-    if(!init_running(t->t, o)) return 0;
-    if(!init_final(&t->f, o)) return 0;
-
-    return 1;
-}
-
-""")
-        w(self.multiplier_init())
-        w("""int init_multipliers(tOptSet *o) {
-    if(!init_multipliers_running(o)) return 0;
-    if(!init_multipliers_final(o)) return 0;
-
-    return 1;
-}
-
-int init_opt(tOptSet *o) {
-    int i;
-
-    for(i= 0; i<NUMBER_OF_THREADS+1; i++)
-        if(!init_trajectory(&o->trajectories[i], o)) return 0;
-
-    o->nominal= &o->trajectories[0];
-    for(i= 1; i<NUMBER_OF_THREADS+1; i++)
-        o->candidates[i-1]= &o->trajectories[i];
-
-    if(!init_multipliers(o)) return 0;
-
-    return 1;
-}
-
-""")
-        w(self.multiplier_update())
-        w("""int update_multipliers(tOptSet *o, int init) {
-    if(!update_multipliers_running(o, init)) return 0;
-    if(!update_multipliers_final(o, init)) return 0;
-
-    return 1;
-}
-
-int get_g_size() {
-    return(0);
-}
-
-int calcG(double g[], trajEl_t *t, int k, double **p) {
-    return(1);
-}
-""")
-        return "".join(o)
+    def emit_setup(self):
+        return ("int init_trajectory(traj_t *t, tOptSet *o) {\n    return init_running(t->t, o) && init_final(&t->f, o);\n}\n\n"
+                + self.multiplier_init() +
+                "int init_multipliers(tOptSet *o) {\n    return init_multipliers_running(o) && init_multipliers_final(o);\n}\n\n"
+                "/* iLQG_mex.c:108: constants of every trajectory buffer; buffer 0 starts as the nominal trajectory, the\n"
+                " * others as line-search candidates; multipliers at their start values */\n"
+                "int init_opt(tOptSet *o) {\n    int b;\n\n"
+                "    for(b= 0; b<=NUMBER_OF_THREADS; b++) {\n"
+                "        if(!init_trajectory(&o->trajectories[b], o)) return 0;\n"
+                "        if(b==0) o->nominal= &o->trajectories[0];\n"
+                "        else o->candidates[b-1]= &o->trajectories[b];\n    }\n"
+                "    return init_multipliers(o);\n}\n\n")
 
 
 def _multiplier_init(self):
-    """init_multipliers_running / _final (iLQG_func.tem:371-393): equality multipliers 0, inequality multipliers 1"""
+    """start values of the multipliers (iLQG_func.tem:371-393): equality constraints 0, inequality constraints 1,
+    no constraint value remembered yet"""
     al = self.cons_al
+
+    def fill(kinds, ind):
+        pad, out = " " * ind, ""
+        for kind in kinds:
+            if al[kind]:
+                out += ("%sfor(i= 0; i<%d; i++) { m->mu_%s[i]= %s; m->last_h%s[i]= 0.0; }\n"
+                        % (pad, len(al[kind]), kind, "0.0" if kind[1] == "e" else "1.0", kind))
+        return out
+
     out = "static int init_multipliers_running(tOptSet *o) {\n"
     if al["le"] or al["li"]:
-        out += "    multipliersEl_t *m= o->multipliers.t;\n    int k, i;\n\n    for(k= 0; k<o->n_hor; k++, m++) {\n"
-        if al["le"]:
-            out += "        for(i= 0; i<%d; i++) { m->mu_le[i]= 0.0; m->last_hle[i]= 0.0; }\n" % len(al["le"])
-        if al["li"]:
-            out += "        for(i= 0; i<%d; i++) { m->mu_li[i]= 1.0; m->last_hli[i]= 0.0; }\n" % len(al["li"])
-        out += "    }\n\n"
+        out += ("    multipliersEl_t *m= o->multipliers.t;\n    multipliersEl_t *const end= m + o->n_hor;\n    int i;\n\n"
+                "    for(; m<end; m++) {\n" + fill(("le", "li"), 8) + "    }\n")
     out += "    return 1;\n}\n\nstatic int init_multipliers_final(tOptSet *o) {\n"
     if al["fe"] or al["fi"]:
-        out += "    multipliersFin_t *m= &o->multipliers.f;\n    int i;\n\n"
-        if al["fe"]:
-            out += "    for(i= 0; i<%d; i++) { m->mu_fe[i]= 0.0; m->last_hfe[i]= 0.0; }\n" % len(al["fe"])
-        if al["fi"]:
-            out += "    for(i= 0; i<%d; i++) { m->mu_fi[i]= 1.0; m->last_hfi[i]= 0.0; }\n" % len(al["fi"])
-        out += "\n"
+        out += "    multipliersFin_t *const m= &o->multipliers.f;\n    int i;\n\n" + fill(("fe", "fi"), 4)
     out += "    return 1;\n}\n\n"
     return out
 
 
 def _multiplier_update(self):
-    """update_multipliers_running / _final (iLQG_func.tem:419-509), literally: the constraint values are the
-    auxiliaries the last roll-out of the nominal trajectory left in its elements; with init != 0 the running part
-    returns inside its loop after the first element, as the reference's template does"""
+    """update_multipliers_running / _final: same effect as iLQG_func.tem:419-509.  The constraint values are the
+    auxiliaries the last roll-out of the nominal trajectory left in its elements.  Per constraint: does its violation
+    stall (larger than the tolerance and not reduced by the factor w_pen_fact1 since the last call)?  Then the
+    violation is remembered and — unless this is the solver-entry call (init) — the multiplier is updated;
+    equality: mu += w_pen*h, inequality after Ruxton.  A stalled violation raises the penalty weight once per call.
+    With init != 0 the running part stops after the first element (as the reference's template does: its
+    `if(init) return 1;` sits inside the loop over the horizon)."""
     al, w = self.cons_al, self.w_pen
 
     def hval(hs):
         return self.macro_name(hs)
 
-    def checks(kind, ind):
+    def progress(kind, ind):
         pad, out = " " * ind, ""
         for i, (hs, mu) in enumerate(al[kind]):
             h = hval(hs)
             if kind[1] == "e":
-                out += ("%sif(fabs(%s)>o->tolConstraint && o->w_pen_fact1*fabs(%s)>fabs(m->last_h%s[%d])) increase_pen= 1;\n"
-                        % (pad, h, h, kind, i))
+                out += "%sstalled|= violation_stalls(fabs(%s), fabs(m->last_h%s[%d]), o);\n" % (pad, h, kind, i)
             else:
-                out += ("%sif(%s>o->tolConstraint && o->w_pen_fact1*%s>m->last_h%s[%d]) increase_pen= 1;\n"
-                        % (pad, h, h, kind, i))
-            out += "%sm->last_h%s[%d]= %s;\n\n" % (pad, kind, i, h)
+                out += "%sstalled|= violation_stalls(%s, m->last_h%s[%d], o);\n" % (pad, h, kind, i)
+            out += "%sm->last_h%s[%d]= %s;\n" % (pad, kind, i, h)
         return out
 
-    def updates(kind, ind, ret="0"):
+    def steps(kind, ind):
         pad, out = " " * ind, ""
         for i, (hs, mu) in enumerate(al[kind]):
             lhs = self.mu_c[mu]
             if kind[1] == "e":
                 out += self.assign(lhs, mu + w * hs, ind)
-            else:  # inequality constraints after D. Ruxton (iLQG_func.tem:455-463)
+            else:  # D. Ruxton's update for inequality constraints: active / inactive branch
                 out += "%sif(%s>=0) {\n" % (pad, hval(hs))
                 out += self.assign(lhs, mu * (1 + 2 * w * hs), ind + 4)
                 out += "%s} else {\n" % pad
                 out += self.assign(lhs, mu * (1 - w * hs) ** -2, ind + 4)
-                out += "%s}\n\n" % pad
+                out += "%s}\n" % pad
         return out
 
-    out = "static int update_multipliers_running(tOptSet *o, int init) {\n"
+    any_al = any(al[k] for k in al)
+    out = ""
+    if any_al:
+        out += ("/* a violation v stalls: above the tolerance and not smaller than 1/w_pen_fact1 of the one remembered */\n"
+                "static int violation_stalls(double v, double last, const tOptSet *o) {\n"
+                "    return v>o->tolConstraint && o->w_pen_fact1*v>last;\n}\n\n")
+    out += "static int update_multipliers_running(tOptSet *o, int init) {\n"
     if al["le"] or al["li"]:
         out += ("    trajEl_t *t= o->nominal->t;\n    multipliersEl_t *m= o->multipliers.t;\n"
-                "    const double w_pen= o->w_pen_l;\n    double **p= o->p;\n    int increase_pen= 0;\n    int k;\n\n"
-                "    for(k= 0; k<o->n_hor; k++, m++, t++) {\n")
-        out += checks("le", 8) + checks("li", 8)
-        out += "        if(init) return 1;\n"
-        out += updates("le", 8) + updates("li", 8)
-        out += ("    }\n\n    if(!init && increase_pen)\n"
-                "        o->w_pen_l= min(o->w_pen_max_l, o->w_pen_l*o->w_pen_fact1);\n\n")
+                "    const double w_pen= o->w_pen_l;\n    double **const p= o->p;\n    int stalled= 0, k;\n\n"
+                "    for(k= 0; k<o->n_hor; k++, t++, m++) {\n")
+        out += progress("le", 8) + progress("li", 8)
+        out += "        if(init) return 1;  /* solver entry: the violations of the first element are remembered, nothing else */\n"
+        out += steps("le", 8) + steps("li", 8)
+        out += ("    }\n    if(!init && stalled)\n"
+                "        o->w_pen_l= min(o->w_pen_max_l, o->w_pen_l*o->w_pen_fact1);\n")
     out += "    return 1;\n}\n\nstatic int update_multipliers_final(tOptSet *o, int init) {\n"
     if al["fe"] or al["fi"]:
-        out += ("    trajFin_t *t= &o->nominal->f;\n    multipliersFin_t *m= &o->multipliers.f;\n"
-                "    const double w_pen= o->w_pen_f;\n    double **p= o->p;\n    int increase_pen= 0;\n    int k= o->n_hor;\n\n")
-        out += checks("fe", 4) + checks("fi", 4)
-        out += ("    if(!init && increase_pen)\n        o->w_pen_f= min(o->w_pen_max_f, o->w_pen_f*o->w_pen_fact1);\n\n"
+        out += ("    trajFin_t *const t= &o->nominal->f;\n    multipliersFin_t *const m= &o->multipliers.f;\n"
+                "    const double w_pen= o->w_pen_f;\n    double **const p= o->p;\n    const int k= o->n_hor;\n    int stalled= 0;\n\n")
+        out += progress("fe", 4) + progress("fi", 4)
+        out += ("    if(!init && stalled)\n        o->w_pen_f= min(o->w_pen_max_f, o->w_pen_f*o->w_pen_fact1);\n"
                 "    if(init) return 1;\n")
-        out += updates("fe", 4) + updates("fi", 4)
+        out += steps("fe", 4) + steps("fi", 4)
     out += "    return 1;\n}\n\n"
     return out
 
 
 Emitter.multiplier_init = _multiplier_init
 Emitter.multiplier_update = _multiplier_update
+
+
+# --------------------------------------------------------------------------
+# common factors of derivative entries
+# --------------------------------------------------------------------------
+class SharedTerms:
+    """Splits derivative entries into sums of (number) * (product of everything else) and gives every distinct
+    product a local name, so that a function evaluates it once however many entries contain it — the large tensors
+    of a problem whose nonlinearity enters through a few auxiliaries are thousands of numeric multiples of a few dozen
+    products.  (The reference leaves common subexpressions to gentran's optimiser.)  Two pools: products needed by
+    first-order entries are declared unconditionally, products only the second derivatives of f need inside
+    #if FULL_DDP (their auxiliaries only exist there)."""
+
+    def __init__(self, emitter):
+        self.em = emitter
+        self.pools = {"first": [], "second": []}
+        self.names = {}
+        self.pool = "first"
+
+    def use(self, pool):
+        self.pool = pool
+
+    def split(self, e):
+        """[(coefficient, product or None)] with e == sum(coefficient * product)"""
+        out = []
+        for term in sp.Add.make_args(sp.sympify(e)):
+            coef, rest = term.as_coeff_Mul()
+            out.append((coef, None if rest == 1 else rest))
+        return out
+
+    def name_of(self, product):
+        if product not in self.names:
+            self.names[product] = sp.Symbol("cs%d" % len(self.names))
+            self.pools[self.pool].append(product)
+        return self.names[product]
+
+    def rewrite(self, e):
+        return sp.Add(*[coef if prod is None else coef * self.name_of(prod) for coef, prod in self.split(e)])
+
+    def declarations(self, pool, ind=4):
+        out = ""
+        for prod in self.pools[pool]:
+            out += self.em.assign("const double %s" % self.names[prod].name, prod, ind, lhs_name=self.names[prod].name)
+        return out
+
+
+def _emit_factored_tensors(self):
+    """Additive (no counterpart in the reference): when every entry of fxx, fuu, fxu is one number times one shared
+    product, the same facts as tables, for back-ends that evaluate the tensors instead of storing them."""
+    if not self.tensor_tables:
+        return ""
+    T = self.tensor_tables
+    out = ("\n#if FULL_DDP\n/* ---- additive: the second derivatives of the dynamics in factored form (batched back-ends; the\n"
+           " * reference's solver never reads this).  Every entry is ONE number times ONE of ILQG_TENSOR_NBASIS shared\n"
+           " * products,\n *     t->fxx[e] == ilqg_tensor_coef_xx[e] * basis[ilqg_tensor_base_xx[e]]      (likewise fuu, fxu)\n"
+           " * and bp_tensor_basis() evaluates the products of one step exactly as bp_derivsL does. */\n"
+           "static int bp_tensor_basis(double *basis, trajEl_t *t, int k, double **p) {\n"
+           "    const double *const x= t->x;\n    const double *const u= t->u;\n\n")
+    for i, prod in enumerate(T["basis"]):
+        out += self.assign("basis[%d]" % i, prod)
+    out += "    return 1;\n}\n\n"
+    for nm in ("xx", "uu", "xu"):
+        coef, base = T[nm]
+        out += "static const double ilqg_tensor_coef_%s[%d]= {\n" % (nm, len(coef))
+        for i in range(0, len(coef), 6):
+            out += "    " + ", ".join(cexpr(sp.Float(c)) if c != 0 else "0.0" for c in coef[i:i + 6]) + ",\n"
+        out += "};\nstatic const unsigned char ilqg_tensor_base_%s[%d]= {\n" % (nm, len(base))
+        for i in range(0, len(base), 32):
+            out += "    " + ", ".join(str(b) for b in base[i:i + 32]) + ",\n"
+        out += "};\n"
+    out += "#endif\n"
+    return out
+
+
+Emitter.emit_factored_tensors = _emit_factored_tensors
 
 
 def load_problem(path):
