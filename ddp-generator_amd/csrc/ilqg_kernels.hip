@@ -233,6 +233,26 @@ constexpr bool WAVE_MAP = ILQG_WAVE_MAP;
 #define ILQG_ROW_STEP (N_X <= 16 && N_U <= 16)
 #endif
 constexpr bool ROW_STEP = ILQG_ROW_STEP;
+// Factored tensors (additive tables of the generated file, tools/gen_problem.py: every entry of fxx / fuu / fxu is a
+// number times one product shared by its slice): the records then carry the products of the step instead of the
+// tensors (k_derivs_wave writes 0.25 KB instead of 38 KB per step for the n = 16 problem) and the backward step
+// multiplies them out on the fly from coefficient tables in LDS.
+#if defined(ILQG_TENSOR_NBASIS) && FULL_DDP && ILQG_WAVE_MAP
+#define ILQG_FACTORED (ILQG_TENSOR_NBASIS > 0 && ILQG_ROW_STEP)
+#else
+#define ILQG_FACTORED 0
+#endif
+constexpr bool FACTORED = ILQG_FACTORED;
+#if ILQG_FACTORED
+constexpr int NBASIS = ILQG_TENSOR_NBASIS;
+#else
+constexpr int NBASIS = 0;
+#endif
+static_assert(NBASIS <= 64 && (!FACTORED || NBASIS <= NX * SXX), "the products of a step travel in the record's fxx member, one per lane");
+// wavefronts (= trajectories) per workgroup of the backward kernel that shares the coefficient tables
+#ifndef ILQG_FACT_WAVES
+#define ILQG_FACT_WAVES 8
+#endif
 // Augmented-Lagrangian multipliers (iLQG_problem.tem:70-89): the generated structs hold nothing but doubles
 // (mu and the constraint value of the last update per constraint); empty for a problem without hle/hli/hfe/hfi.
 constexpr int ME = std::is_empty<multipliersEl_t>::value ? 0 : (int)(sizeof(multipliersEl_t) / sizeof(double));
@@ -958,8 +978,10 @@ __global__ __launch_bounds__(WAVE *PACK_WAVES) void k_pack_records(DevPtrs P) {
 // wave mapping: calc_derivs straight into the device trajEl_t records, one lane per
 // (trajectory of the chunk, time step); step N is the final record
 // ---------------------------------------------------------------------------
+// factored: the first-order part of the record and, in place of the tensors, the products they are multiples of
+// (NBASIS doubles at the start of the record's fxx member)
 __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first,
-                                                    int chunk_count, int init_consts) {
+                                                    int chunk_count, int init_consts, int factored) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int bw = (int)(tid / (P.N + 1));
     const int k = (int)(tid % (P.N + 1));
@@ -982,7 +1004,13 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
             ok = calcXVariableAux(t, mp, k, &o);
             ok &= calcXUVariableAux(t, mp, k, &o);
             ok &= calcLAuxDeriv(t, mp, k, &o);
-            ok &= bp_derivsL(t, k, o.p);
+#if ILQG_FACTORED
+            if(factored) {
+                ok &= bp_derivsL_first(t, k, o.p);
+                ok &= bp_tensor_basis(t->fxx, t, k, o.p);
+            } else
+#endif
+                ok &= bp_derivsL(t, k, o.p);
             limitsU(t, k, o.p, P.N);
         };
 #if ILQG_UNIFORM_GUARDS
@@ -1026,12 +1054,47 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
 
 using StepLds = std::conditional_t<ROW_STEP, RowLds<(ROW_STEP ? NX : 1), (ROW_STEP ? NU : 1)>, WaveLds<NX, NU>>;
 
+#if ILQG_FACTORED
+// the step's record with the tensors multiplied out on the fly: coefficient tables (LDS copies of the generated
+// ilqg_tensor_coef_*) times the products bp_tensor_basis left in the record (LDS copy of this step's)
+struct FactoredSource : RecordSource<NX, NU, true> {
+    const double *txx, *tuu, *txu;  // LDS copies of ilqg_tensor_coef_xx / _uu / _xu
+    double product;                 // lane i: product i of this step (bp_tensor_basis)
+    struct Slice {
+        int i;
+        double gxx, guu, gxu;       // the products the entries of slice i are multiples of (wave-uniform)
+    };
+    ILQG_DEV Slice slice(int i) const {
+        return {i, lane_bcast(product, ilqg_tensor_slice_xx[i]), lane_bcast(product, ilqg_tensor_slice_uu[i]),
+                lane_bcast(product, ilqg_tensor_slice_xu[i])};
+    }
+    ILQG_DEV double fxx(const Slice &s, int e) const { return txx[e + s.i * SXX] * s.gxx; }
+    ILQG_DEV double fuu(const Slice &s, int e) const { return tuu[e + s.i * SUU] * s.guu; }
+    ILQG_DEV double fxu(const Slice &s, int e) const { return txu[e + s.i * NXU] * s.gxu; }
+};
+#endif
+constexpr int TABLE_DOUBLES = FACTORED ? NX * (SXX + SUU + NXU) : 0;
+constexpr int WAVE_LDS_DOUBLES = (int)((sizeof(StepLds) + 7) / 8);  // LDS of one wavefront
+
 // one backward step in the form that goes with the LDS block (a template, so that only that form is instantiated)
-template <class Lds>
-__device__ __forceinline__ int step_of_wave(Lds &S, const StepFields<NX, NU> &F, double *lout, double *Kout, double lambda,
-                                            int regType, double &dV0, double &dV1, double &gsum, Prof *pf) {
+template <bool FACT, class Lds>
+__device__ __forceinline__ int step_of_wave(Lds &S, const double *tables, double product, const StepFields<NX, NU> &F, double *lout,
+                                            double *Kout, double lambda, int regType, double &dV0, double &dV1, double &gsum,
+                                            Prof *pf) {
     if constexpr(std::is_same<Lds, WaveLds<NX, NU>>::value) {
         return back_step_wave<NX, NU, FULL, HX>(S, F, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
+    } else if constexpr(FACT) {
+#if ILQG_FACTORED
+        FactoredSource D;
+        D.F = F;
+        D.txx = tables;
+        D.tuu = tables + NX * SXX;
+        D.txu = tables + NX * (SXX + SUU);
+        D.product = product;
+        return back_step_row<NX, NU, FULL, HX>(S, D, F, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
+#else
+        return 0;
+#endif
     } else {
         const RecordSource<NX, NU, FULL> D{F};
         return back_step_row<NX, NU, FULL, HX>(S, D, F, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
@@ -1039,7 +1102,8 @@ __device__ __forceinline__ int step_of_wave(Lds &S, const StepFields<NX, NU> &F,
 }
 
 // one sweep of one trajectory on one wave; returns 0 ok, 1 box-QP failed (wave-uniform)
-__device__ __forceinline__ int backward_sweep_wave(StepLds &S, const DevPtrs &P, int b, int bw, double lambda,
+template <bool FACT>
+__device__ __forceinline__ int backward_sweep_wave(StepLds &S, const double *tables, const DevPtrs &P, int b, int bw, double lambda,
                                                    int regType, double &dV0, double &dV1, double &g_norm) {
     const int lane = threadIdx.x & 63;
     const int N = P.N;
@@ -1047,7 +1111,7 @@ __device__ __forceinline__ int backward_sweep_wave(StepLds &S, const DevPtrs &P,
     for(int i = lane; i < NX; i += 64) S.Vx[i] = fin[i];
     for(int i = lane; i < SXX; i += 64) S.Vxx[i] = fin[NX + i];
     for(int i = lane; i < NU; i += 64) S.l[i] = 0.0;
-    __syncthreads();
+    wave_sync();
     dV0 = 0.0;
     dV1 = 0.0;
     double gsum = 0.0;
@@ -1073,16 +1137,32 @@ __device__ __forceinline__ int backward_sweep_wave(StepLds &S, const DevPtrs &P,
         F.u = nomp(P, k, b) + NOM_U;
         return F;
     };
+    // factored records: lane i holds product i of the step (the one of step k-1 is requested at the start of step k)
+    const int bl = (lane < NBASIS) ? lane : 0;
+    double product = 0.0;
+    if(FACT) product = fields(N - 1).fxx[bl];
+    int failed = 0;
     for(int k = N - 1; k >= 0; k--) {
-        if(pf) pf->probe(7);
+        if(pf) pf->probe(0);
         const StepFields<NX, NU> F = fields(k);
-        const int rc = step_of_wave(S, F, nomp(P, k, b) + NOM_L, nomp(P, k, b) + NOM_K, lambda, regType, dV0, dV1, gsum, pf);
-        if(rc < 1) return 1;
+        double next_product = 0.0;
+        if(FACT && k > 0) next_product = fields(k - 1).fxx[bl];
+        const int rc = step_of_wave<FACT>(S, tables, product, F, nomp(P, k, b) + NOM_L, nomp(P, k, b) + NOM_K, lambda, regType,
+                                         dV0, dV1, gsum, pf);
+#ifdef ILQG_PROFILE_SECTIONS
+        prof.acc[7]++;  // steps executed (sweeps that are abandoned half way count with the steps they ran)
+#endif
+        if(rc < 1) {
+            failed = 1;
+            break;
+        }
+        product = next_product;
     }
 #ifdef ILQG_PROFILE_SECTIONS
     if(lane == 0)
         for(int i = 0; i < 8; i++) atomicAdd(&ilqg_prof_cycles[i], (unsigned long long)prof.acc[i]);
 #endif
+    if(failed) return 1;
     g_norm = gsum / ((double)(N - 1));
     return 0;
 }
@@ -1097,10 +1177,23 @@ __device__ __forceinline__ int backward_sweep_wave(StepLds &S, const DevPtrs &P,
 #else
 #define ILQG_WAVE_ATTR
 #endif
-__global__ __launch_bounds__(64, ILQG_WAVE_OCC) ILQG_WAVE_ATTR void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep,
-                                                         int chunk_first, int chunk_count) {
-    __shared__ StepLds S;
-    const int bw = blockIdx.x;
+// FACT: factored records (see FactoredSource); ILQG_FACT_WAVES wavefronts per workgroup share the coefficient tables
+template <bool FACT>
+__global__ __launch_bounds__(64 * (FACT ? ILQG_FACT_WAVES : 1), FACT ? 1 : ILQG_WAVE_OCC) ILQG_WAVE_ATTR
+void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_first, int chunk_count) {
+    extern __shared__ double wave_lds[];  // [coefficient tables][per wavefront: step block, products]
+    constexpr int WAVES = FACT ? ILQG_FACT_WAVES : 1;
+#if ILQG_FACTORED
+    if(FACT) {
+        for(int i = threadIdx.x; i < NX * SXX; i += 64 * WAVES) wave_lds[i] = ilqg_tensor_coef_xx[i];
+        for(int i = threadIdx.x; i < NX * SUU; i += 64 * WAVES) wave_lds[NX * SXX + i] = ilqg_tensor_coef_uu[i];
+        for(int i = threadIdx.x; i < NX * NXU; i += 64 * WAVES) wave_lds[NX * (SXX + SUU) + i] = ilqg_tensor_coef_xu[i];
+        __syncthreads();  // the only meeting of the workgroup's wavefronts
+    }
+#endif
+    const int wave = threadIdx.x >> 6;
+    StepLds &S = *reinterpret_cast<StepLds *>(wave_lds + (FACT ? TABLE_DOUBLES : 0) + wave * WAVE_LDS_DOUBLES);
+    const int bw = blockIdx.x * WAVES + wave;
     const int b = chunk_first + bw;
     const int lane = threadIdx.x & 63;
     if(bw >= chunk_count || b >= P.B) return;
@@ -1116,7 +1209,7 @@ __global__ __launch_bounds__(64, ILQG_WAVE_OCC) ILQG_WAVE_ATTR void k_backward_w
     double dV0 = 0.0, dV1 = 0.0, g_norm = P.f[ILQG_F_GNORM][b];
     int calls = 0, rc, status = ILQG_ST_ACTIVE;
     for(;;) {
-        rc = backward_sweep_wave(S, P, b, bw, lambda, O.regType, dV0, dV1, g_norm);
+        rc = backward_sweep_wave<FACT>(S, wave_lds, P, b, bw, lambda, O.regType, dV0, dV1, g_norm);
         calls++;
         if(single_sweep || rc != 1) break;
         const double t1 = dlambda * O.lambdaFactor;
@@ -1124,7 +1217,7 @@ __global__ __launch_bounds__(64, ILQG_WAVE_OCC) ILQG_WAVE_ATTR void k_backward_w
         const double t2 = lambda * dlambda;
         lambda = (t2 > O.lambdaMin) ? t2 : O.lambdaMin;
         if(lambda > O.lambdaMax) break;
-        __syncthreads();
+        wave_sync();
     }
     if(!single_sweep) {
         if(rc) {
@@ -1745,11 +1838,14 @@ __global__ __launch_bounds__(64) void k_boxqp_rows_test(int count, const double 
     if(t >= count) return;
     for(int i = lane; i < T; i += 64) sH[i] = H[(size_t)t * T + i];
     if(lane < M) sl[lane] = x[(size_t)t * M + lane];
-    __syncthreads();
-    const int me = lane % M;
-    int nf;
-    const int r = box_qp_rows<M>(sH, g[(size_t)t * M + me], lower[(size_t)t * M + me], upper[(size_t)t * M + me], sl, scl, sinv, nf);
-    __syncthreads();
+    wave_sync();
+    const int me = (M <= 16) ? (lane & 15) % M : lane % M;
+    int nf, r;
+    if constexpr(M <= 16)  // the form the row-mapped backward step uses
+        r = box_qp_row<M>(sH, g[(size_t)t * M + me], lower[(size_t)t * M + me], upper[(size_t)t * M + me], sl, scl, sinv, nf);
+    else
+        r = box_qp_rows<M>(sH, g[(size_t)t * M + me], lower[(size_t)t * M + me], upper[(size_t)t * M + me], sl, scl, sinv, nf);
+    wave_sync();
     if(lane == 0) {
         rc[t] = r;
         n_free[t] = nf;
@@ -1778,6 +1874,10 @@ struct ilqg_dev {
     int *counter;
     int chunk;            // wave mapping: trajectories whose derivative records fit the work buffer
     bool work_consts;     // wave mapping: constant entries of the records written (init_running)
+    bool work_factored;   // wave mapping: the records in the work buffer are factored ones (see FACTORED)
+    bool half_consts[2];  // wave mapping: the same per half of the work buffer (chunks alternate between the halves)
+    hipStream_t stream2;  // wave mapping: second stream of the chunk pipeline, fork / join events
+    hipEvent_t fork, join;
     bool timing;
     struct Span { int kernel; hipEvent_t a, b; };
     std::vector<Span> spans;
@@ -1860,6 +1960,7 @@ struct Timed {
 int drain_spans(ilqg_dev *d) {
     if(d->spans.empty()) return 0;
     HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream2));
     for(auto &s : d->spans) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, s.a, s.b);
@@ -1940,8 +2041,20 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
     d->P.Bp = d->Bp;
     d->P.N = d->N;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+#if ILQG_WAVE_MAP
+    if(FACTORED) {  // the workgroups that share the coefficient tables need more than the default 64 KB of LDS
+        const int lds = (int)((TABLE_DOUBLES + ILQG_FACT_WAVES * WAVE_LDS_DOUBLES) * sizeof(double));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_backward_wave<FACTORED>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+#endif
     d->chunk = 0;
     d->work_consts = false;
+    d->work_factored = false;
+    d->half_consts[0] = d->half_consts[1] = false;
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d->fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d->join, hipEventDisableTiming));
     for(int f = 0; f < ILQG_F_COUNT; f++) {
         if(WAVE_MAP && f == ILQG_F_DER) {
             // derivative records = device trajEl_t structs for as many trajectories as fit the budget
@@ -2013,6 +2126,9 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     if(d->P.p) hipFree(d->P.p);
     if(d->staging) hipFree(d->staging);
     hipStreamDestroy(d->stream);
+    hipStreamDestroy(d->stream2);
+    hipEventDestroy(d->fork);
+    hipEventDestroy(d->join);
     delete d;
 }
 
@@ -2049,7 +2165,7 @@ int ilqg_dev_set_params(ilqg_dev_t *d, int n_params, const int *sizes, const dou
     }
     HIP_TRY(hipMalloc((void **)&d->P.p, ptrs.size() * sizeof(double *)));
     HIP_TRY(hipMemcpy(d->P.p, ptrs.data(), ptrs.size() * sizeof(double *), hipMemcpyHostToDevice));
-    d->work_consts = false;  // constant record entries depend on the parameters
+    d->work_consts = d->half_consts[0] = d->half_consts[1] = false;  // constant record entries depend on the parameters
     return 0;
 }
 
@@ -2275,19 +2391,57 @@ int ilqg_dev_rollout_init(ilqg_dev_t *d) {
 // wave mapping: derivative records are evaluated chunk by chunk into the work buffer and consumed by
 // the backward kernel of the same chunk.  do_derivs = 0 uses the records already in the buffer.
 static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_backward) {
-    for(int c0 = 0; c0 < d->B; c0 += d->chunk) {
-        const int cnt = (d->B - c0 < d->chunk) ? d->B - c0 : d->chunk;
+    // factored records (FACTORED builds, option fuse_derivs): only where records are produced and consumed in one go —
+    // records the caller reads or writes (ilqg_dev_derivs, the drop-in back_pass()) are always the complete ones
+    const bool fact = FACTORED && d->O.fuse_derivs && do_derivs && do_backward;
+    if(do_derivs && fact != d->work_factored) {
+        d->work_consts = d->half_consts[0] = d->half_consts[1] = false;  // the products of a step overwrite the start of fxx
+        d->work_factored = fact;
+    }
+    // A batch that needs several chunks alternates between the two halves of the work buffer on two streams.  The
+    // trajectories of a chunk need very different numbers of sweeps (lambda retries), so a chunk on its own ends in a
+    // long tail of a few busy wavefronts; with the next chunk already running on the other stream the tail is filled
+    // (measured on the n = 16 problem: one chunk of 1 024 trajectories takes 41 ms, the average trajectory 14 ms).
+    const bool split = d->B > d->chunk && d->chunk >= 2 && do_derivs && do_backward;
+    const int part = split ? d->chunk / 2 : d->chunk;
+    if(split) {
+        HIP_TRY(hipEventRecord(d->fork, d->stream));
+        HIP_TRY(hipStreamWaitEvent(d->stream2, d->fork, 0));
+    }
+    int piece = 0;
+    for(int c0 = 0; c0 < d->B; c0 += part, piece++) {
+        const int cnt = (d->B - c0 < part) ? d->B - c0 : part;
+        const int h = split ? (piece & 1) : 0;
+        hipStream_t st = h ? d->stream2 : d->stream;
+        DevPtrs P = d->P;
+        P.work = d->P.work + (size_t)h * part * d->N;
         if(do_derivs) {
-            Timed t(d, ILQG_K_DERIVS);
+            Timed t(d, ILQG_K_DERIVS, st);
             const size_t total = (size_t)cnt * (d->N + 1);
-            hipLaunchKernelGGL(k_derivs_wave, grid1(total, 64), dim3(64), 0, d->stream, d->P, d->O, d->pv, c0, cnt,
-                               d->work_consts ? 0 : 1);
+            const bool have_consts = d->work_consts || (split && d->half_consts[h]);
+            hipLaunchKernelGGL(k_derivs_wave, grid1(total, 64), dim3(64), 0, st, P, d->O, d->pv, c0, cnt, have_consts ? 0 : 1,
+                               fact ? 1 : 0);
+            if(cnt == part) {  // every element of this (half of the) buffer has its constants now
+                if(split) d->half_consts[h] = true;
+                else d->work_consts = d->half_consts[0] = d->half_consts[1] = true;
+            }
         }
         if(do_backward) {
-            Timed t(d, ILQG_K_BACKWARD);
-            hipLaunchKernelGGL(k_backward_wave, dim3(cnt), dim3(64), 0, d->stream, d->P, d->O, single_sweep, c0, cnt);
+            Timed t(d, ILQG_K_BACKWARD, st);
+            if(fact) {
+                constexpr int W = ILQG_FACT_WAVES;
+                const size_t lds = (size_t)(TABLE_DOUBLES + W * WAVE_LDS_DOUBLES) * sizeof(double);
+                hipLaunchKernelGGL(k_backward_wave<FACTORED>, dim3((cnt + W - 1) / W), dim3(64 * W), lds, st, P, d->O,
+                                   single_sweep, c0, cnt);
+            } else {
+                hipLaunchKernelGGL(k_backward_wave<false>, dim3(cnt), dim3(64), (size_t)WAVE_LDS_DOUBLES * sizeof(double), st,
+                                   P, d->O, single_sweep, c0, cnt);
+            }
         }
-        if(do_derivs && cnt == d->chunk) d->work_consts = true;  // every element of the buffer has its constants now
+    }
+    if(split) {
+        HIP_TRY(hipEventRecord(d->join, d->stream2));
+        HIP_TRY(hipStreamWaitEvent(d->stream, d->join, 0));
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -34,14 +34,18 @@ ILQG_DEV void static_for(F &&f) {
 }
 
 // acc += (a of lane S of this lane's 16-lane row) * b
+// The statements are `volatile` for one reason: a row broadcast reads OTHER lanes' registers, so it must execute with
+// every lane of the row active.  A plain asm is a pure function of its operands to the optimiser, which sinks it into a
+// conditional block if its result is only used there (the guarded stores of the triangular results) — where the lanes
+// that hold the operand may be masked off (seen: the -ffp-contract=off build of the stored-tensor kernel, 1e-4 off).
 template <int S>
 ILQG_DEV void row_fma(double &acc, const double a, const double b) {
 #ifdef ILQG_STRICT_FP
     double t;
-    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(a), "n"(S));
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(a), "n"(S));
     acc = acc + t * b;
 #else
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(S));
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(S));
 #endif
 }
 // A value written by a VALU instruction must not be read through DPP in the next two issue slots (the hazard
@@ -76,6 +80,196 @@ ILQG_DEV void row_dot(double &acc, const double a, const double *b) {
     });
 }
 
+// acc += (a of lane S of the row) * (b of lane S of the row)
+template <int S>
+ILQG_DEV void row_fma2(double &acc, const double a, const double b) {
+    double t;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(b), "n"(S));
+    row_fma<S>(acc, a, t);
+}
+// the value of lane S of the row
+template <int S>
+ILQG_DEV double row_get(const double a) {
+    double t;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(a), "n"(S));
+    return t;
+}
+
+// ---------------------------------------------------------------------------
+// boxQP.c:39-238 for the wave mapping, cooperative as box_qp_rows (ilqg_wave.hpp: lane i owns variable i — its x, g,
+// limits, clamp flag, row i of H and of the inverse, column i of the Cholesky factor), with every exchange between the
+// lanes a row broadcast inside the consuming multiply-add instead of two v_readlane and a scalar operand: lane j of
+// EVERY 16-lane row holds variable j (the other lanes mirror lane mod M), so row_newbcast:j reaches it from anywhere.
+// Expression trees, operand order and exits are those of box_qp_rows, i.e. of the reference, bit for bit.
+// ---------------------------------------------------------------------------
+template <int M>
+ILQG_DEV int box_qp_row(const double *Hpacked /* LDS */, const double g, const double lower, const double upper,
+                        double *S_l, int *S_clamp, double *S_invH, int &n_free_out) {
+    static_assert(M <= 16, "one 16-lane row holds all variables");
+    constexpr int T = tri(M);
+    const int lane = threadIdx.x & 63, me = (lane & 15) % M;
+    const unsigned all = (1u << M) - 1u;
+    const int max_iter = 100;
+    const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+
+    double Hrow[M], invrow[M], Ucol[M];
+#pragma unroll
+    for(int j = 0; j < M; j++) {
+        Hrow[j] = Hpacked[sy(me, j)];
+        invrow[j] = 0.0;
+        Ucol[j] = 0.0;
+    }
+    double x = S_l[me];  // warm start
+    if(x > upper) x = upper;
+    if(x < lower) x = lower;
+    int clamp = 0;
+    for(int e = lane; e < T; e += 64) S_invH[e] = 0.0;
+    n_free_out = 0;
+
+    // value(y) = sum_i y_i (g_i + 0.5 (H y)_i), boxQP.c:17-37
+    auto qp_value = [&](double y) {
+        dpp_source(y);
+        double hx = 0.0;
+        row_dot<M>(hx, y, Hrow);
+        double w = g + 0.5 * hx;
+        dpp_source(w);
+        double v = 0.0;
+        static_for<0, M>([&](auto ic) { row_fma2<decltype(ic)::value>(v, y, w); });
+        return v;
+    };
+
+    double value = qp_value(x), oldvalue = 0.0;
+    int rc = 1;  // max_iter iterations (boxQP.c:237)
+    for(int iter = 0; iter < max_iter; iter++) {
+        if(iter > 0 && (oldvalue - value) < min_rel_improve * fabs(oldvalue)) { rc = 4; break; }
+        oldvalue = value;
+
+        // gradient and clamped set (boxQP.c:101-124)
+        dpp_source(x);
+        double hx = 0.0;
+        row_dot<M>(hx, x, Hrow);
+        double grad = g + hx;
+        const int was = clamp;
+        if(x <= lower && grad > 0)
+            clamp = 1;
+        else if(x >= upper && grad < 0)
+            clamp = 2;
+        else
+            clamp = 0;
+        const unsigned cm = (unsigned)__ballot(clamp != 0) & all;               // clamped variables
+        const bool changed = ((unsigned)__ballot((!was) != (!clamp)) & all) != 0;
+        const int n_free = M - __popc(cm);
+        n_free_out = n_free;
+        if(cm == all) { rc = 6; break; }
+        dpp_source(grad);
+        double gnorm = 0.0;
+        static_for<0, M>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if(!((cm >> i) & 1u)) row_fma2<i>(gnorm, grad, grad);
+        });
+
+        if(iter == 0 || changed) {
+            // Cholesky of the Hessian with clamped rows and columns replaced by identity (boxQP.c:131-160,
+            // cholesky.c:6-27): lane i computes column i of U, row j in step j
+            bool pd = true;
+            static_for<0, M>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                double dot = 0.0;
+                static_for<0, j>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    row_fma<j>(dot, Ucol[k], Ucol[k]);  // U[k, j] * U[k, me]
+                });
+                const bool masked = clamp != 0 || ((cm >> j) & 1u);
+                const double a = masked ? ((me == j) ? 1.0 : 0.0) : Hrow[j];
+                double sv = a - dot;
+                dpp_source(sv);
+                const double piv = row_get<j>(sv);
+                if(piv <= 0.0) pd = false;
+                const double d = sqrt(piv);
+                Ucol[j] = (me == j) ? d : ((me > j) ? 1.0 / d * sv : 0.0);
+                dpp_source(Ucol[j]);
+            });
+            if(!pd) { rc = -1; break; }
+            // explicit inverse (cholesky.c:51-74): lane l solves U'U y = e_l; y[k] for k >= l is row l of the inverse
+            double y[M], ny[M];
+            static_for<0, M>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                double v = (k == me) ? 1.0 : 0.0;
+                static_for<0, k>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    row_fma<k>(v, Ucol[i], ny[i]);  // v -= y[i] * U[i, k]    (y[i] = 0 for i < l: exact zeros)
+                });
+                y[k] = v / row_get<k>(Ucol[k]);
+                ny[k] = -y[k];
+            });
+            static_for<0, M>([&](auto kr) {
+                constexpr int k = M - 1 - decltype(kr)::value;
+                double v = y[k];
+                static_for<k + 1, M>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    row_fma<i>(v, Ucol[k], ny[i]);  // v -= y[i] * U[k, i]
+                });
+                y[k] = v / row_get<k>(Ucol[k]);
+                ny[k] = -y[k];
+            });
+            wave_sync();
+            if(lane < M) {
+#pragma unroll
+                for(int k = 0; k < M; k++)
+                    if(k >= me) S_invH[ut(me, k)] = y[k];
+            }
+            wave_sync();
+#pragma unroll
+            for(int j = 0; j < M; j++) invrow[j] = S_invH[sy(me, j)];
+        }
+
+        if(gnorm < min_grad * min_grad) { rc = 5; break; }
+
+        // search(free) = -invH(free,free) (g + H x_clamped)(free) - x(free); search(clamped) = 0 (boxQP.c:170-196)
+        double hc = 0.0;
+        static_for<0, M>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if((cm >> j) & 1u) row_fma<j>(hc, x, Hrow[j]);
+        });
+        double gc = g + hc;
+        dpp_source(gc);
+        double sr = -x;
+        static_for<0, M>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if(!((cm >> j) & 1u)) row_fma<j>(sr, gc, -invrow[j]);
+        });
+        double search = clamp ? 0.0 : sr;
+        dpp_source(search);
+
+        double sdotg = 0.0;
+        static_for<0, M>([&](auto ic) { row_fma2<decltype(ic)::value>(sdotg, search, grad); });
+        if(sdotg >= 0.0) { rc = -2; break; }
+
+        // Armijo line search (boxQP.c:203-228)
+        double step = 1.0, vc, xc;
+        bool tiny = false;
+        for(;;) {
+            xc = x + step * search;
+            if(xc > upper) xc = upper;
+            if(xc < lower) xc = lower;
+            vc = qp_value(xc);
+            if(((vc - oldvalue) / (step * sdotg)) >= armijo) break;
+            step = step * step_dec;
+            if(step < min_step) { tiny = true; break; }
+        }
+        if(tiny) { rc = 2; break; }
+        x = xc;
+        value = vc;
+    }
+    wave_sync();
+    if(lane < M) {
+        S_l[me] = x;
+        S_clamp[me] = clamp;
+    }
+    wave_sync();
+    return rc;
+}
+
 template <int NX, int NU>
 struct RowLds {
     static constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
@@ -85,8 +279,16 @@ struct RowLds {
     double T1[LDX * NX], T2[LDX * NU];   // Vxx fx, Vxx fu
     double Qxu[LDX * NU];                // NX x NU
     double Qu[NU], Quu[SUU], QuuF[SUU];
-    double K[LDU * NX], BA[LDU * NX];    // gains (NU x NX), Quu K
-    double l[NU], invH[SUU];
+    double l[NU];
+    union {
+        struct {                         // from the box QP to the end of the step
+            double K[LDU * NX], BA[LDU * NX];  // gains (NU x NX), Quu K
+            double invH[SUU];
+        };
+        struct {                         // from the start of the step to the assembly of the Q blocks
+            double dxx[SXX], duu[SUU], dxu[NXU];  // sum_i Vx[i] * (fxx_i, fuu_i, fxu_i), in the arrays' own order
+        };
+    };
     int clamp[NU];
 };
 
@@ -104,6 +306,8 @@ struct RecordSource {
     ILQG_DEV double cxu(int i) const { return F.cxu[i]; }
     ILQG_DEV double cxx(int e) const { return F.cxx[e]; }
     ILQG_DEV double cuu(int e) const { return F.cuu[e]; }
+    // the tensors slice by slice: slice(i) is whatever identifies slice i, f??(slice, e) entry e of it
+    ILQG_DEV int slice(int i) const { return i; }
     ILQG_DEV double fxu(int i, int e) const { return F.fxu[e + i * NXU]; }
     ILQG_DEV double fuu(int i, int e) const { return F.fuu[e + i * SUU]; }
     ILQG_DEV double fxx(int i, int e) const { return F.fxx[e + i * SXX]; }
@@ -118,7 +322,12 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     static_assert(NX <= 16 && NU <= 16, "one 16-lane row per matrix row block");
     constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
     constexpr int LDX = NX + 1, LDU = NU + 1;
-    const int lane = threadIdx.x & 63;
+    // Everything below that depends on the lane alone (rows, columns, the LDS and record addresses made of them) is
+    // loop invariant in the sweep, and the optimiser would move all of it — some hundred values — in front of the
+    // loop and keep it in registers, i.e. spill it.  The lane number is made opaque here, once per step: the
+    // addresses are recomputed by a few integer instructions where they are used.
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
     const int g = lane >> 4, c = lane & 15;
     const int cx_ = (c < NX) ? c : 0, cu_ = (c < NU) ? c : 0;  // this lane's column, clamped into range
     int a[4], ax[4], au[4];                                    // this lane's rows 4g+j, clamped into range
@@ -163,47 +372,44 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         cuu_e[j] = D.cuu(euu[j]);
         cxx_e[j] = D.cxx(exx[j]);
     }
-    const double lo_k = F.lower[lane % NU], up_k = F.upper[lane % NU];
+    const double lo_k = F.lower[(lane & 15) % NU], up_k = F.upper[(lane & 15) % NU];
     const double u_l = F.u[cu_];
 
-    // ---- second-order terms of the dynamics (back_pass.c:95-131): sum_i Vx[i] * tensor_i[entry], i ascending.
-    // The slices of the next chunk are requested before the current chunk is consumed.
-    double txu[4] = {0.0, 0.0, 0.0, 0.0}, tuu[4] = {0.0, 0.0, 0.0, 0.0}, txx[4] = {0.0, 0.0, 0.0, 0.0};
+    // ---- second-order terms of the dynamics (back_pass.c:95-131): d[e] = sum_i Vx[i] * tensor_i[e], i ascending.
+    // Here the lanes take the entries e of a tensor slice in the array's own order (e = lane, lane + 64, ...: consecutive
+    // lanes on consecutive doubles, every lane busy) and hand the sums to the lanes that own them through LDS.
     if(FULL) {
-#ifndef ILQG_ROW_CH
-#define ILQG_ROW_CH 2
+        constexpr int NTX = (SXX + 63) / 64, NTU = (SUU + 63) / 64, NTC = (NXU + 63) / 64;
+        double dxx[NTX], duu[NTU], dxu[NTC];
+#pragma unroll
+        for(int q = 0; q < NTX; q++) dxx[q] = 0.0;
+#pragma unroll
+        for(int q = 0; q < NTU; q++) duu[q] = 0.0;
+#pragma unroll
+        for(int q = 0; q < NTC; q++) dxu[q] = 0.0;
+#ifndef ILQG_ROW_UNROLL
+#define ILQG_ROW_UNROLL 2
 #endif
-        constexpr int CH = ILQG_ROW_CH, NCH = (NX + CH - 1) / CH;
-        double buf[2][CH][12];
-        auto request = [&](auto cc, double (&v)[CH][12]) {
-            constexpr int i0 = decltype(cc)::value * CH;
+#pragma unroll ILQG_ROW_UNROLL
+        for(int i = 0; i < NX; i++) {
+            const double vxi = lane_bcast(vxl, i);  // Vx[i] (lane i holds it)
+            const auto slice = D.slice(i);
 #pragma unroll
-            for(int q = 0; q < CH; q++) {
-                const int i = (i0 + q < NX) ? i0 + q : 0;
+            for(int q = 0; q < NTC; q++) dxu[q] += vxi * D.fxu(slice, (lane + 64 * q < NXU) ? lane + 64 * q : 0);
 #pragma unroll
-                for(int j = 0; j < 4; j++) {
-                    v[q][j] = D.fxu(i, exu[j]);
-                    v[q][4 + j] = D.fuu(i, euu[j]);
-                    v[q][8 + j] = D.fxx(i, exx[j]);
-                }
-            }
-        };
-        request(std::integral_constant<int, 0>{}, buf[0]);
-        static_for<0, NCH>([&](auto cc) {
-            constexpr int ch = decltype(cc)::value, i0 = ch * CH;
-            if constexpr(ch + 1 < NCH) request(std::integral_constant<int, ch + 1>{}, buf[(ch + 1) & 1]);
-            static_for<0, CH>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                if constexpr(i0 + q < NX) {
+            for(int q = 0; q < NTU; q++) duu[q] += vxi * D.fuu(slice, (lane + 64 * q < SUU) ? lane + 64 * q : 0);
 #pragma unroll
-                    for(int j = 0; j < 4; j++) {
-                        row_fma<i0 + q>(txu[j], vxl, buf[ch & 1][q][j]);
-                        row_fma<i0 + q>(tuu[j], vxl, buf[ch & 1][q][4 + j]);
-                        row_fma<i0 + q>(txx[j], vxl, buf[ch & 1][q][8 + j]);
-                    }
-                }
-            });
-        });
+            for(int q = 0; q < NTX; q++) dxx[q] += vxi * D.fxx(slice, (lane + 64 * q < SXX) ? lane + 64 * q : 0);
+        }
+#pragma unroll
+        for(int q = 0; q < NTC; q++)
+            if(lane + 64 * q < NXU) S.dxu[lane + 64 * q] = dxu[q];
+#pragma unroll
+        for(int q = 0; q < NTU; q++)
+            if(lane + 64 * q < SUU) S.duu[lane + 64 * q] = duu[q];
+#pragma unroll
+        for(int q = 0; q < NTX; q++)
+            if(lane + 64 * q < SXX) S.dxx[lane + 64 * q] = dxx[q];
     }
     // fx, fu into LDS
 #pragma unroll
@@ -216,85 +422,117 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         const int i = lane + 64 * q;
         if(i < NXU) S.fu[(i % NX) + (i / NX) * LDX] = fu_in[q];
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- T1 = Vxx fx, T2 = Vxx fu (the `ba` / `bc` temporaries of matMult.c); Qu = cu + fu'Vx, Qx = cx + fx'Vx
-    double fxc[NX], fuc[NX];  // column c of fx and of fu
-#pragma unroll
-    for(int s = 0; s < NX; s++) {
-        fxc[s] = S.fx[s + cx_ * LDX];
-        fuc[s] = S.fu[s + cu_ * LDX];
-    }
     double qxl = cxl, qul = cul;  // Qx[c], Qu[c]
-    row_dot<NX>(qul, vxl, fuc);
-    row_dot<NX>(qxl, vxl, fxc);
     {
-        double t1[4] = {0.0, 0.0, 0.0, 0.0}, t2[4] = {0.0, 0.0, 0.0, 0.0};
+        double fxc[NX];  // column c of fx
+#pragma unroll
+        for(int s = 0; s < NX; s++) fxc[s] = S.fx[s + cx_ * LDX];
+        row_dot<NX>(qxl, vxl, fxc);
+        double t1[4] = {0.0, 0.0, 0.0, 0.0};
         row_product<NX>(t1, vxx_r, fxc);
+#pragma unroll
+        for(int j = 0; j < 4; j++)
+            if(a[j] < NX && c < NX) S.T1[a[j] + c * LDX] = t1[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        double fuc[NX];  // column c of fu
+#pragma unroll
+        for(int s = 0; s < NX; s++) fuc[s] = S.fu[s + cu_ * LDX];
+        row_dot<NX>(qul, vxl, fuc);
+        double t2[4] = {0.0, 0.0, 0.0, 0.0};
         row_product<NX>(t2, vxx_r, fuc);
 #pragma unroll
-        for(int j = 0; j < 4; j++) {
-            if(a[j] < NX && c < NX) S.T1[a[j] + c * LDX] = t1[j];
+        for(int j = 0; j < 4; j++)
             if(a[j] < NX && c < NU) S.T2[a[j] + c * LDX] = t2[j];
-        }
     }
     if(g == 0 && c < NU) S.Qu[c] = qul;
-    __syncthreads();
+    wave_sync();
     if(pf) pf->probe(0);
 
     // ---- Qxu = cxu + fx'T2, Quu = cuu + fu'T2 (symmetrised), Qxx = cxx + fx'T1 (symmetrised)   back_pass.c:90-131
+    // Three blocks, each with its operands read from LDS right in front of it and nothing but its results alive behind
+    // it (the scheduling barriers keep the reads of a later block from being issued — and held in registers — early).
     double qxu_r[4], qxx_r[4];  // Qxu[4g+j, c], Qxx[4g+j, c]
     {
-        double t1c[NX], t2c[NX];            // column c of T1 and of T2
-        double fxt[4], fut[4], t1t[4], t2t[4];  // fx[c, 4g+j], fu[c, 4g+j], T1[c, 4g+j], T2[c, 4g+j]: what row mates read
+        double t2c[NX];  // column c of T2
+#pragma unroll
+        for(int s = 0; s < NX; s++) t2c[s] = S.T2[s + cu_ * LDX];
+        {
+            double fxt[4];  // fx[c, 4g+j]: what the row mates read
+#pragma unroll
+            for(int j = 0; j < 4; j++) fxt[j] = S.fx[cx_ + ax[j] * LDX];
+            dpp_source(fxt);
+            double dxu[4] = {0.0, 0.0, 0.0, 0.0};
+            row_product<NX>(dxu, fxt, t2c);  // sum_si fx[si, r] * T2[si, c]
+#pragma unroll
+            for(int j = 0; j < 4; j++) {
+                double v = cxu_e[j] + dxu[j];
+                if(FULL) v += S.dxu[exu[j]];
+                qxu_r[j] = v;
+                if(a[j] < NX && c < NU) S.Qxu[a[j] + c * LDX] = v;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            double fuc2[NX], fut[4], t2t[4];  // column c of fu; fu[c, 4g+j], T2[c, 4g+j]
+#pragma unroll
+            for(int s = 0; s < NX; s++) fuc2[s] = S.fu[s + cu_ * LDX];
+#pragma unroll
+            for(int j = 0; j < 4; j++) {
+                fut[j] = S.fu[cx_ + au[j] * LDX];
+                t2t[j] = S.T2[cx_ + au[j] * LDX];
+            }
+            dpp_source(fut);
+            dpp_source(t2t);
+            double suu[4] = {0.0, 0.0, 0.0, 0.0}, suu_d[4];
+            row_product<NX>(suu, fut, t2c);     // sum_si fu[si, r] * T2[si, c] ...
+#pragma unroll
+            for(int j = 0; j < 4; j++) suu_d[j] = suu[j];  // a diagonal entry stops here
+            row_product_t<NX>(suu, fuc2, t2t);  // ... + sum_si fu[si, c] * T2[si, r]      (r < c)
+#pragma unroll
+            for(int j = 0; j < 4; j++) {
+                double v = cuu_e[j] + ((a[j] == c) ? suu_d[j] : suu[j] * 0.5);
+                if(FULL) v += S.duu[euu[j]];
+                if(a[j] <= c && c < NU) {
+                    S.Quu[ut(au[j], cu_)] = v;
+                    S.QuuF[ut(au[j], cu_)] = (regType == 1 && a[j] == c) ? v + lambda : v;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        double t1c[NX], fxc2[NX], fxt[4], t1t[4];  // columns c of T1 and fx; fx[c, 4g+j], T1[c, 4g+j]
 #pragma unroll
         for(int s = 0; s < NX; s++) {
             t1c[s] = S.T1[s + cx_ * LDX];
-            t2c[s] = S.T2[s + cu_ * LDX];
+            fxc2[s] = S.fx[s + cx_ * LDX];
         }
 #pragma unroll
         for(int j = 0; j < 4; j++) {
             fxt[j] = S.fx[cx_ + ax[j] * LDX];
             t1t[j] = S.T1[cx_ + ax[j] * LDX];
-            fut[j] = S.fu[cx_ + au[j] * LDX];
-            t2t[j] = S.T2[cx_ + au[j] * LDX];
         }
         dpp_source(fxt);
-        dpp_source(fut);
         dpp_source(t1t);
-        dpp_source(t2t);
-        double dxu[4] = {0.0, 0.0, 0.0, 0.0}, suu[4] = {0.0, 0.0, 0.0, 0.0}, sxx[4] = {0.0, 0.0, 0.0, 0.0};
-        row_product<NX>(dxu, fxt, t2c);    // sum_si fx[si, r] * T2[si, c]
-        row_product<NX>(suu, fut, t2c);    // sum_si fu[si, r] * T2[si, c] ...
+        double sxx[4] = {0.0, 0.0, 0.0, 0.0}, sxx_d[4];
         row_product<NX>(sxx, fxt, t1c);
-        double suu_d[4], sxx_d[4];         // diagonal entries stop after the first half sum
+#pragma unroll
+        for(int j = 0; j < 4; j++) sxx_d[j] = sxx[j];
+        row_product_t<NX>(sxx, fxc2, t1t);
 #pragma unroll
         for(int j = 0; j < 4; j++) {
-            suu_d[j] = suu[j];
-            sxx_d[j] = sxx[j];
-        }
-        row_product_t<NX>(suu, fuc, t2t);  // ... + sum_si fu[si, c] * T2[si, r]      (r < c)
-        row_product_t<NX>(sxx, fxc, t1t);
-#pragma unroll
-        for(int j = 0; j < 4; j++) {
-            const double uu = (a[j] == c) ? suu_d[j] : suu[j] * 0.5;
-            const double xx = (a[j] == c) ? sxx_d[j] : sxx[j] * 0.5;
-            double vxu = cxu_e[j] + dxu[j], vuu = cuu_e[j] + uu, vxx = cxx_e[j] + xx;
-            if(FULL) {
-                vxu += txu[j];
-                vuu += tuu[j];
-                vxx += txx[j];
-            }
-            qxu_r[j] = vxu;
-            qxx_r[j] = vxx;
-            if(a[j] < NX && c < NU) S.Qxu[a[j] + c * LDX] = vxu;
-            if(a[j] <= c && c < NU) {
-                S.Quu[ut(au[j], cu_)] = vuu;
-                S.QuuF[ut(au[j], cu_)] = (regType == 1 && a[j] == c) ? vuu + lambda : vuu;
-            }
+            double v = cxx_e[j] + ((a[j] == c) ? sxx_d[j] : sxx[j] * 0.5);
+            if(FULL) v += S.dxx[exx[j]];
+            qxx_r[j] = v;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    wave_sync();
     if(pf) pf->probe(1);
 
     // regType 2, literally as in the reference (back_pass.c:136-155)
@@ -319,13 +557,13 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
             for(int s = 0; s < NX; s++) acc += S.fx[s + i * LDX] * S.fu[((s + q * NU) % NX) + ((s + q * NU) / NX) * LDX];
             qxur_r[j] = qxu_r[j] + acc * lambda;
         }
-        __syncthreads();
+        wave_sync();
     }
     if(pf) pf->probe(2);
 
     // ---- box QP, one lane per input (box_qp_rows); warm start: the later step's solution in S.l (back_pass.c:163-166)
     int nf;
-    const int rc = box_qp_rows<NU>(S.QuuF, S.Qu[lane % NU], lo_k, up_k, S.l, S.clamp, S.invH, nf);
+    const int rc = box_qp_row<NU>(S.QuuF, S.Qu[(lane & 15) % NU], lo_k, up_k, S.l, S.clamp, S.invH, nf);
     if(pf) pf->probe(3);
     if(rc < 1) return rc;
 
@@ -379,7 +617,7 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
             }
         if(g == 0 && c < NU) lout[c] = S.l[c];
     }
-    __syncthreads();
+    wave_sync();
     if(pf) pf->probe(4);
 
     // ---- Quu l, Quu K; expected cost change (back_pass.c:205-214)
@@ -412,7 +650,7 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         dV0 += qi * li;
         dV1 += 0.5 * li * bi;
     }
-    __syncthreads();
+    wave_sync();
     if(pf) pf->probe(5);
 
     // ---- Vx, Vxx with the unregularised Quu / Qxu (back_pass.c:219-241)
@@ -475,7 +713,7 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         }
         gsum += gmax;
     }
-    __syncthreads();
+    wave_sync();
     if(pf) pf->probe(6);
     return rc;
 }

@@ -61,6 +61,20 @@ struct WaveLds {
 // Results: x -> S_l[i], flags -> S_clamp[i], inverse of the free Hessian (full-index form, packed) -> S_invH,
 // all in LDS, where the gain formula reads them.  Returns the reference's code, wave-uniform.
 // ---------------------------------------------------------------------------
+// Hand-over of LDS data between the lanes of ONE wavefront.  A wavefront's LDS operations execute in issue order, so
+// a lane's read behind another lane's write of the same wavefront sees it; all that is needed is that the compiler
+// keeps that order.  (No s_barrier: a workgroup may hold several wavefronts, each working on a trajectory of its own at
+// its own pace.)
+ILQG_DEV void wave_sync() {
+#ifdef ILQG_WAVE_SYNC_BARRIER
+    __syncthreads();
+    return;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 ILQG_DEV double lane_bcast(double v, int src) {  // src: wave-uniform lane number
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -167,13 +181,13 @@ ILQG_DEV int box_qp_rows(const double *Hpacked /* LDS */, const double g, const 
                 for(int i = k + 1; i < M; i++) v -= y[i] * lane_bcast(Ucol[k], i);
                 y[k] = v / lane_bcast(Ucol[k], k);
             }
-            __syncthreads();
+            wave_sync();
             if(lane < M) {
 #pragma unroll
                 for(int k = 0; k < M; k++)
                     if(k >= me) S_invH[ut(me, k)] = y[k];
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for(int j = 0; j < M; j++) invrow[j] = S_invH[sy(me, j)];
         }
@@ -217,12 +231,12 @@ ILQG_DEV int box_qp_rows(const double *Hpacked /* LDS */, const double g, const 
         x = xc;
         value = vc;
     }
-    __syncthreads();
+    wave_sync();
     if(lane < M) {
         S_l[me] = x;
         S_clamp[me] = clamp;
     }
-    __syncthreads();
+    wave_sync();
     return rc;
 }
 
@@ -345,7 +359,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
     double u_k[NU];
 #pragma unroll
     for(int i = 0; i < NU; i++) u_k[i] = R.u[i];
-    __syncthreads();
+    wave_sync();
 
     // Qu = cu + fu'Vx ; Qx = cx + fx'Vx   (addMulVec, matMult.c:3-12)
 #pragma unroll
@@ -375,7 +389,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         reads_before_math();
         (second ? S.T1 : S.T2)[r + q * LDX] = dot_acc(0.0, row, col);
     }
-    __syncthreads();
+    wave_sync();
 
     if(pf) pf->probe(0);
     // Qxu = cxu + fx' T2 (+ sum_i Vx_i fxu_i)        (back_pass.c:90-102)
@@ -429,7 +443,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         }
         (isxx ? S.Qxx : S.Quu)[e] = v;
     }
-    __syncthreads();
+    wave_sync();
 
     if(pf) pf->probe(1);
     // regularisation (back_pass.c:134-159); regType 2 literally as in the reference
@@ -457,7 +471,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         }
         S.Qxur[j] = v;
     }
-    __syncthreads();
+    wave_sync();
 
     if(pf) pf->probe(2);
     // box QP, one lane per input (box_qp_rows); warm start: the later step's solution in S.l (back_pass.c:163-166)
@@ -505,7 +519,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         Kout[o] = v;
     }
     for(int i = lane; i < NU; i += 64) lout[i] = S.l[i];
-    __syncthreads();
+    wave_sync();
 
     if(pf) pf->probe(4);
     // expected cost change, redundantly on every lane (back_pass.c:205-214)
@@ -542,7 +556,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
             S.ba[r + c * LDU] = dot_acc(0.0, qrow, kcol);
         }
     }
-    __syncthreads();
+    wave_sync();
 
     if(pf) pf->probe(5);
     // Vx, Vxx with the unregularised Quu / Qxu (back_pass.c:219-241)
@@ -601,7 +615,7 @@ __device__ __forceinline__ int back_step_wave(WaveLds<NX, NU> &S, const StepFiel
         if(gi > gmax) gmax = gi;
     }
     gsum += gmax;
-    __syncthreads();
+    wave_sync();
     if(pf) pf->probe(6);
     return rc;
 }

@@ -590,6 +590,34 @@ def test_wave_mapping_synthetic_golden(ilqg, fd):
     s.close()
 
 
+@pytest.mark.parametrize("strict", [False, True])
+def test_factored_tensors_equal_stored_tensors(ilqg, strict):
+    """n=16 FULL_DDP: the backward pass that multiplies the tensors out of the generated coefficient tables (records
+    carry the 32 products of a step; option fuse_derivs) against the one that reads fxx/fuu/fxu from the records.
+    Same products in the same order: bit-identical without FMA contraction.  B = 9: the workgroups that share the
+    tables hold several trajectories, the last one is partly filled."""
+    g = golden("synth16x8_fd1.npz")
+    N = int(g["n_hor"])
+    B, iters = 9, 4
+    x0, u0 = syn_inputs(B, N, first=200)
+    res = []
+    for fuse in (0, 1):
+        s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT,
+                             opts=dict(max_iter=iters, fuse_derivs=fuse), strict=strict)
+        s.init(x0, u0)
+        s.iterate(iters)
+        l, L = s.gains()
+        res.append((s.scalar("cost"), s.x(), s.u(), l, L, s.scalar("lambda"), s.ints("alpha_idx"), s.ints("bp_calls")))
+        s.close()
+    a, b = res
+    assert np.array_equal(a[6], b[6]) and np.array_equal(a[7], b[7])
+    for va, vb in zip(a[:6], b[:6]):
+        if strict:
+            assert np.array_equal(va, vb), worst(va, vb)
+        else:
+            assert close(va, vb, 1e-9), worst(va, vb)
+
+
 def test_wave_mapping_chunked_records(ilqg, monkeypatch):
     """a work buffer smaller than the batch: derivative records are produced and consumed chunk by chunk"""
     g = golden("synth16x8_fd0.npz")

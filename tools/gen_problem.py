@@ -272,28 +272,36 @@ class Emitter:
         self.tensor_tables = self._factor_tensors() if prob.cse else None
 
     def _factor_tensors(self):
-        """{'basis': [products], 'xx': (coefficients, basis numbers), 'uu': ..., 'xu': ...} in the array order of
-        fxx / fuu / fxu if every entry is one number times one product (or zero), else None"""
+        """{'basis': [products], 'xx': (coefficients, product number per slice), 'uu': ..., 'xu': ...} in the array
+        order of fxx / fuu / fxu, if every entry of slice i (the second derivatives of f_i) is a number times ONE
+        product shared by the whole slice (or zero); else None"""
         st = SharedTerms(self)
         basis, number, tables = [], {}, {}
         for nm, ten in (("xx", self.fxx), ("uu", self.fuu), ("xu", self.fxu)):
-            coefs, bases = [], []
-            for lhs, e in self.jaco2_items("f" + nm, ten):
-                terms = st.split(e) if e != 0 else []
-                if len(terms) > 1 or (terms and terms[0][1] is None):
-                    return None
-                if not terms:
-                    coefs.append(0.0)
-                    bases.append(0)
-                    continue
-                coef, prod = terms[0]
-                if prod not in number:
-                    number[prod] = len(basis)
-                    basis.append(prod)
-                coefs.append(float(coef))
-                bases.append(number[prod])
-            tables[nm] = (coefs, bases)
-        if not basis or len(basis) > 255:
+            items = self.jaco2_items("f" + nm, ten)
+            per_slice = len(items) // self.n
+            coefs, slices = [], []
+            for i in range(self.n):
+                shared = None
+                for lhs, e in items[i * per_slice:(i + 1) * per_slice]:
+                    terms = st.split(e) if e != 0 else []
+                    if len(terms) > 1 or (terms and terms[0][1] is None):
+                        return None
+                    if not terms:
+                        coefs.append(0.0)
+                        continue
+                    coef, prod = terms[0]
+                    if shared is None:
+                        shared = prod
+                    elif prod != shared:
+                        return None
+                    coefs.append(float(coef))
+                if shared is not None and shared not in number:
+                    number[shared] = len(basis)
+                    basis.append(shared)
+                slices.append(number[shared] if shared is not None else 0)
+            tables[nm] = (coefs, slices)
+        if not basis:
             return None
         tables["basis"] = basis
         return tables
@@ -792,16 +800,31 @@ int calc_derivs(tOptSet *o) {
         for items in (self.grad_items("cx", self.Lx), self.hess_items("cxx", self.Lxx), self.grad_items("cu", self.Lu),
                       self.hess_items("cuu", self.Luu), self.hess_items("cxu", self.Lxu)):
             cost += self.block(items, True, cse=cse) + "\n"
-        if cse:
-            cse.use("second")
+        cse2 = cse
+        if self.tensor_tables:
+            cse2 = SharedTerms(self, "ct")  # a function of its own (bp_derivsL_second): its own names
+        if cse2:
+            cse2.use("second")
         second = ""
         for nm, ten in (("fxx", self.fxx), ("fuu", self.fuu), ("fxu", self.fxu)):
             if not self.all_zero(ten):
-                second += self.block(self.jaco2_items(nm, ten), True, cse=cse) + "\n"
-        if cse:
-            out += "    /* products shared by several entries */\n" + cse.declarations("first") + "\n"
-            second = "    /* products shared by the entries of the tensors */\n" + cse.declarations("second") + "\n" + second
-        out += "    /* dynamics */\n" + first + "#if FULL_DDP\n" + second + "#endif\n    /* cost */\n" + cost + "    return 1;\n}\n\n"
+                second += self.block(self.jaco2_items(nm, ten), True, cse=cse2) + "\n"
+        if cse2:
+            second = "    /* products shared by the entries of the tensors */\n" + cse2.declarations("second") + "\n" + second
+            if not self.tensor_tables:
+                out += "    /* products shared by several entries */\n" + cse.declarations("first") + "\n"
+        if self.tensor_tables:
+            # the part a back-end that evaluates the tensors from the factored tables still needs, on its own
+            head = "    const double *const x= t->x;\n    const double *const u= t->u;\n\n"
+            out = ("static int bp_derivsL_first(trajEl_t *t, int k, double **p) {\n" + head +
+                   "    /* products shared by several entries */\n" + cse.declarations("first") + "\n"
+                   "    /* dynamics */\n" + first + "    /* cost */\n" + cost + "    return 1;\n}\n\n"
+                   "#if FULL_DDP\nstatic int bp_derivsL_second(trajEl_t *t, int k, double **p) {\n" + head +
+                   second + "    return 1;\n}\n#endif\n\n"
+                   "static int bp_derivsL(trajEl_t *t, int k, double **p) {\n    if(!bp_derivsL_first(t, k, p)) return 0;\n"
+                   "#if FULL_DDP\n    if(!bp_derivsL_second(t, k, p)) return 0;\n#endif\n    return 1;\n}\n\n")
+        else:
+            out += "    /* dynamics */\n" + first + "#if FULL_DDP\n" + second + "#endif\n    /* cost */\n" + cost + "    return 1;\n}\n\n"
 
         out += "static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {\n" + self.prologue("x", "wf", "p", "kN")
         out += self.aux_block(self.fin_need, ("d1", "d2"), True) + "    return 1;\n}\n\n"
@@ -957,8 +980,9 @@ class SharedTerms:
     first-order entries are declared unconditionally, products only the second derivatives of f need inside
     #if FULL_DDP (their auxiliaries only exist there)."""
 
-    def __init__(self, emitter):
+    def __init__(self, emitter, prefix="cs"):
         self.em = emitter
+        self.prefix = prefix
         self.pools = {"first": [], "second": []}
         self.names = {}
         self.pool = "first"
@@ -976,7 +1000,7 @@ class SharedTerms:
 
     def name_of(self, product):
         if product not in self.names:
-            self.names[product] = sp.Symbol("cs%d" % len(self.names))
+            self.names[product] = sp.Symbol("%s%d" % (self.prefix, len(self.names)))
             self.pools[self.pool].append(product)
         return self.names[product]
 
@@ -997,23 +1021,21 @@ def _emit_factored_tensors(self):
         return ""
     T = self.tensor_tables
     out = ("\n#if FULL_DDP\n/* ---- additive: the second derivatives of the dynamics in factored form (batched back-ends; the\n"
-           " * reference's solver never reads this).  Every entry is ONE number times ONE of ILQG_TENSOR_NBASIS shared\n"
-           " * products,\n *     t->fxx[e] == ilqg_tensor_coef_xx[e] * basis[ilqg_tensor_base_xx[e]]      (likewise fuu, fxu)\n"
-           " * and bp_tensor_basis() evaluates the products of one step exactly as bp_derivsL does. */\n"
+           " * reference's solver never reads this).  Every entry of slice i (the second derivatives of f_i) is a number\n"
+           " * times ONE product shared by the slice,\n"
+           " *     t->fxx[i*sizeofQxx + e] == ilqg_tensor_coef_xx[i*sizeofQxx + e] * basis[ilqg_tensor_slice_xx[i]]   (likewise fuu, fxu)\n"
+           " * and bp_tensor_basis() evaluates the ILQG_TENSOR_NBASIS products of one step exactly as bp_derivsL does. */\n"
            "static int bp_tensor_basis(double *basis, trajEl_t *t, int k, double **p) {\n"
            "    const double *const x= t->x;\n    const double *const u= t->u;\n\n")
     for i, prod in enumerate(T["basis"]):
         out += self.assign("basis[%d]" % i, prod)
     out += "    return 1;\n}\n\n"
     for nm in ("xx", "uu", "xu"):
-        coef, base = T[nm]
+        coef, slices = T[nm]
         out += "static const double ilqg_tensor_coef_%s[%d]= {\n" % (nm, len(coef))
         for i in range(0, len(coef), 6):
             out += "    " + ", ".join(cexpr(sp.Float(c)) if c != 0 else "0.0" for c in coef[i:i + 6]) + ",\n"
-        out += "};\nstatic const unsigned char ilqg_tensor_base_%s[%d]= {\n" % (nm, len(base))
-        for i in range(0, len(base), 32):
-            out += "    " + ", ".join(str(b) for b in base[i:i + 32]) + ",\n"
-        out += "};\n"
+        out += "};\nstatic const int ilqg_tensor_slice_%s[N_X]= {%s};\n" % (nm, ", ".join(str(b) for b in slices))
     out += "#endif\n"
     return out
 

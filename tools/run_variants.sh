@@ -5,7 +5,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 ARGS=$1; shift
 mkdir -p $R/gpurun_out/variants
 for v in "$@"; do
-  ILQG_LIBDIR=$R/ddp-generator_amd/lib_$v timeout -k 10 300 python3 $R/bench.py $ARGS > $R/gpurun_out/variants/$v.json 2> $R/gpurun_out/variants/$v.err || { echo "$v failed"; tail -3 $R/gpurun_out/variants/$v.err; }
+  L=$R/ddp-generator_amd/lib_$v; [ "$v" = default ] && L=$R/ddp-generator_amd/lib
+  ILQG_LIBDIR=$L timeout -k 10 300 python3 $R/bench.py $ARGS > $R/gpurun_out/variants/$v.json 2> $R/gpurun_out/variants/$v.err || { echo "$v failed"; tail -3 $R/gpurun_out/variants/$v.err; }
   python3 - "$v" "$R/gpurun_out/variants/$v.json" <<'PY'
 import json, sys
 try:

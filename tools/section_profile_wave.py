@@ -13,11 +13,14 @@ s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=synth.SYNTH16_PARA
 s.init(x0, u0)
 out = (C.c_ulonglong * 8)()
 s.lib.ilqg_dev_section_cycles(out)
-names = ["stage fx,fu; Qu,Qx; Vxx*fx, Vxx*fu", "Qxu, Quu, Qxx incl. tensors", "regularisation", "box QP (every lane, size 8)",
-         "gains", "dV, Quu*l, Quu*K", "Vx, Vxx, g_norm", "loop head"]
+names = ["loads, tensors, Vxx*fx, Vxx*fu, Qu, Qx", "Qxu, Quu, Qxx", "regularisation", "box QP",
+         "gains", "dV, Quu*l, Quu*K", "Vx, Vxx, g_norm"]
 for it in range(K):
     s.iterate(1); s.sync()
     s.lib.ilqg_dev_section_cycles(out)
     calls = s.ints("bp_calls").sum()
-    v = np.array(list(out), dtype=float) / max(1, calls) / N   # per sweep and step
-    print("iteration %d (%.2f sweeps per trajectory): %.0f ticks per step: " % (it + 1, calls / B, v.sum()) + ", ".join("%s %.0f" % (n, x) for n, x in zip(names, v)))
+    v = np.array(list(out), dtype=float)
+    steps = max(1.0, v[7])  # steps executed by all sweeps, abandoned ones included
+    v = v[:7] / steps
+    print("iteration %d (%.2f sweeps per trajectory, %.0f steps): %.0f ticks per step: " % (it + 1, calls / B, steps / B, v.sum())
+          + ", ".join("%s %.0f" % (n, x) for n, x in zip(names, v)))

@@ -7,4 +7,5 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; FLAGS=$2; PROB=${3:-synth16x8}; FD=${4:-1}
 make -s -C $R/ddp-generator_amd/csrc PROBLEMS=$PROB WAVE_PROBLEMS= LIBDIR=../lib_$NAME OBJDIR=../build_$NAME \
     EXTRA_HIPFLAGS="$FLAGS" ../lib_$NAME/libilqg_${PROB}_fd${FD}_hip.so 2>&1 | grep -v "argument unused" || true
-ls -la $R/ddp-generator_amd/lib_$NAME/
+cp -n $R/ddp-generator_amd/lib/*.so $R/ddp-generator_amd/lib_$NAME/  # everything else: the product build
+ls -la $R/ddp-generator_amd/lib_$NAME/ | grep ${PROB}_fd${FD}_hip.so
