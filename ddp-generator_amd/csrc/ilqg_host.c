@@ -56,6 +56,8 @@ struct ilqg_batch {
     double **p;                      /* owned copies of the problem parameters */
     char *p_given;                   /* which of them the caller has set */
     int params_pushed;
+    double *scratch;                 /* host arrays of the drop-in entry points, kept between calls */
+    size_t scratch_doubles;
     char err[512];
 };
 
@@ -294,6 +296,7 @@ void ilqg_batch_destroy(ilqg_batch_t *c) {
     for(i = 0; i < n_params; i++) free(c->p[i]);
     free(c->p);
     free(c->p_given);
+    free(c->scratch);
     free(c);
 }
 
@@ -354,15 +357,17 @@ int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value
         return 0;
     }
     if(strcmp(name, "alpha") == 0) {
+        /* the option set only borrows the array (iLQG.c:101): it is validated on the caller's values first, and only
+         * an accepted set replaces the stored one */
+        tOptSet probe = c->opt;
         if(n > ILQG_MAX_ALPHA) return fail_msg(c, "at most 16 alpha values");
+        e = setOptParam(&probe, name, value, n);
+        if(e) return fail_msg(c, e);
         memcpy(c->alpha_store, value, sizeof(double) * n);
         value = c->alpha_store;
     }
     e = setOptParam(&c->opt, name, value, n);
-    if(e) {
-        snprintf(c->err, sizeof(c->err), "%s", e);
-        return 1;
-    }
+    if(e) return fail_msg(c, e);
     return 0;
 }
 
@@ -703,21 +708,32 @@ static void pack_xu(const traj_t *tr, int N, double *x, double *u) {
     memcpy(x + N * N_X, tr->f.x, sizeof(double) * N_X);
 }
 
+/* host arrays of the drop-in entry points: one block owned by the backend, grown on demand */
+static double *dropin_scratch(ilqg_batch_t *c, size_t doubles, const char *who) {
+    if(doubles > c->scratch_doubles) {
+        free(c->scratch);
+        c->scratch = (double *)malloc(sizeof(double) * doubles);
+        c->scratch_doubles = c->scratch ? doubles : 0;
+        if(!c->scratch) fatal_no_device(who, "out of host memory");
+    }
+    return c->scratch;
+}
+
 /* Backward Riccati sweep of the nominal trajectory on the GPU.
  * Same contract as reference back_pass.c:38-257: reads the derivative fields
  * calc_derivs() left in o->nominal, writes t[k].l, t[k].L, o->dV, o->g_norm;
- * returns 0, or 1 when the box QP failed at some step. */
+ * returns 0, or 1 when the box QP failed at some step.
+ * All transfers of the call are queued on the stream and waited for once (ilqg_dev_io_begin / _end). */
 int back_pass(tOptSet *o) {
-    ilqg_batch_t *c = backend_of(o, "back_pass()");
+    static const char who[] = "back_pass()";
+    ilqg_batch_t *c = backend_of(o, who);
+    ilqg_dev_t *d = c->dev[0];
     const int N = o->n_hor;
-    double *rec = (double *)malloc(sizeof(double) * ((size_t)N * REC_HOST_SIZE + FIN_SIZE));
-    double *fin = rec + (size_t)N * REC_HOST_SIZE;
-    double *x = (double *)malloc(sizeof(double) * ((size_t)(N + 1) * N_X + (size_t)N * N_U));
-    double *u = x + (size_t)(N + 1) * N_X;
-    double *l = (double *)malloc(sizeof(double) * (size_t)N * (N_U + N_U * N_X));
-    double *L = l + (size_t)N * N_U;
-    double *r = rec, v;
-    int k, rc, zero = 0;
+    const size_t n_rec = (size_t)N * REC_HOST_SIZE + FIN_SIZE, n_u = (size_t)N * N_U, n_l = (size_t)N * N_U, n_L = (size_t)N * N_U * N_X;
+    double *rec = dropin_scratch(c, n_rec + n_u + n_l + n_L, who);
+    double *fin = rec + (size_t)N * REC_HOST_SIZE, *u = rec + n_rec, *l = u + n_u, *L = l + n_l;
+    double *r = rec, g_norm = 0.0;
+    int k, rc = 1, zero = 0;
 
     for(k = 0; k < N; k++) {
         const trajEl_t *t = &o->nominal->t[k];
@@ -730,32 +746,31 @@ int back_pass(tOptSet *o) {
 #endif
         PUT(t->lower_sign, N_U); PUT(t->upper_sign, N_U);
         PUT(t->lower_hx, N_X * N_U); PUT(t->upper_hx, N_X * N_U);
+        memcpy(u + (size_t)k * N_U, t->u, sizeof(double) * N_U);
     }
     r = fin;
     PUT(o->nominal->f.cx, N_X); PUT(o->nominal->f.cxx, sizeofQxx);
 #undef PUT
-    pack_xu(o->nominal, N, x, u);
 
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_DER, rec), "back_pass()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_FIN, fin), "back_pass()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_U, u), "back_pass()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_LAMBDA, &o->lambda), "back_pass()");
-    DEV_OK(ilqg_dev_write_int(c->dev[0], ILQG_I_STATUS, &zero), "back_pass()");
-    DEV_OK(ilqg_dev_backward(c->dev[0], 1), "back_pass()");
-    DEV_OK(ilqg_dev_read_int(c->dev[0], ILQG_I_BP_RC, &rc), "back_pass()");
-    DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_LG, l), "back_pass()");
-    DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_KG, L), "back_pass()");
-    DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_DV0, &o->dV[0]), "back_pass()");
-    DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_DV1, &o->dV[1]), "back_pass()");
-    if(!rc) {
-        DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_GNORM, &v), "back_pass()");
-        o->g_norm = v;
-    }
+    DEV_OK(ilqg_dev_io_begin(d), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_DER, rec), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_FIN, fin), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_U, u), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_LAMBDA, &o->lambda), who);
+    DEV_OK(ilqg_dev_write_int(d, ILQG_I_STATUS, &zero), who);
+    DEV_OK(ilqg_dev_backward(d, 1), who);
+    DEV_OK(ilqg_dev_read_int(d, ILQG_I_BP_RC, &rc), who);
+    DEV_OK(ilqg_dev_read(d, ILQG_F_LG, l), who);
+    DEV_OK(ilqg_dev_read(d, ILQG_F_KG, L), who);
+    DEV_OK(ilqg_dev_read(d, ILQG_F_DV0, &o->dV[0]), who);
+    DEV_OK(ilqg_dev_read(d, ILQG_F_DV1, &o->dV[1]), who);
+    DEV_OK(ilqg_dev_read(d, ILQG_F_GNORM, &g_norm), who);
+    DEV_OK(ilqg_dev_io_end(d), who);
+    if(!rc) o->g_norm = g_norm;  /* an abandoned sweep leaves it alone (back_pass.c:168-171,254) */
     for(k = 0; k < N; k++) {
-        memcpy(o->nominal->t[k].l, l + k * N_U, sizeof(double) * N_U);
-        memcpy(o->nominal->t[k].L, L + k * N_U * N_X, sizeof(double) * N_U * N_X);
+        memcpy(o->nominal->t[k].l, l + (size_t)k * N_U, sizeof(double) * N_U);
+        memcpy(o->nominal->t[k].L, L + (size_t)k * N_U * N_X, sizeof(double) * N_U * N_X);
     }
-    free(rec); free(x); free(l);
     return rc;
 }
 
@@ -765,52 +780,55 @@ int back_pass(tOptSet *o) {
  * line_search.c:33-78: candidate left in o->candidates[0], o->new_cost /
  * dcost / expected and the optional logs written; returns 1 if accepted. */
 int line_search(tOptSet *o, int iter) {
-    ilqg_batch_t *c = backend_of(o, "line_search()");
+    static const char who[] = "line_search()";
+    ilqg_batch_t *c = backend_of(o, who);
+    ilqg_dev_t *d = c->dev[0];
     const int N = o->n_hor;
-    double *x = (double *)malloc(sizeof(double) * ((size_t)(N + 1) * N_X + (size_t)N * N_U));
-    double *u = x + (size_t)(N + 1) * N_X;
-    double *l = (double *)malloc(sizeof(double) * (size_t)N * (N_U + N_U * N_X));
-    double *L = l + (size_t)N * N_U;
-    int k, accepted, idx, zero = 0;
-    double cnew, dcost, expected, z, tmp;
+    const size_t n_x = (size_t)(N + 1) * N_X, n_u = (size_t)N * N_U, n_L = (size_t)N * N_U * N_X;
+    double *x = dropin_scratch(c, 2 * n_x + 3 * n_u + n_L, who);
+    double *u = x + n_x, *l = u + n_u, *L = l + n_u, *xc = L + n_L, *uc = xc + n_x;
+    int k, accepted = 0, idx = 0, zero = 0;
+    double cnew = 0.0, dcost = 0.0, expected = 0.0, z, tmp;
 
     pack_xu(o->nominal, N, x, u);
     for(k = 0; k < N; k++) {
-        memcpy(l + k * N_U, o->nominal->t[k].l, sizeof(double) * N_U);
-        memcpy(L + k * N_U * N_X, o->nominal->t[k].L, sizeof(double) * N_U * N_X);
+        memcpy(l + (size_t)k * N_U, o->nominal->t[k].l, sizeof(double) * N_U);
+        memcpy(L + (size_t)k * N_U * N_X, o->nominal->t[k].L, sizeof(double) * N_U * N_X);
     }
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_X, x), "line_search()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_U, u), "line_search()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_LG, l), "line_search()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_KG, L), "line_search()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_COST, &o->cost), "line_search()");
+    DEV_OK(ilqg_dev_io_begin(d), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_X, x), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_U, u), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_LG, l), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_KG, L), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_COST, &o->cost), who);
     if(sizeof(multipliersEl_t) > 0) { /* structs of doubles (iLQG_problem.tem:70-89): the array as it is */
-        DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_MUL, (const double *)o->multipliers.t), "line_search()");
+        DEV_OK(ilqg_dev_write(d, ILQG_F_MUL, (const double *)o->multipliers.t), who);
     }
     if(sizeof(multipliersFin_t) > 0) {
-        DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_MULF, (const double *)&o->multipliers.f), "line_search()");
+        DEV_OK(ilqg_dev_write(d, ILQG_F_MULF, (const double *)&o->multipliers.f), who);
     }
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_WPEN_L, &o->w_pen_l), "line_search()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_WPEN_F, &o->w_pen_f), "line_search()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_DV0, &o->dV[0]), "line_search()");
-    DEV_OK(ilqg_dev_write(c->dev[0], ILQG_F_DV1, &o->dV[1]), "line_search()");
-    DEV_OK(ilqg_dev_write_int(c->dev[0], ILQG_I_STATUS, &zero), "line_search()");
-    DEV_OK(ilqg_dev_search(c->dev[0]), "line_search()");
-    DEV_OK(ilqg_dev_winner(c->dev[0]), "line_search()");
-    DEV_OK(ilqg_dev_read_int(c->dev[0], ILQG_I_ACCEPTED, &accepted), "line_search()");
-    DEV_OK(ilqg_dev_read_int(c->dev[0], ILQG_I_ALPHA_IDX, &idx), "line_search()");
-    DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_NEW_COST, &cnew), "line_search()");
-    DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_DCOST, &dcost), "line_search()");
-    DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_EXPECTED, &expected), "line_search()");
+    DEV_OK(ilqg_dev_write(d, ILQG_F_WPEN_L, &o->w_pen_l), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_WPEN_F, &o->w_pen_f), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_DV0, &o->dV[0]), who);
+    DEV_OK(ilqg_dev_write(d, ILQG_F_DV1, &o->dV[1]), who);
+    DEV_OK(ilqg_dev_write_int(d, ILQG_I_STATUS, &zero), who);
+    DEV_OK(ilqg_dev_search(d), who);
+    DEV_OK(ilqg_dev_winner(d), who);
+    DEV_OK(ilqg_dev_read_int(d, ILQG_I_ACCEPTED, &accepted), who);
+    DEV_OK(ilqg_dev_read_int(d, ILQG_I_ALPHA_IDX, &idx), who);
+    DEV_OK(ilqg_dev_read(d, ILQG_F_NEW_COST, &cnew), who);
+    DEV_OK(ilqg_dev_read(d, ILQG_F_DCOST, &dcost), who);
+    DEV_OK(ilqg_dev_read(d, ILQG_F_EXPECTED, &expected), who);
+    DEV_OK(ilqg_dev_read(d, ILQG_F_X, xc), who);  /* the stored winner; unchanged nominal if nothing was accepted */
+    DEV_OK(ilqg_dev_read(d, ILQG_F_U, uc), who);
+    DEV_OK(ilqg_dev_io_end(d), who);
     if(accepted) {
         traj_t *cand = o->candidates[0];
-        DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_X, x), "line_search()");
-        DEV_OK(ilqg_dev_read(c->dev[0], ILQG_F_U, u), "line_search()");
         for(k = 0; k < N; k++) {
-            memcpy(cand->t[k].x, x + k * N_X, sizeof(double) * N_X);
-            memcpy(cand->t[k].u, u + k * N_U, sizeof(double) * N_U);
+            memcpy(cand->t[k].x, xc + (size_t)k * N_X, sizeof(double) * N_X);
+            memcpy(cand->t[k].u, uc + (size_t)k * N_U, sizeof(double) * N_U);
         }
-        memcpy(cand->f.x, x + N * N_X, sizeof(double) * N_X);
+        memcpy(cand->f.x, xc + (size_t)N * N_X, sizeof(double) * N_X);
         /* let the generated code refresh the members it caches per step (auxiliaries, c)
          * from the stored x,u: its cost-only mode touches nothing else (iLQG_func.tem:160-176) */
         forward_pass(cand, o, 0.0, &tmp, 1);
@@ -822,7 +840,6 @@ int line_search(tOptSet *o, int iter) {
     o->new_cost = cnew;
     o->dcost = dcost;
     o->expected = expected;
-    free(x); free(l);
     return accepted;
 }
 
@@ -831,7 +848,7 @@ int boxQP(double *H, const double *g, const double *lower, const double *upper, 
           double *L, double *grad, double *grad_clamped, double *search, int *is_clamped, int *n_free_,
           double *invHfree, const int n) {
     int rc = 0, i, j, fi, fj;
-    double inv_full[36];
+    double inv_full[(N_U * (N_U + 1) / 2 > 36) ? N_U * (N_U + 1) / 2 : 36];  /* n <= max(8, N_U) */
     (void)Hfree; (void)L; (void)grad; (void)grad_clamped; (void)search;
     if(n != 2 && n != 8 && n != N_U) {
         fprintf(stderr, "ilqg: boxQP on the device supports n in {2, 8, N_U}, got %d\n", n);
@@ -965,3 +982,91 @@ int iLQG(tOptSet *o) {
     o->iterations = iter;
     return (done && iter < o->max_iter) ? 1 : 0;
 }
+
+/* =========================================================================
+ * the reference's MEX entry without MEX                 iLQG_mex.c:19-144
+ * =========================================================================
+ * [success, x, u, cost] = iLQG<Problem>(x0, u_nom, params, opts) for a C caller: same sequence — options by
+ * name through setOptParam, every parameter of paramdesc[] by name with its length checked, trajectory buffers,
+ * init_opt, the initial roll-out, iLQG() — and the same messages.  x is [n_hor+1][N_X], u is [n_hor][N_U] (the MEX
+ * entry's column-major x_new(n,N), u_new(m,N-1)).  Returns iLQG()'s 1 / 0, or -1 with a message in err when an
+ * argument is refused (where the MEX entry raises an error).  seconds: wall time of the iLQG() call alone, as the
+ * reference times it (iLQG_mex.c:123-126). */
+#include <time.h>
+
+static const ilqg_named_t *find_named(const ilqg_named_t *list, int n, const char *name) {
+    int i;
+    for(i = 0; i < n; i++)
+        if(strcmp(list[i].name, name) == 0) return &list[i];
+    return NULL;
+}
+
+int ilqg_solve_single(int n_hor, const double *x0, const double *u_nom, const ilqg_named_t *params, int n_given,
+                      const ilqg_named_t *opts, int n_opts, double *x, double *u, double *cost, int *iterations,
+                      double *seconds, char *err, int err_len) {
+    tOptSet o = INIT_OPTSET;
+    struct timespec t0, t1;
+    int i, k, ok = 0, success = 0;
+    double x0_copy[N_X];
+
+    if(err && err_len > 0) err[0] = 0;
+    if(seconds) *seconds = 0.0;
+    if(n_hor < 2) {
+        if(err) snprintf(err, err_len, "There must be more than one time step.");
+        return -1;
+    }
+    memcpy(x0_copy, x0, sizeof(x0_copy));
+    o.x0 = x0_copy;
+    o.n_hor = n_hor;
+    standard_parameters(&o);
+    for(i = 0; i < n_opts; i++) {
+        char *msg = setOptParam(&o, opts[i].name, opts[i].value, opts[i].n);
+        if(msg) {
+            if(err) snprintf(err, err_len, "Error setting optimization parameter '%s': %s.", opts[i].name, msg);
+            return -1;
+        }
+    }
+    o.p = (double **)calloc(n_params > 0 ? n_params : 1, sizeof(double *));
+    for(i = 0; i < n_params; i++) {
+        const int want = (paramdesc[i]->size == -1) ? n_hor + 1 : paramdesc[i]->size;
+        const ilqg_named_t *g = find_named(params, n_given, paramdesc[i]->name);
+        if(!g) {
+            if(err) snprintf(err, err_len, "Parameter name '%s' is not member of parameters struct.", paramdesc[i]->name);
+            free(o.p);
+            return -1;
+        }
+        if(g->n != want) {
+            if(err) snprintf(err, err_len, "Parameter name '%s' must be a vector length %d.", paramdesc[i]->name, want);
+            free(o.p);
+            return -1;
+        }
+        o.p[i] = (double *)g->value;  /* borrowed, as in the reference */
+    }
+    for(i = 0; i < NUMBER_OF_THREADS + 1; i++) o.trajectories[i].t = (trajEl_t *)calloc(n_hor, sizeof(trajEl_t));
+    o.multipliers.t = (multipliersEl_t *)calloc(n_hor + 1, sizeof(multipliersEl_t) > 0 ? sizeof(multipliersEl_t) : 1);
+
+    if(init_opt(&o)) {
+        for(k = 0; k < n_hor; k++) memcpy(o.nominal->t[k].u, u_nom + (size_t)k * N_U, sizeof(double) * N_U);
+        if(forward_pass(o.candidates[0], &o, 0.0, &o.cost, 0)) {
+            makeCandidateNominal(&o, 0);
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            success = iLQG(&o);
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if(seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+            for(k = 0; k < n_hor; k++) {
+                memcpy(x + (size_t)k * N_X, o.nominal->t[k].x, sizeof(double) * N_X);
+                memcpy(u + (size_t)k * N_U, o.nominal->t[k].u, sizeof(double) * N_U);
+            }
+            memcpy(x + (size_t)n_hor * N_X, o.nominal->f.x, sizeof(double) * N_X);
+            ok = 1;
+        }
+    }
+    if(cost) *cost = o.cost;
+    if(iterations) *iterations = o.iterations;
+    ilqg_release(&o);
+    free(o.p);
+    for(i = 0; i < NUMBER_OF_THREADS + 1; i++) free(o.trajectories[i].t);
+    free(o.multipliers.t);
+    return ok ? success : 0;
+}
+

@@ -1871,6 +1871,16 @@ struct ilqg_dev {
     ParamValues pv;       // fixed-size parameters, passed to the kernels by value
     double *staging;
     size_t staging_bytes;
+    // Deferred transfers (ilqg_dev_io_begin .. ilqg_dev_io_end): every write / read takes its own slice of the device
+    // staging buffer and of a pinned host buffer and nothing waits; the stream is synchronised once, at the end, and
+    // the reads are handed to the caller then.  (The drop-in back_pass() / line_search() move two dozen small arrays
+    // per call: one wait instead of one per array.)
+    bool io_deferred;
+    size_t io_off;
+    char *pinned;
+    size_t pinned_bytes;
+    struct PendingRead { void *dst; const void *src; size_t bytes; int transpose_w; };
+    std::vector<PendingRead> pending;
     int *counter;
     int chunk;            // wave mapping: trajectories whose derivative records fit the work buffer
     bool work_consts;     // wave mapping: constant entries of the records written (init_running)
@@ -1933,6 +1943,69 @@ int ensure_staging(ilqg_dev *d, size_t bytes) {
     d->staging_bytes = 0;
     HIP_TRY(hipMalloc((void **)&d->staging, bytes));
     d->staging_bytes = bytes;
+    return 0;
+}
+
+// end of a deferred batch (or of a part of it): wait once, deliver the reads
+int io_flush(ilqg_dev *d) {
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for(const auto &r : d->pending) {
+        if(r.transpose_w) {  // int field: device [width][Bp] -> host [B][width]
+            const int *src = (const int *)r.src;
+            int *dst = (int *)r.dst;
+            for(int b = 0; b < d->B; b++)
+                for(int j = 0; j < r.transpose_w; j++) dst[(size_t)b * r.transpose_w + j] = src[(size_t)j * d->Bp + b];
+        } else {
+            memcpy(r.dst, r.src, r.bytes);
+        }
+    }
+    d->pending.clear();
+    d->io_off = 0;
+    return 0;
+}
+
+// Staging for one transfer of `bytes`: *dev in the device staging buffer and, while transfers are deferred, *pin in the
+// pinned host buffer (nullptr otherwise: the transfer then uses the caller's memory and is waited for at once).
+int stage(ilqg_dev *d, size_t bytes, void **dev, void **pin) {
+    if(!d->io_deferred) {
+        if(ensure_staging(d, bytes)) return 1;
+        *dev = d->staging;
+        *pin = nullptr;
+        return 0;
+    }
+    bytes = (bytes + 255) & ~(size_t)255;
+    if(d->io_off + bytes > d->staging_bytes || d->io_off + bytes > d->pinned_bytes) {
+        if(io_flush(d)) return 1;  // what is in flight uses the old buffers
+        const size_t want = (bytes > (1u << 20) ? bytes : (1u << 20)) + 2 * d->pinned_bytes;
+        if(ensure_staging(d, want)) return 1;
+        if(d->pinned) HIP_TRY(hipHostFree(d->pinned));
+        d->pinned = nullptr;
+        d->pinned_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&d->pinned, want, hipHostMallocDefault));
+        d->pinned_bytes = want;
+    }
+    *dev = (char *)d->staging + d->io_off;
+    *pin = d->pinned + d->io_off;
+    d->io_off += bytes;
+    return 0;
+}
+// host -> staging slice / staging slice -> host, according to the mode
+int stage_in(ilqg_dev *d, void *dev, void *pin, const void *host, size_t bytes) {
+    if(pin) {
+        memcpy(pin, host, bytes);
+        host = pin;
+    }
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, d->stream));
+    return 0;
+}
+int stage_out(ilqg_dev *d, const void *dev, void *pin, void *host, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(pin ? pin : host, dev, bytes, hipMemcpyDeviceToHost, d->stream));
+    if(pin) d->pending.push_back({host, pin, bytes, 0});
+    else HIP_TRY(hipStreamSynchronize(d->stream));
+    return 0;
+}
+int io_done(ilqg_dev *d) {  // end of a single write
+    if(!d->io_deferred) HIP_TRY(hipStreamSynchronize(d->stream));
     return 0;
 }
 
@@ -2011,6 +2084,8 @@ const char *ilqg_dev_kernel_name(int k) {
     return (k >= 0 && k < ILQG_K_COUNT) ? names[k] : "?";
 }
 
+static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor);
+
 int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
     *out = nullptr;
     if(batch < 1 || n_hor < 2) {
@@ -2024,13 +2099,28 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
         return 1;
     }
     HIP_TRY(hipSetDevice(device));
-    ilqg_dev *d = new ilqg_dev();
+    ilqg_dev *d = new ilqg_dev();  // value-initialised: every pointer and handle is null until it is acquired
+    if(dev_fill(d, device, batch, n_hor)) {
+        const std::string why = g_err;
+        ilqg_dev_destroy(d);  // releases whatever the failed attempt had acquired
+        g_err = why;
+        return 1;
+    }
+    *out = d;
+    return 0;
+}
+
+static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
     d->device = device;
     d->B = batch;
     d->Bp = (batch + WAVE - 1) / WAVE * WAVE;
     d->N = n_hor;
     d->staging = nullptr;
     d->staging_bytes = 0;
+    d->io_deferred = false;
+    d->io_off = 0;
+    d->pinned = nullptr;
+    d->pinned_bytes = 0;
     d->timing = false;
     memset(d->t_ms, 0, sizeof(d->t_ms));
     memset(d->t_n, 0, sizeof(d->t_n));
@@ -2101,14 +2191,14 @@ int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
     d->P.n_pending_next = d->P.n_pending;
     d->P.p = nullptr;
     HIP_TRY(hipStreamSynchronize(d->stream));
-    *out = d;
     return 0;
 }
 
 void ilqg_dev_destroy(ilqg_dev_t *d) {
     if(!d) return;
     hipSetDevice(d->device);
-    hipStreamSynchronize(d->stream);
+    if(d->stream) hipStreamSynchronize(d->stream);
+    if(d->stream2) hipStreamSynchronize(d->stream2);
     for(auto &s : d->spans) {
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
@@ -2117,18 +2207,20 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
         if(d->P.f[f]) hipFree(d->P.f[f]);
     if(d->P.work) hipFree(d->P.work);
     if(d->P.nom) hipFree(d->P.nom);
-    for(int f = 0; f < ILQG_I_COUNT; f++) hipFree(d->P.i[f]);
-    hipFree(d->P.derivs_failed);
-    hipFree(d->counter);
-    hipFree(d->P.pending);
-    hipFree(d->P.n_pending);
+    for(int f = 0; f < ILQG_I_COUNT; f++)
+        if(d->P.i[f]) hipFree(d->P.i[f]);
+    if(d->P.derivs_failed) hipFree(d->P.derivs_failed);
+    if(d->counter) hipFree(d->counter);
+    if(d->P.pending) hipFree(d->P.pending);
+    if(d->P.n_pending) hipFree(d->P.n_pending);
     for(double *p : d->param_bufs) hipFree(p);
     if(d->P.p) hipFree(d->P.p);
     if(d->staging) hipFree(d->staging);
-    hipStreamDestroy(d->stream);
-    hipStreamDestroy(d->stream2);
-    hipEventDestroy(d->fork);
-    hipEventDestroy(d->join);
+    if(d->pinned) hipHostFree(d->pinned);
+    if(d->stream) hipStreamDestroy(d->stream);
+    if(d->stream2) hipStreamDestroy(d->stream2);
+    if(d->fork) hipEventDestroy(d->fork);
+    if(d->join) hipEventDestroy(d->join);
     delete d;
 }
 
@@ -2204,17 +2296,17 @@ static bool is_traj_major(int field) { return WAVE_MAP && field == ILQG_F_FIN; }
 static int nom_io(ilqg_dev *d, int field, double *host_rw, const double *host_ro, int steps) {
     const FieldInfo fi = field_info(field);
     const size_t n = (size_t)d->B * steps * fi.wh;
-    if(ensure_staging(d, n * sizeof(double))) return 1;
-    if(host_ro) HIP_TRY(hipMemcpyAsync(d->staging, host_ro, n * sizeof(double), hipMemcpyHostToDevice, d->stream));
+    void *dev, *pin;
+    if(stage(d, n * sizeof(double), &dev, &pin)) return 1;
+    if(host_ro && stage_in(d, dev, pin, host_ro, n * sizeof(double))) return 1;
     {
         Timed t(d, ILQG_K_TRANSPOSE);
-        hipLaunchKernelGGL(k_nom_io, grid1(n, 256), dim3(256), 0, d->stream, d->P.nom, d->staging, d->B, d->N, steps,
+        hipLaunchKernelGGL(k_nom_io, grid1(n, 256), dim3(256), 0, d->stream, d->P.nom, (double *)dev, d->B, d->N, steps,
                            fi.wh, nom_column(field), host_ro ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
-    if(host_rw) HIP_TRY(hipMemcpyAsync(host_rw, d->staging, n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    return 0;
+    if(host_rw) return stage_out(d, dev, pin, host_rw, n * sizeof(double));
+    return io_done(d);
 }
 
 #if ILQG_WAVE_MAP
@@ -2266,7 +2358,7 @@ int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps
     }
 #if ILQG_WAVE_MAP
     if(field == ILQG_F_DER) {
-        HIP_TRY(hipStreamSynchronize(d->stream));
+        if(io_flush(d)) return 1;
         return der_io(d, nullptr, host);
     }
 #endif
@@ -2277,22 +2369,28 @@ int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps
     if(is_traj_major(field)) {
         const size_t row = (size_t)steps * fi.wd * sizeof(double);
         const size_t dpitch = (size_t)field_steps(d, field) * fi.wd * sizeof(double);
-        HIP_TRY(hipMemcpy2DAsync(d->P.f[field], dpitch, host, row, row, d->B, hipMemcpyHostToDevice, d->stream));
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        return 0;
+        const void *src = host;
+        if(d->io_deferred) {
+            void *dev, *pin;
+            if(stage(d, row * d->B, &dev, &pin)) return 1;
+            memcpy(pin, host, row * d->B);
+            src = pin;
+        }
+        HIP_TRY(hipMemcpy2DAsync(d->P.f[field], dpitch, src, row, row, d->B, hipMemcpyHostToDevice, d->stream));
+        return io_done(d);
     }
     const size_t n = (size_t)d->B * steps * fi.wh;
-    if(ensure_staging(d, n * sizeof(double))) return 1;
-    HIP_TRY(hipMemcpyAsync(d->staging, host, n * sizeof(double), hipMemcpyHostToDevice, d->stream));
+    void *dev, *pin;
+    if(stage(d, n * sizeof(double), &dev, &pin)) return 1;
+    if(stage_in(d, dev, pin, host, n * sizeof(double))) return 1;
     {
         Timed t(d, ILQG_K_TRANSPOSE);
         const size_t total = (size_t)d->B * steps * fi.wd;
-        hipLaunchKernelGGL(k_to_dev, grid1(total, 256), dim3(256), 0, d->stream, d->staging, d->P.f[field], d->B, d->Bp,
+        hipLaunchKernelGGL(k_to_dev, grid1(total, 256), dim3(256), 0, d->stream, (const double *)dev, d->P.f[field], d->B, d->Bp,
                            steps, fi.wh, fi.wd);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    return 0;
+    return io_done(d);
 }
 
 int ilqg_dev_read(ilqg_dev_t *d, int field, double *host) {
@@ -2302,49 +2400,78 @@ int ilqg_dev_read(ilqg_dev_t *d, int field, double *host) {
     const size_t n = (size_t)d->B * steps * fi.wh;
 #if ILQG_WAVE_MAP
     if(field == ILQG_F_DER) {
-        HIP_TRY(hipStreamSynchronize(d->stream));
+        if(io_flush(d)) return 1;
         return der_io(d, host, nullptr);
     }
 #endif
     if(nom_column(field) >= 0 && !has_tiled_copy(field)) return nom_io(d, field, host, nullptr, steps);
     if(is_traj_major(field)) {
-        HIP_TRY(hipMemcpyAsync(host, d->P.f[field], n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        return 0;
+        void *dev = nullptr, *pin = nullptr;
+        if(d->io_deferred && stage(d, n * sizeof(double), &dev, &pin)) return 1;
+        return stage_out(d, d->P.f[field], pin, host, n * sizeof(double));
     }
-    if(ensure_staging(d, n * sizeof(double))) return 1;
+    void *dev, *pin;
+    if(stage(d, n * sizeof(double), &dev, &pin)) return 1;
     {
         Timed t(d, ILQG_K_TRANSPOSE);
-        hipLaunchKernelGGL(k_from_dev, grid1(n, 256), dim3(256), 0, d->stream, d->P.f[field], d->staging, d->B, d->Bp,
+        hipLaunchKernelGGL(k_from_dev, grid1(n, 256), dim3(256), 0, d->stream, d->P.f[field], (double *)dev, d->B, d->Bp,
                            steps, fi.wh, fi.wd);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host, d->staging, n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    return 0;
+    return stage_out(d, dev, pin, host, n * sizeof(double));
 }
 
 // int fields are [width][Bp] on the device, [B][width] on the host
 int ilqg_dev_write_int(ilqg_dev_t *d, int field, const int *host) {
     HIP_TRY(hipSetDevice(d->device));
     const int w = int_field_width(field);
-    std::vector<int> tmp((size_t)w * d->Bp, 0);
+    const size_t bytes = (size_t)w * d->Bp * sizeof(int);
+    std::vector<int> tmp;
+    int *src;
+    if(d->io_deferred) {
+        void *dev, *pin;
+        if(stage(d, bytes, &dev, &pin)) return 1;
+        src = (int *)pin;
+    } else {
+        tmp.resize((size_t)w * d->Bp);
+        src = tmp.data();
+    }
+    memset(src, 0, bytes);
     for(int b = 0; b < d->B; b++)
-        for(int j = 0; j < w; j++) tmp[(size_t)j * d->Bp + b] = host[(size_t)b * w + j];
-    HIP_TRY(hipMemcpyAsync(d->P.i[field], tmp.data(), tmp.size() * sizeof(int), hipMemcpyHostToDevice, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    return 0;
+        for(int j = 0; j < w; j++) src[(size_t)j * d->Bp + b] = host[(size_t)b * w + j];
+    HIP_TRY(hipMemcpyAsync(d->P.i[field], src, bytes, hipMemcpyHostToDevice, d->stream));
+    return io_done(d);
 }
 
 int ilqg_dev_read_int(ilqg_dev_t *d, int field, int *host) {
     HIP_TRY(hipSetDevice(d->device));
     const int w = int_field_width(field);
+    const size_t bytes = (size_t)w * d->Bp * sizeof(int);
+    if(d->io_deferred) {
+        void *dev, *pin;
+        if(stage(d, bytes, &dev, &pin)) return 1;
+        HIP_TRY(hipMemcpyAsync(pin, d->P.i[field], bytes, hipMemcpyDeviceToHost, d->stream));
+        d->pending.push_back({host, pin, bytes, w});
+        return 0;
+    }
     std::vector<int> tmp((size_t)w * d->Bp, 0);
     HIP_TRY(hipMemcpyAsync(tmp.data(), d->P.i[field], tmp.size() * sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     for(int b = 0; b < d->B; b++)
         for(int j = 0; j < w; j++) host[(size_t)b * w + j] = tmp[(size_t)j * d->Bp + b];
     return 0;
+}
+
+int ilqg_dev_io_begin(ilqg_dev_t *d) {
+    d->io_deferred = true;
+    d->io_off = 0;
+    return 0;
+}
+
+int ilqg_dev_io_end(ilqg_dev_t *d) {
+    HIP_TRY(hipSetDevice(d->device));
+    d->io_deferred = false;
+    return io_flush(d);
 }
 
 #define NEED_PARAMS(d)                                                   \

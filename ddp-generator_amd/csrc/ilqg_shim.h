@@ -129,6 +129,11 @@ int ilqg_dev_read(ilqg_dev_t *d, int field, double *host);
 int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps);
 int ilqg_dev_write_int(ilqg_dev_t *d, int field, const int *host);
 int ilqg_dev_read_int(ilqg_dev_t *d, int field, int *host);
+/* Deferred transfers: between begin and end the write / read calls above return without waiting (each uses its own
+ * slice of a pinned staging buffer); ilqg_dev_io_end waits once for everything on the stream and only then are the
+ * arrays of the read calls filled.  Kernels launched in between run in stream order with the transfers. */
+int ilqg_dev_io_begin(ilqg_dev_t *d);
+int ilqg_dev_io_end(ilqg_dev_t *d);
 int ilqg_dev_field_width(int field);                 /* doubles per step and trajectory (host view) */
 int ilqg_dev_field_steps(ilqg_dev_t *d, int field);  /* time steps stored */
 /* device address of a per-trajectory scalar field (for collectives on device memory) */

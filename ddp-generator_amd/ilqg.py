@@ -23,8 +23,10 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 STATUS = {0: "active", 1: "converged_grad", 2: "converged_fun", 3: "max_iter", 4: "no_descent",
           5: "lambda_max", 6: "derivs_failed", 7: "init_failed"}
-# the reference's iLQG() return value for each exit (1 = "success", iLQG.c:365-378 and SURVEY Appendix B-11)
-REFERENCE_SUCCESS = {1: 1, 2: 1, 5: 1, 3: 0, 4: 0, 6: 0, 7: 0}
+# the reference's iLQG() return value for each exit (1 = "success", iLQG.c:365-378 and SURVEY Appendix B-11).
+# Exit 6 (calc_derivs failed) is not in the table: iLQG() leaves its loop with the back-pass flag of the PREVIOUS
+# iteration (iLQG.c:247-249, 367), i.e. returns 1 unless it happened in the very first iteration — see success().
+REFERENCE_SUCCESS = {1: 1, 2: 1, 5: 1, 3: 0, 4: 0, 7: 0}
 
 MAX_ALPHA = 16
 
@@ -41,6 +43,21 @@ def library_path(problem="carparking", full_ddp=0, strict=False):
 
 
 _libs = {}
+
+
+class _Named(C.Structure):
+    """ilqg_named_t of include/ilqg_batch.h"""
+    _fields_ = [("name", C.c_char_p), ("value", C.POINTER(C.c_double)), ("n", C.c_int)]
+
+
+def _named_list(items):
+    keep = []  # the arrays must outlive the call
+    arr = (_Named * max(1, len(items)))()
+    for i, (k, v) in enumerate(items.items()):
+        a = np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64)
+        keep.append(a)
+        arr[i] = _Named(k.encode(), a.ctypes.data_as(C.POINTER(C.c_double)), a.size)
+    return arr, len(items), keep
 
 
 def load_library(problem="carparking", full_ddp=0, strict=False):
@@ -99,6 +116,8 @@ def load_library(problem="carparking", full_ddp=0, strict=False):
     lib.ilqg_boxqp_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _ip]
     lib.ilqg_boxqp_wave_batch.argtypes = lib.ilqg_boxqp_batch.argtypes
     lib.ilqg_sincos_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+    lib.ilqg_solve_single.argtypes = [C.c_int, _dp, _dp, C.POINTER(_Named), C.c_int, C.POINTER(_Named), C.c_int, _dp, _dp,
+                                      _dp, _ip, _dp, C.c_char_p, C.c_int]
     _libs[path] = lib
     return lib
 
@@ -283,8 +302,10 @@ class BatchSolver:
         self._ck(self.lib.ilqg_batch_set_int(self.h, name.encode(), v))
 
     def success(self):
-        """the reference's iLQG() return value per trajectory"""
-        return np.array([REFERENCE_SUCCESS.get(int(s), 0) for s in self.ints("status")], dtype=np.int32)
+        """the reference's iLQG() return value per trajectory (what the drop-in iLQG() of this library returns too)"""
+        status, iters = self.ints("status"), self.ints("iterations")
+        return np.array([(1 if it > 0 else 0) if int(s) == 6 else REFERENCE_SUCCESS.get(int(s), 0)
+                         for s, it in zip(status, iters)], dtype=np.int32)
 
     # -- plumbing for collectives / profiling ------------------------------
     def cost_device_ptr(self):
@@ -312,6 +333,26 @@ class BatchSolver:
             self._ck(self.lib.ilqg_batch_get_timing(self.h, k, n, ms))
             out[self.lib.ilqg_batch_kernel_name(k).decode()] = (int(n[0]), float(ms[0]))
         return out
+
+
+def solve_single(x0, u_nom, params, opts=None, problem="carparking", full_ddp=0, strict=False):
+    """[success, x, u, cost] = iLQG<Problem>(x0, u_nom, params, opts) — the reference's MEX entry (iLQG_mex.c:19-144)
+    through ilqg_solve_single: the drop-in iLQG() with back_pass() / line_search() on the GPU.
+    Returns dict(success, x [N+1,nx], u [N,nu], cost, iterations, seconds)."""
+    prob = Problem(problem, full_ddp, strict)
+    u_nom = np.ascontiguousarray(u_nom, dtype=np.float64).reshape(-1, prob.nu)
+    n_hor = u_nom.shape[0]
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(prob.nx)
+    p_arr, p_n, keep1 = _named_list(params or {})
+    o_arr, o_n, keep2 = _named_list(opts or {})
+    x = np.zeros((n_hor + 1, prob.nx))
+    u = np.zeros((n_hor, prob.nu))
+    cost, secs, iters = np.zeros(1), np.zeros(1), np.zeros(1, dtype=np.int32)
+    err = C.create_string_buffer(512)
+    rc = prob.lib.ilqg_solve_single(n_hor, x0, u_nom, p_arr, p_n, o_arr, o_n, x, u, cost, iters, secs, err, 512)
+    if rc < 0:
+        raise IlqgError(err.value.decode())
+    return dict(success=int(rc), x=x, u=u, cost=float(cost[0]), iterations=int(iters[0]), seconds=float(secs[0]))
 
 
 def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, device=0, strict=False, cooperative=False):

@@ -128,6 +128,21 @@ int ilqg_batch_scalar_to_device(ilqg_batch_t *c, const char *name, void *dst_dev
 void *ilqg_batch_cost_device_ptr(ilqg_batch_t *c);
 void *ilqg_batch_stream(ilqg_batch_t *c);
 
+/* The reference's MEX entry for a C caller (iLQG_mex.c:19-144):
+ *     [success, x, u, cost] = iLQG<Problem>(x0, u_nom, params, opts)
+ * One trajectory through the drop-in iLQG() (outer loop on the host, back_pass() / line_search() on the GPU).
+ * params: every parameter of the problem by name (length checked against paramdesc[]); opts: setOptParam keys.
+ * x [n_hor+1][N_X], u [n_hor][N_U], cost, iterations, seconds (wall time of iLQG() alone, iLQG_mex.c:123-126) out.
+ * Returns iLQG()'s 1 / 0, or -1 with the MEX entry's message in err when an argument is refused. */
+typedef struct {
+    const char *name;
+    const double *value;
+    int n;
+} ilqg_named_t;
+int ilqg_solve_single(int n_hor, const double *x0, const double *u_nom, const ilqg_named_t *params, int n_params_given,
+                      const ilqg_named_t *opts, int n_opts, double *x, double *u, double *cost, int *iterations,
+                      double *seconds, char *err, int err_len);
+
 /* per-kernel device time measured with HIP events on the context's stream */
 int ilqg_batch_timing(ilqg_batch_t *c, int enable);
 int ilqg_batch_kernel_count(void);

@@ -482,6 +482,26 @@ def test_dropin_ilqg_symbols(ilqg, oracle_built):
         dd.close()
 
 
+def test_mex_entry_without_mex(ilqg, oracle_built):
+    """ilqg_solve_single = the call sequence of the reference's MEX entry (iLQG_mex.c:55-137) on the product's drop-in
+    iLQG(): same solve as the oracle's, the MEX entry's messages for refused arguments"""
+    g = golden("car_single_fd0.npz")
+    r = ilqg.solve_single(g["x0"], g["u0"], ilqg.CAR_PARAMS, dict(max_iter=6))
+    o = Driver(lib_path("oracle", full_ddp=0), 500, CAR_PARAMS, dict(max_iter=6))
+    assert o.init(g["x0"], g["u0"]) == 1
+    o.solve()
+    assert r["iterations"] == o.scalars()["iterations"] and close(r["cost"], o.scalars()["cost"], 1e-9)
+    assert close(r["x"], o.traj(0)[0], 1e-8) and close(r["u"], o.traj(0)[1], 1e-8)
+    assert r["seconds"] > 0
+    o.close()
+    with pytest.raises(ilqg.IlqgError, match="Parameter name 'cf' is not member of parameters struct"):
+        ilqg.solve_single(g["x0"], g["u0"], {k: v for k, v in ilqg.CAR_PARAMS.items() if k != "cf"})
+    with pytest.raises(ilqg.IlqgError, match="Parameter name 'pf' must be a vector length 4"):
+        ilqg.solve_single(g["x0"], g["u0"], dict(ilqg.CAR_PARAMS, pf=[1.0, 2.0]))
+    with pytest.raises(ilqg.IlqgError, match="Error setting optimization parameter 'zMin': parameter must be in range"):
+        ilqg.solve_single(g["x0"], g["u0"], ilqg.CAR_PARAMS, dict(zMin=2.0))
+
+
 # ---------------------------------------------------------------------------
 # state-dependent input limits and regType 2
 # ---------------------------------------------------------------------------
@@ -917,3 +937,21 @@ def test_option_and_parameter_errors(ilqg):
     with pytest.raises(ilqg.IlqgError, match="was not set"):
         s.init(np.zeros((2, 4)), np.zeros((2, 10, 2)))  # parameters were never given
     s.close()
+
+
+def test_rejected_alpha_leaves_the_step_sizes_alone(ilqg, synth):
+    """a refused option value must not leak into the option set (the alpha array is only borrowed, iLQG.c:101)"""
+    x0, u0 = synth.car_batch(3, 50)
+    res = []
+    for bad in (None, [0.5, 0.9], [2.0, 0.1]):
+        s = ilqg.BatchSolver("carparking", 0, batch=3, n_hor=50, params=ilqg.CAR_PARAMS, opts=dict(ls_split=0))
+        s.set_option("alpha", [1.0, 0.1])
+        if bad is not None:
+            with pytest.raises(ilqg.IlqgError):
+                s.set_option("alpha", bad)
+        s.init(x0, u0)
+        s.calc_derivs(); s.back_pass(); s.line_search()
+        res.append((s.scalar("alpha_cost")[:, :2].copy(), s.ints("alpha_idx").copy()))
+        s.close()
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1])
