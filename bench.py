@@ -19,10 +19,16 @@ single RCCL gather of the per-trajectory costs at the end of the timed window
 (weak scaling: 65 536 trajectories per GPU).  PyTorch is used only for process
 rendezvous, the RCCL collective and device synchronisation.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel from its
-HIP-event time measured inside this run; `cpu_baseline` times the CPU checker
-(the reference's own sources when oracle/_ref was shipped, else the C port) on a
-bounded sample of the same workload on this box's host cores.
+Prints ONE JSON line (rank 0):
+  value / ms_per_step   the timed window (three groups of trajectories on three streams)
+  iteration_roofline    the whole iteration against the HBM roofline with SURVEY 8(d)'s algorithmic bytes
+  roofline              the dominant kernel, timed ALONE (one group, nothing else on the GPU): it evaluates the
+                        derivatives in registers and is bound by fp64 vector issue, so it is priced in flop/s
+  unfused_kernels       the two HBM-bound kernels it replaces, each alone, against the HBM roofline
+  config5               BASELINE config 5 (synthetic n=16, m=8, N=1000, FULL_DDP=1, 16 384 trajectories)
+  dropin_b1             BASELINE config 1 through the drop-in iLQG() (one trajectory, hot path on the GPU)
+  cpu_baseline          the CPU checker (the reference's own sources when oracle/_ref was shipped) on a bounded
+                        sample of the same workload on this box's host cores
 """
 import argparse
 import json
@@ -35,26 +41,48 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_HOR = 500
-NX, NU = 4, 2
-SXX, SUU, NXU = 10, 3, 8
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-
-# ALGORITHMIC bytes per time step and trajectory (doubles x 8 B)
-ALG_BYTES = {
-    "k_derivs": (NX + NU + (NX + NU + SXX + SUU + NXU + NX * NX + NXU + 2 * NU)) * 8,      # 61 dbl = 488 B
-    "k_backward": ((NX + SXX + NU + SUU + NXU + NX * NX + NXU + 2 * NU + NU) + NU + NXU) * 8,  # 67 dbl = 536 B
-    "k_rollout[search]": (NX + 2 * NU + NXU) * 8,                                          # 16 dbl read, shared by all alpha
-    "k_rollout[winner]": (NX + NU) * 8,                                                     # 6 dbl written (winner only)
-}
-# derivatives evaluated inside the backward kernel: priced against the UNFUSED figure of the two
-# kernels it replaces; what it actually moves is 6 dbl read + 10 written = 128 B
-ALG_BYTES["k_backward[fused derivs]"] = ALG_BYTES["k_derivs"] + ALG_BYTES["k_backward"]
-FUSED_MOVED_BYTES = (NX + NU) * 8 + (NX + 2 * NU + NXU) * 8
-ITERATION_BYTES = 1200  # per step and trajectory, SURVEY.md §8(d)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+FP64_PEAK_TFLOPS = 78.6   # fp64 vector peak (spec; half the guide's FP32 vector 157.3 TF); v_fma_f64 measured at
+                          # one per 2.6 ns and SIMD under load = 50 TFLOP/s (profiles/r2_ubench_dpp_row_fma.txt)
 
 
-def cpu_baseline(batch_per_gpu, iters, problem, fd, params, n_hor, make_inputs, budget_s=6.0):
+def tri(n):
+    return n * (n + 1) // 2
+
+
+def algorithmic_bytes(nx, nu, full):
+    """per time step and trajectory, SURVEY.md §8(d) (doubles x 8 B)"""
+    sxx, suu, nxu = tri(nx), tri(nu), nx * nu
+    rec = nx + sxx + nu + suu + nxu + nx * nx + nxu + 2 * nu + (nx * (sxx + suu + nxu) if full else 0)
+    b = {
+        "k_derivs": (nx + nu + rec) * 8,
+        "k_backward": (rec + nu + nu + nxu) * 8,
+        "k_rollout[search]": (nx + 2 * nu + nxu) * 8,   # read once, shared by all step sizes
+        "k_rollout[winner]": (nx + nu) * 8,             # the winner only is stored
+    }
+    b["iteration"] = sum(b.values())
+    return b
+
+
+def backpass_flops(n, m, full):
+    """floating-point operations of ONE time step of the reference's back_pass (back_pass.c:80-251, matMult.c:3-72),
+    a multiply-add counted as 2; the box QP with one factorisation (boxQP.c:75-232) and all inputs free."""
+    sxx, suu, nm = tri(n), tri(m), n * m
+    f = 2 * nm + 2 * n * n                                   # Qu, Qx (addMulVec)
+    f += 2 * n * n * m + 2 * n * nm                          # Qxu (addMul2Tri: Vxx fu, then fx' that)
+    f += 2 * n * n * m + 2 * n * m + (4 * n + 1) * (suu - m)  # Quu (addSquareTri)
+    f += 2 * n * n * n + 2 * n * n + (4 * n + 1) * (sxx - n)  # Qxx (addSquareTri)
+    if full:
+        f += 2 * n * (sxx + suu + nm) + (sxx + suu + nm)     # sum_i Vx[i] * (fxx, fuu, fxu)_i
+    f += 3 * (2 * m * m + 2 * m) + m ** 3 // 3 + 2 * m ** 3 + 4 * m * m  # box QP: values, gradient, factor, inverse, step
+    f += 2 * m * m * n                                       # gains
+    f += 2 * m + 2 * m * m + 3 * m                           # dV
+    f += 2 * m * m + 2 * nm + 2 * nm + 2 * nm                # Vx
+    f += 2 * m * m * n + 2 * m * n + (4 * m + 1) * (sxx - n) + 3 * n * n * m  # Vxx
+    return f
+
+
+def cpu_baseline(batch_per_gpu, iters, problem, fd, params, n_hor, make_inputs, budget_s=6.0, max_per_core=None):
     """CPU checker on a bounded sample of the same workload, one pthread per host core, each solving
     its share of the sample exactly as independent runs of the reference would (oracle/driver.c,
     drv_solve_many).  Returns the JSON object for `cpu_baseline`."""
@@ -73,6 +101,8 @@ def cpu_baseline(batch_per_gpu, iters, problem, fd, params, n_hor, make_inputs, 
     # threads on a loaded many-core host run ~2-3x slower than the single calibration thread: the budget is
     # sized for ~10-20 s of wall time
     sample = int(max(cores, min(32768, budget_s / per_traj * cores)))
+    if max_per_core:  # large problems: the threads share the memory bandwidth and run far slower than the calibration
+        sample = min(sample, max_per_core * cores)
     x0, u0 = make_inputs(sample, n_hor)
     t0 = time.perf_counter()
     cost, its, rc = d.solve_many(x0, u0, cores)
@@ -90,6 +120,88 @@ def cpu_baseline(batch_per_gpu, iters, problem, fd, params, n_hor, make_inputs, 
     }
 
 
+def kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, iters, **opts):
+    """{kernel: (launches, total ms)} of `iters` iterations run as ONE group of trajectories: every launch covers the
+    whole batch and nothing else is on the GPU while it is timed"""
+    s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=n_hor, device=local, params=params,
+                         opts=dict(max_iter=iters + 1, **opts), groups=1)
+    s.init(x0, u0)
+    s.timing(True)
+    s.iterate(iters)
+    s.sync()
+    t = s.kernel_times()
+    s.close()
+    return t
+
+
+def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
+    """BASELINE config 5: synthetic n=16, m=8, N=1000, FULL_DDP=1, 16 384 trajectories, one wavefront per trajectory"""
+    B, N, nx, nu = 16384, 1000, 16, 8
+    alg = algorithmic_bytes(nx, nu, 1)
+    x0, u0 = synth.synth16_batch(B, N)
+    s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, device=local, params=synth.SYNTH16_PARAMS,
+                         opts=dict(max_iter=K + W + 1))
+    s.init(x0, u0)
+    if W > 0:
+        s.iterate(W)
+        s.sync()
+        s.init(x0, u0)
+    s.timing(True)
+    s.sync()
+    t0 = time.perf_counter()
+    s.iterate(K)
+    s.sync()
+    dt = time.perf_counter() - t0
+    times = s.kernel_times()
+    sweeps = float(s.ints("bp_calls").mean())
+    active = s.active()
+    cost = float(s.scalar("cost").mean())
+    s.close()
+    it_s = K / dt
+    iter_bytes = alg["iteration"] * N * B
+    flops = backpass_flops(nx, nu, 1) * N * B  # one sweep per iteration; lambda retries repeat (parts of) it
+    out = {
+        "metric": "iLQG iterations/sec, batch 16384 synthetic problem (n=16,m=8,N=1000, FULL_DDP=1)",
+        "value": it_s, "unit": "iterations/s", "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "dtype": "f64",
+        "config": {"workload": "Synth16x8 batch=16384, 8-alpha line search, FULL_DDP=1, first %d iterations after the "
+                               "initial roll-out" % K,
+                   "mapping": "one wavefront per trajectory (row-mapped backward step); records carry the first-order "
+                              "derivatives and the 32 products the tensors are multiples of (factored tensor tables of "
+                              "the generated file), the backward step multiplies the tensors out",
+                   "backward_sweeps_per_trajectory_in_last_iteration": sweeps},
+        "roofline": {"bound": "hbm", "kernel": "iteration (k_derivs_wave + k_backward_wave + roll-outs)",
+                     "achieved": iter_bytes * it_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": iter_bytes * it_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_iteration": iter_bytes,
+                     "note": "SURVEY 8(d): 91 200 algorithmic bytes per step and trajectory with the tensors "
+                             "materialised (1.49 TB per iteration, ceiling 5.4 it/s); the factored path moves ~7 KB per "
+                             "step instead of 44 KB, the number is the HBM-equivalent rate.  Kernel launches of "
+                             "consecutive chunks overlap on two streams, so no per-launch figure is given.",
+                     "backward_fp64": {"algorithmic_TFLOPs": flops * it_s / 1e12, "peak": FP64_PEAK_TFLOPS,
+                                       "frac": flops * it_s / 1e12 / FP64_PEAK_TFLOPS,
+                                       "note": "reference back_pass arithmetic, one sweep per iteration, over the WHOLE "
+                                               "iteration time"}},
+        "kernels_ms_per_iteration_overlapping": {k: v[1] / K for k, v in times.items() if v[0]},
+        "trajectories_still_active": int(active), "cost_mean_after_window": cost,
+    }
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(B, K, "synth16x8", 1, synth.SYNTH16_PARAMS, N, synth.synth16_batch, budget_s=4.0,
+                                           max_per_core=2)
+    return out
+
+
+def dropin_b1(ilqg, synth, iters=20):
+    """BASELINE config 1 through the drop-in iLQG(): one CarParking trajectory, the reference's demo start"""
+    x0, u0 = synth.car_single()
+    ilqg.solve_single(x0, u0, ilqg.CAR_PARAMS, dict(max_iter=2))  # first call: context, buffers
+    r = ilqg.solve_single(x0, u0, ilqg.CAR_PARAMS, dict(max_iter=iters))
+    n = max(1, r["iterations"])
+    return {"ms_per_iteration": 1e3 * r["seconds"] / n, "iterations": r["iterations"], "cost": r["cost"],
+            "note": "ilqg_solve_single (the MEX entry's call sequence): outer loop and calc_derivs on the host, back_pass() "
+                    "and line_search() on the GPU with a batch of one; a 500-step sweep is a chain of dependent steps, "
+                    "so one trajectory cannot use the GPU — compare cpu_baseline.single_core_ms_per_trajectory_iteration"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,7 +209,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=("car", "synth"), default="car",
                     help="car: BASELINE metric (CarParking n=4,m=2,N=500, 65 536 per GPU); synth: BASELINE config 5 "
-                         "(n=16,m=8,N=1000, FULL_DDP=1, 16 384 per GPU, one wavefront per trajectory)")
+                         "(n=16,m=8,N=1000, FULL_DDP=1, 16 384 per GPU, one wavefront per trajectory) as the headline")
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU")
     ap.add_argument("--n-hor", type=int, default=None)
     ap.add_argument("--full-ddp", type=int, default=None)
@@ -107,7 +219,8 @@ def main():
     ap.add_argument("--resweep", type=int, default=-1, help="-1: library default (off without multipliers)")
     ap.add_argument("--fuse-derivs", type=int, default=1)
     ap.add_argument("--ls-split", type=int, default=3)
-    ap.add_argument("--no-unfused", action="store_true", help="skip the secondary run with materialised derivative records")
+    ap.add_argument("--no-unfused", action="store_true", help="skip the secondary runs (kernels alone, config 5, drop-in)")
+    ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--groups", type=int, default=0,
                     help="independent sets of trajectories advanced on separate HIP streams (0: library default)")
     args = ap.parse_args()
@@ -125,33 +238,20 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    global N_HOR, NX, NU, SXX, SUU, NXU, ALG_BYTES, FUSED_MOVED_BYTES, ITERATION_BYTES
     car = args.workload == "car"
     problem = "carparking" if car else "synth16x8"
     fd = args.full_ddp if args.full_ddp is not None else (0 if car else 1)
     B = args.batch if args.batch is not None else (65536 if car else 16384)
-    N_HOR = args.n_hor if args.n_hor is not None else (500 if car else 1000)
+    n_hor = args.n_hor if args.n_hor is not None else (500 if car else 1000)
     K, W = args.steps, args.warmup
-    if not car:
-        NX, NU = 16, 8
-        SXX, SUU, NXU = NX * (NX + 1) // 2, NU * (NU + 1) // 2, NX * NU
-    rec = NX + SXX + NU + SUU + NXU + NX * NX + NXU + 2 * NU + (NX * (SXX + SUU + NXU) if fd else 0)
-    ALG_BYTES = {  # SURVEY.md 8(d) formulas, doubles x 8 B per step and trajectory
-        "k_derivs": (NX + NU + rec) * 8,
-        "k_backward": (rec + NU + NU + NXU) * 8,
-        "k_rollout[search]": (NX + 2 * NU + NXU) * 8,
-        "k_rollout[winner]": (NX + NU) * 8,
-    }
-    ALG_BYTES["k_backward[fused derivs]"] = ALG_BYTES["k_derivs"] + ALG_BYTES["k_backward"]
-    FUSED_MOVED_BYTES = (NX + NU) * 8 + (NX + 2 * NU + NXU) * 8  # reads (x_k,u_k), writes the packed record of step k
-    ITERATION_BYTES = sum(ALG_BYTES[k] for k in ("k_derivs", "k_backward", "k_rollout[search]", "k_rollout[winner]"))
+    nx, nu = (4, 2) if car else (16, 8)
+    alg = algorithmic_bytes(nx, nu, fd)
     first = pkg.dist.shard_first(rank, B)
-    x0, u0 = synth.car_batch(B, N_HOR, first=first) if car else synth.synth16_batch(B, N_HOR, first=first)
+    x0, u0 = synth.car_batch(B, n_hor, first=first) if car else synth.synth16_batch(B, n_hor, first=first)
     params = ilqg.CAR_PARAMS if car else synth.SYNTH16_PARAMS
-    s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=N_HOR, device=local, params=params,
+    s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=n_hor, device=local, params=params,
                          opts=dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_split=args.ls_split),
                          strict=("wave" if args.mapping == "wave" else False), groups=args.groups)
-    args.full_ddp = fd
     if args.resweep >= 0:
         s.set_option("resweep", args.resweep)
     s.init(x0, u0)
@@ -167,7 +267,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    s.timing(True)
+    s.timing(True)  # (events come from a pool filled here: none is created inside the window)
     barrier()
     t0 = time.perf_counter()
     s.iterate(K)
@@ -184,47 +284,16 @@ def main():
     times = s.kernel_times()
     active = s.active()
     stream_groups = s.groups()
+    wave_mapping = s.problem.wave_mapping
     cost = gathered.cpu().numpy() if world > 1 and rank == 0 else s.scalar("cost")
+    s.close()
 
-    # secondary, untimed for `value`: the same iterations with the derivative records materialised in
-    # HBM (k_derivs + k_backward<0>), the two kernels the HBM roofline of SURVEY 8(d) was written for
-    # It runs as ONE group of trajectories, so that a launch covers the whole batch and nothing else is on the GPU
-    # while it is timed (the timed run above overlaps the kernels of several groups).
-    unfused = {}
-    if rank == 0 and args.fuse_derivs and not args.no_unfused and not s.problem.wave_mapping:
-        s.close()
-        s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=N_HOR, device=local, params=params,
-                             opts=dict(max_iter=max(K, W) + 1, fuse_derivs=0, ls_split=args.ls_split), groups=1)
-        s.init(x0, u0)
-        s.timing(True)
-        s.iterate(5)
-        s.sync()
-        for kname, (n, ms) in s.kernel_times().items():
-            if n and kname in ("k_derivs", "k_backward"):
-                b_alg = ALG_BYTES[kname] * N_HOR * B
-                unfused[kname] = {"avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": b_alg,
-                                  "achieved_GBs": b_alg / (ms / n * 1e-3) / 1e9,
-                                  "frac_of_peak": b_alg / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "stream_groups": 1}
     if rank == 0:
         per_iter = {k: v[1] / max(1, K) for k, v in times.items() if v[0]}
-        # the kernel the HBM roofline is about: the one that accounts for most ALGORITHMIC bytes of an iteration
-        # (the backward pass incl. derivatives: 1 024 of 1 200 B per step and trajectory; the roll-outs read 128 B
-        # shared by all step sizes and are fp64-VALU bound — their times are in kernels_ms_per_iteration)
-        dominant = max((k for k in per_iter if k in ALG_BYTES), key=lambda k: ALG_BYTES[k] * times[k][0])
-        n_launch, total_ms = times[dominant]
-        avg_ms = total_ms / n_launch
-        # per launch; in the wave mapping a kernel is launched once per chunk of trajectories per iteration
-        alg_bytes = ALG_BYTES[dominant] * N_HOR * B * K / n_launch
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (tools/collect_traffic.sh), if committed
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and B == 65536 and car and not s.problem.wave_mapping:
-            traffic = json.load(open(tpath)).get(dominant, {}).get("hbm_bytes_per_launch")
-        iter_bytes = ITERATION_BYTES * N_HOR * B
+        iter_bytes = alg["iteration"] * n_hor * B
         out = {
             "metric": ("iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)" if car else
-                       "iLQG iterations/sec, batch %d synthetic problem (n=16,m=8,N=%d, FULL_DDP=%d)" % (B, N_HOR, fd)),
+                       "iLQG iterations/sec, batch %d synthetic problem (n=16,m=8,N=%d, FULL_DDP=%d)" % (B, n_hor, fd)),
             "value": K / dt,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -237,39 +306,90 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "%s batch=%d per GPU x %d GPU, 8-alpha line search, FULL_DDP=%d, "
-                                   "first %d iterations after the initial roll-out" % ("CarParking" if car else "Synth16x8", B, world, args.full_ddp, K),
-                       "batch_per_gpu": B, "n_hor": N_HOR, "n_x": NX, "n_u": NU, "full_ddp": args.full_ddp,
-                       "mapping": ("one wavefront per trajectory" if s.problem.wave_mapping else
+                                   "first %d iterations after the initial roll-out" % ("CarParking" if car else "Synth16x8", B, world, fd, K),
+                       "batch_per_gpu": B, "n_hor": n_hor, "n_x": nx, "n_u": nu, "full_ddp": fd,
+                       "mapping": ("one wavefront per trajectory" if wave_mapping else
                                    "one lane per trajectory (64 trajectories per wavefront)"),
                        "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split, "resweep": args.resweep,
                        "stream_groups": stream_groups,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": n_launch,
-                         "note": "achieved = ALGORITHMIC bytes of SURVEY 8(d) per launch / average HIP-event "
-                                 "time of a launch. For k_backward[fused derivs] that is the figure of the two "
-                                 "kernels it replaces (k_derivs 488 B + k_backward 536 B per step and trajectory), "
-                                 "as SURVEY 8(d) prescribes; the fused kernel itself moves 176 B per step and "
-                                 "trajectory (48 B read, the 128 B record of the step written = traffic) and is bound by fp64 VALU issue, not by HBM. The batch "
-                                 "advances as stream_groups sets of trajectories on separate streams: a launch "
-                                 "covers one set and shares the GPU with the kernels of the others while it is "
-                                 "timed. See unfused_kernels for the HBM-bound kernels measured alone, and "
-                                 "iteration_roofline for the whole iteration.",
-                         "moved_bytes_per_launch": (FUSED_MOVED_BYTES * N_HOR * B * K / n_launch) if "fused" in dominant else alg_bytes},
-            "unfused_kernels": unfused,
-            "iteration_roofline": {"algorithmic_bytes_per_iteration": iter_bytes,
-                                   "achieved_GBs": iter_bytes * (K / dt) / 1e9 / world * 1.0,
-                                   "frac_of_peak": iter_bytes * (K / dt) / world / 1e9 / HBM_PEAK_GBS},
-            "kernels_ms_per_iteration": per_iter,
+            # PRIMARY: the whole iteration against the HBM roofline, algorithmic bytes of SURVEY 8(d)
+            "iteration_roofline": {"bound": "hbm", "algorithmic_bytes_per_iteration": iter_bytes,
+                                   "achieved_GBs": iter_bytes * (K / dt) / world / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                                   "frac_of_peak": iter_bytes * (K / dt) / world / 1e9 / HBM_PEAK_GBS,
+                                   "note": "1 200 B per step and trajectory for CarParking (derivatives 488 + backward pass "
+                                           "536 + line search 176): what the iteration would move with every stage's "
+                                           "arrays materialised in HBM; the fused kernels move less (roofline.traffic)"},
+            "kernels_ms_per_iteration_overlapping": per_iter,
             "trajectories_still_active": int(active),
             "cost_mean_after_window": float(cost.mean()),
         }
+        secondary = world == 1 and not args.no_unfused and not wave_mapping and car
+        if secondary:
+            # the dominant kernel ALONE: one group of trajectories, so a launch covers the whole batch and shares the
+            # GPU with nothing (in the timed window above three groups overlap and launch times are inflated)
+            iters1 = 8
+            t1 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, iters1, fuse_derivs=1, ls_split=args.ls_split)
+            name = "k_backward[fused derivs]"
+            n_launch, total_ms = t1[name]
+            avg_ms = total_ms / n_launch
+            flops_launch = backpass_flops(nx, nu, fd) * n_hor * B
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath) and B == 65536:
+                tj = json.load(open(tpath))
+                if name in tj:
+                    launches_per_iter = max(1, tj[name].get("groups", 3))
+                    traffic = tj[name]["hbm_bytes_per_launch"] * launches_per_iter
+                    traffic_src = ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                   "tools/collect_traffic.sh; per launch of a third of the batch x %d; NOT collected in "
+                                   "this run)" % launches_per_iter)
+            out["roofline"] = {
+                "bound": "valu_fp64", "kernel": name, "achieved": flops_launch / (avg_ms * 1e-3) / 1e12,
+                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": avg_ms, "launches": n_launch, "stream_groups": 1,
+                "algorithmic_flops_per_launch": flops_launch,
+                "moved_bytes_per_launch": ((nx + nu) * 8 + (nx + 2 * nu + nx * nu) * 8) * n_hor * B,
+                "hbm_equivalent": {"algorithmic_bytes_per_launch": (alg["k_derivs"] + alg["k_backward"]) * n_hor * B,
+                                   "unfused_equivalent_GBs": (alg["k_derivs"] + alg["k_backward"]) * n_hor * B / (avg_ms * 1e-3) / 1e9,
+                                   "note": "the bytes of the two kernels this one replaces (SURVEY 8(d)) over its time: "
+                                           "above the 8 TB/s peak means the fused kernel beats what the unfused pair "
+                                           "could reach; it is not an HBM utilisation"},
+                "note": "flops = the reference's back_pass arithmetic (%d per step and trajectory, back_pass.c:80-251 "
+                        "counted by backpass_flops()); the kernel also evaluates the derivatives of the step (generated "
+                        "callbacks, not counted) and the lanes of a wavefront wait for the slowest box QP.  One wavefront "
+                        "per SIMD (65 536 lanes): a chain of dependent fp64 instructions, see DESIGN.md" % backpass_flops(nx, nu, fd),
+            }
+            out["kernels_ms_per_iteration_alone"] = {k: v[1] / iters1 for k, v in t1.items() if v[0]}
+            # the HBM-bound kernels of the unfused path, each alone
+            t2 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, 5, fuse_derivs=0, ls_split=args.ls_split)
+            unfused = {}
+            for kname in ("k_derivs", "k_backward"):
+                n, ms = t2[kname]
+                if n:
+                    b_alg = alg[kname] * n_hor * B
+                    unfused[kname] = {"bound": "hbm", "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": b_alg,
+                                      "achieved_GBs": b_alg / (ms / n * 1e-3) / 1e9,
+                                      "frac_of_peak": b_alg / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, "stream_groups": 1}
+            out["unfused_kernels"] = unfused
+            out["dropin_b1"] = dropin_b1(ilqg, synth)
+            if not args.no_config5:
+                out["config5"] = config5(ilqg, synth, local, with_cpu=not args.no_cpu_baseline)
+        elif not car:
+            flops = backpass_flops(nx, nu, fd) * n_hor * B
+            out["roofline"] = {"bound": "hbm", "kernel": "iteration", "achieved": iter_bytes * (K / dt) / world / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": iter_bytes * (K / dt) / world / 1e9 / HBM_PEAK_GBS,
+                               "traffic": None, "backward_fp64_frac": flops * (K / dt) / world / 1e12 / FP64_PEAK_TFLOPS}
+        if "roofline" not in out:  # N > 1, or the secondary runs were switched off: the iteration-level figure
+            out["roofline"] = {"bound": "hbm", "kernel": "iteration", "achieved": out["iteration_roofline"]["achieved_GBs"],
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["iteration_roofline"]["frac_of_peak"],
+                               "traffic": None, "note": "per GPU; algorithmic bytes of SURVEY 8(d) per iteration x "
+                                                        "iterations/s.  The per-kernel figures are measured at N = 1."}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, K, problem, fd, params, N_HOR,
+            out["cpu_baseline"] = cpu_baseline(B, K, problem, fd, params, n_hor,
                                                synth.car_batch if car else synth.synth16_batch)
         print(json.dumps(out))
-    s.close()
     if world > 1:
         dist.destroy_process_group()
 

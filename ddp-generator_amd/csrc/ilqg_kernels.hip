@@ -1891,6 +1891,7 @@ struct ilqg_dev {
     bool timing;
     struct Span { int kernel; hipEvent_t a, b; };
     std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;  // events of drained spans, reused: none is created while a window is timed
     double t_ms[ILQG_K_COUNT];
     int t_n[ILQG_K_COUNT];
 };
@@ -2014,11 +2015,21 @@ struct Timed {
     int kernel;
     hipEvent_t a, b;
     hipStream_t st;
+    static hipEvent_t take(ilqg_dev *d) {
+        hipEvent_t e = nullptr;
+        if(!d->event_pool.empty()) {
+            e = d->event_pool.back();
+            d->event_pool.pop_back();
+        } else {
+            hipEventCreate(&e);
+        }
+        return e;
+    }
     Timed(ilqg_dev *d_, int k, hipStream_t stream = nullptr) : d(d_), kernel(k), a(nullptr), b(nullptr) {
         st = stream ? stream : d->stream;
         if(d->timing) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
+            a = take(d);
+            b = take(d);
             hipEventRecord(a, st);
         }
     }
@@ -2039,8 +2050,8 @@ int drain_spans(ilqg_dev *d) {
         hipEventElapsedTime(&ms, s.a, s.b);
         d->t_ms[s.kernel] += ms;
         d->t_n[s.kernel]++;
-        hipEventDestroy(s.a);
-        hipEventDestroy(s.b);
+        d->event_pool.push_back(s.a);
+        d->event_pool.push_back(s.b);
     }
     d->spans.clear();
     return 0;
@@ -2203,6 +2214,7 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
     }
+    for(hipEvent_t e : d->event_pool) hipEventDestroy(e);
     for(int f = 0; f < ILQG_F_COUNT; f++)
         if(d->P.f[f]) hipFree(d->P.f[f]);
     if(d->P.work) hipFree(d->P.work);
@@ -2724,7 +2736,14 @@ int ilqg_dev_section_cycles(unsigned long long *out) {
 }
 
 int ilqg_dev_timing(ilqg_dev_t *d, int enable) {
+    HIP_TRY(hipSetDevice(d->device));
     if(drain_spans(d)) return 1;
+    if(enable)
+        while(d->event_pool.size() < 1024) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            d->event_pool.push_back(e);
+        }
     d->timing = enable != 0;
     memset(d->t_ms, 0, sizeof(d->t_ms));
     memset(d->t_n, 0, sizeof(d->t_n));

@@ -11,7 +11,7 @@ for v in "$@"; do
 import json, sys
 try:
     d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-    print("%-10s %.3f it/s  %s" % (sys.argv[1], d["value"], " ".join("%s=%.1f" % (k.replace("k_rollout", "roll"), v) for k, v in d["kernels_ms_per_iteration"].items() if v > 0.05)))
+    print("%-10s %.3f it/s  %s" % (sys.argv[1], d["value"], " ".join("%s=%.1f" % (k.replace("k_rollout", "roll"), v) for k, v in d["kernels_ms_per_iteration_overlapping"].items() if v > 0.05)))
 except Exception as e:
     print(sys.argv[1], "no result:", e)
 PY
