@@ -202,6 +202,42 @@ def dropin_b1(ilqg, synth, iters=20):
                     "so one trajectory cannot use the GPU — compare cpu_baseline.single_core_ms_per_trajectory_iteration"}
 
 
+def single_process(args, ilqg, synth):
+    """N GPUs of the node driven by ONE process through ilqg_multi_* (the C counterpart of the torchrun path)"""
+    G, K, W = args.gpus, args.steps, args.warmup
+    per, n_hor = (args.batch or 65536), (args.n_hor or 500)
+    B = per * G
+    x0, u0 = synth.car_batch(B, n_hor)
+    m = ilqg.MultiSolver("carparking", 0, batch=B, n_hor=n_hor, devices=list(range(G)), params=ilqg.CAR_PARAMS,
+                         opts=dict(max_iter=max(K, W) + 1, ls_split=args.ls_split))
+    m.init(x0, u0)
+    if W > 0:
+        m.iterate(W)
+        m.sync()
+        m.init(x0, u0)
+    m.sync()
+    t0 = time.perf_counter()
+    m.iterate(K)
+    cost = m.costs()  # the single collective (ncclGather), synchronises
+    m.sync()
+    dt = time.perf_counter() - t0
+    active = m.active()
+    m.close()
+    iter_bytes = algorithmic_bytes(4, 2, 0)["iteration"] * n_hor * per
+    print(json.dumps({
+        "metric": "iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)", "value": K / dt, "unit": "iterations/s",
+        "n_gpus": G, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "CarParking batch=%d per GPU x %d GPU, 8-alpha line search, FULL_DDP=0, first %d iterations "
+                               "after the initial roll-out" % (per, G, K),
+                   "batch_per_gpu": per, "n_hor": n_hor,
+                   "parallelism": "ONE process, ilqg_multi_*: contiguous shards, one ncclGather of the costs"},
+        "roofline": {"bound": "hbm", "kernel": "iteration", "achieved": iter_bytes * (K / dt) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": iter_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "note": "per GPU; algorithmic bytes of SURVEY 8(d)"},
+        "trajectories_still_active": int(active), "cost_mean_after_window": float(cost.mean())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,6 +257,9 @@ def main():
     ap.add_argument("--ls-split", type=int, default=3)
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary runs (kernels alone, config 5, drop-in)")
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N > 1 without torch.distributed.run: ONE process drives the N GPUs through the C "
+                         "interface ilqg_multi_* (hipSetDevice per shard, ncclCommInitAll, one ncclGather of the costs)")
     ap.add_argument("--groups", type=int, default=0,
                     help="independent sets of trajectories advanced on separate HIP streams (0: library default)")
     args = ap.parse_args()
@@ -232,6 +271,8 @@ def main():
     from ddp_generator_amd import ilqg, synth
 
     rank, local, world = pkg.dist.env_world()
+    if args.single_process and world == 1 and args.gpus > 1:
+        return single_process(args, ilqg, synth)
     if world > 1:
         pkg.dist.init("nccl", rank, world, torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus

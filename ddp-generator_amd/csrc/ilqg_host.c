@@ -984,6 +984,163 @@ int iLQG(tOptSet *o) {
 }
 
 /* =========================================================================
+ * several GPUs of one node, one process                         SURVEY 8(e)
+ * =========================================================================
+ * The reference is single-threaded and has no counterpart.  Trajectories are independent: device g owns the
+ * contiguous block [first_g, first_g + count_g) of the batch (blocks of ceil(B / G)), advances it with the batch
+ * interface above and never talks to the others; the one exchange is a single RCCL gather of the per-trajectory
+ * costs (ilqg_multi_gather_costs).  All launches are asynchronous, so one host thread keeps every device busy:
+ * the devices are served one iteration at a time in turn. */
+struct ilqg_multi {
+    int n, B, N, per;
+    ilqg_batch_t *shard[ILQG_MULTI_MAX];
+    int device[ILQG_MULTI_MAX], first[ILQG_MULTI_MAX], count[ILQG_MULTI_MAX];
+    ilqg_comm_t *comm;
+    char err[512];
+};
+
+static char g_multi_err[512];
+const char *ilqg_multi_error(const ilqg_multi_t *m) { return m ? m->err : g_multi_err; }
+
+static int multi_fail(ilqg_multi_t *m, int g) {
+    snprintf(m->err, sizeof(m->err), "device %d: %s", m->device[g], ilqg_batch_error(m->shard[g]));
+    return 1;
+}
+
+void ilqg_multi_destroy(ilqg_multi_t *m) {
+    int g;
+    if(!m) return;
+    if(m->comm) ilqg_comm_destroy(m->comm);
+    for(g = 0; g < m->n; g++) ilqg_batch_destroy(m->shard[g]);
+    free(m);
+}
+
+ilqg_multi_t *ilqg_multi_create(int n_devices, const int *devices, int batch, int n_hor) {
+    ilqg_multi_t *m;
+    int g;
+    if(n_devices < 1 || n_devices > ILQG_MULTI_MAX || batch < n_devices) {
+        snprintf(g_multi_err, sizeof(g_multi_err), "ilqg_multi_create: 1..%d devices, at least one trajectory each", ILQG_MULTI_MAX);
+        return NULL;
+    }
+    m = (ilqg_multi_t *)calloc(1, sizeof(*m));
+    if(!m) return NULL;
+    m->B = batch;
+    m->N = n_hor;
+    m->per = (batch + n_devices - 1) / n_devices;
+    for(g = 0; g < n_devices && g * m->per < batch; g++) {
+        m->device[g] = devices ? devices[g] : g;
+        m->first[g] = g * m->per;
+        m->count[g] = (batch - m->first[g] < m->per) ? batch - m->first[g] : m->per;
+        m->shard[g] = ilqg_batch_create(m->device[g], m->count[g], n_hor);
+        if(!m->shard[g]) {
+            snprintf(g_multi_err, sizeof(g_multi_err), "device %d: %s", m->device[g], ilqg_batch_error(NULL));
+            ilqg_multi_destroy(m);
+            return NULL;
+        }
+        m->n = g + 1;
+    }
+    if(ilqg_comm_create(&m->comm, m->n, m->device, m->per)) {
+        snprintf(g_multi_err, sizeof(g_multi_err), "RCCL communicator: %s", ilqg_dev_error());
+        ilqg_multi_destroy(m);
+        return NULL;
+    }
+    return m;
+}
+
+int ilqg_multi_devices(const ilqg_multi_t *m) { return m->n; }
+ilqg_batch_t *ilqg_multi_shard(ilqg_multi_t *m, int g, int *first, int *count) {
+    if(g < 0 || g >= m->n) return NULL;
+    if(first) *first = m->first[g];
+    if(count) *count = m->count[g];
+    return m->shard[g];
+}
+
+#define EACH_SHARD(g) for(g = 0; g < m->n; g++)
+int ilqg_multi_set_option(ilqg_multi_t *m, const char *name, const double *value, int n) {
+    int g;
+    EACH_SHARD(g) if(ilqg_batch_set_option(m->shard[g], name, value, n)) return multi_fail(m, g);
+    return 0;
+}
+int ilqg_multi_set_param(ilqg_multi_t *m, const char *name, const double *value, int n) {
+    int g;
+    EACH_SHARD(g) if(ilqg_batch_set_param(m->shard[g], name, value, n)) return multi_fail(m, g);
+    return 0;
+}
+int ilqg_multi_set_x0(ilqg_multi_t *m, const double *x0) {
+    int g;
+    EACH_SHARD(g) if(ilqg_batch_set_x0(m->shard[g], x0 + (size_t)m->first[g] * N_X)) return multi_fail(m, g);
+    return 0;
+}
+int ilqg_multi_set_u(ilqg_multi_t *m, const double *u) {
+    int g;
+    EACH_SHARD(g) if(ilqg_batch_set_u(m->shard[g], u + (size_t)m->first[g] * m->N * N_U)) return multi_fail(m, g);
+    return 0;
+}
+int ilqg_multi_init(ilqg_multi_t *m) {
+    int g;
+    EACH_SHARD(g) if(ilqg_batch_init(m->shard[g])) return multi_fail(m, g);
+    return 0;
+}
+int ilqg_multi_iterate(ilqg_multi_t *m, int n) {
+    int it, g;
+    for(it = 0; it < n; it++) EACH_SHARD(g) if(ilqg_batch_iterate(m->shard[g], 1)) return multi_fail(m, g);
+    return 0;
+}
+int ilqg_multi_sync(ilqg_multi_t *m) {
+    int g;
+    EACH_SHARD(g) if(ilqg_batch_sync(m->shard[g])) return multi_fail(m, g);
+    return 0;
+}
+int ilqg_multi_active(ilqg_multi_t *m, int *n_active) {
+    int g, a;
+    *n_active = 0;
+    EACH_SHARD(g) {
+        if(ilqg_batch_active(m->shard[g], &a)) return multi_fail(m, g);
+        *n_active += a;
+    }
+    return 0;
+}
+int ilqg_multi_solve(ilqg_multi_t *m) {
+    int it, active = 1, max_iter = m->shard[0]->opt.max_iter;
+    for(it = 0; it < max_iter && active; it += 4) {
+        if(ilqg_multi_iterate(m, max_iter - it < 4 ? max_iter - it : 4)) return 1;
+        if(ilqg_multi_active(m, &active)) return 1;
+    }
+    return 0;
+}
+int ilqg_multi_get_x(ilqg_multi_t *m, double *x) {
+    int g;
+    EACH_SHARD(g) if(ilqg_batch_get_x(m->shard[g], x + (size_t)m->first[g] * (m->N + 1) * N_X)) return multi_fail(m, g);
+    return 0;
+}
+int ilqg_multi_get_u(ilqg_multi_t *m, double *u) {
+    int g;
+    EACH_SHARD(g) if(ilqg_batch_get_u(m->shard[g], u + (size_t)m->first[g] * m->N * N_U)) return multi_fail(m, g);
+    return 0;
+}
+int ilqg_multi_get_int(ilqg_multi_t *m, const char *name, int *out) {
+    int g;
+    EACH_SHARD(g) if(ilqg_batch_get_int(m->shard[g], name, out + (size_t)m->first[g] * (strcmp(name, "alpha_ok") ? 1 : ILQG_MAX_ALPHA))) return multi_fail(m, g);
+    return 0;
+}
+
+/* the path's single collective: every device copies the costs of its shard (all its groups of trajectories) into its
+ * send buffer, then ONE ncclGather moves them to device 0 and on to the host */
+int ilqg_multi_gather_costs(ilqg_multi_t *m, double *cost) {
+    ilqg_dev_t *devs[ILQG_MULTI_MAX];
+    int g;
+    EACH_SHARD(g) {
+        if(ilqg_batch_scalar_to_device(m->shard[g], "cost", ilqg_comm_send_buffer(m->comm, g))) return multi_fail(m, g);
+        devs[g] = m->shard[g]->dev[0];
+    }
+    if(ilqg_comm_gather(m->comm, devs, m->first, m->count, cost)) {
+        snprintf(m->err, sizeof(m->err), "gather of costs: %s", ilqg_dev_error());
+        return 1;
+    }
+    return 0;
+}
+
+/* =========================================================================
  * the reference's MEX entry without MEX                 iLQG_mex.c:19-144
  * =========================================================================
  * [success, x, u, cost] = iLQG<Problem>(x0, u_nom, params, opts) for a C caller: same sequence — options by

@@ -28,6 +28,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "mex.h"
 
 // NaN/Inf guards in generated code still `return 0`; their printing is dropped on the device
@@ -2860,4 +2862,100 @@ int ilqg_dev_boxqp_wave_batch(int device, int n, int count, const double *H, con
     return boxqp_batch(1, device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);
 }
 
+// ---------------------------------------------------------------------------
+// Several GPUs of one node in ONE process: the trajectory batch is sharded, every device advances its
+// shard by itself, and the only exchange is one RCCL gather of a per-trajectory scalar (the costs) to a root device.
+// ---------------------------------------------------------------------------
+struct ilqg_comm {
+    int n;
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+    std::vector<double *> send;   // per device: its shard of the scalar, padded to `per`
+    double *recv;                 // root device: n * per doubles
+    int per;
+};
+
+#define NCCL_TRY(expr)                                                              \
+    do {                                                                            \
+        ncclResult_t r_ = (expr);                                                   \
+        if(r_ != ncclSuccess) {                                                     \
+            g_err = std::string(#expr) + ": " + ncclGetErrorString(r_);             \
+            return 1;                                                               \
+        }                                                                           \
+    } while(0)
+
+void ilqg_comm_destroy(ilqg_comm_t *c) {
+    if(!c) return;
+    for(size_t g = 0; g < c->comms.size(); g++)
+        if(c->comms[g]) ncclCommDestroy(c->comms[g]);
+    for(size_t g = 0; g < c->send.size(); g++) {
+        hipSetDevice(c->devices[g]);
+        if(c->send[g]) hipFree(c->send[g]);
+    }
+    if(c->recv) {
+        hipSetDevice(c->devices[0]);
+        hipFree(c->recv);
+    }
+    delete c;
+}
+
+static int comm_fill(ilqg_comm *c, int n, const int *devices, int per) {
+    c->n = n;
+    c->per = per;
+    c->devices.assign(devices, devices + n);
+    c->comms.assign(n, nullptr);
+    c->send.assign(n, nullptr);
+    NCCL_TRY(ncclCommInitAll(c->comms.data(), n, devices));
+    for(int g = 0; g < n; g++) {
+        HIP_TRY(hipSetDevice(devices[g]));
+        HIP_TRY(hipMalloc((void **)&c->send[g], (size_t)per * sizeof(double)));
+        HIP_TRY(hipMemset(c->send[g], 0, (size_t)per * sizeof(double)));
+    }
+    HIP_TRY(hipSetDevice(devices[0]));
+    HIP_TRY(hipMalloc((void **)&c->recv, (size_t)n * per * sizeof(double)));
+    return 0;
+}
+
+// one communicator over `n` distinct devices; `per` = doubles every device contributes to a gather
+int ilqg_comm_create(ilqg_comm_t **out, int n, const int *devices, int per) {
+    *out = nullptr;
+    if(n < 1 || per < 1) {
+        g_err = "ilqg_comm_create: need at least one device and one value per device";
+        return 1;
+    }
+    ilqg_comm *c = new ilqg_comm();
+    if(comm_fill(c, n, devices, per)) {
+        const std::string why = g_err;
+        ilqg_comm_destroy(c);
+        g_err = why;
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+void *ilqg_comm_send_buffer(ilqg_comm_t *c, int g) { return (g >= 0 && g < c->n) ? c->send[g] : nullptr; }
+
+// The single collective of the path: the send buffers (filled by the caller, `per` doubles per device, all copies
+// complete) -> device 0 by ONE ncclGather, enqueued on the stream of each device's context devs[g], and on to the
+// host: host[first[g] .. first[g] + counts[g]) = what device g sent.
+int ilqg_comm_gather(ilqg_comm_t *c, ilqg_dev_t *const *devs, const int *first, const int *counts, double *host) {
+    for(int g = 0; g < c->n; g++)
+        if(counts[g] > c->per) {
+            g_err = "ilqg_comm_gather: a shard is larger than the communicator's send buffers";
+            return 1;
+        }
+    NCCL_TRY(ncclGroupStart());
+    for(int g = 0; g < c->n; g++)
+        NCCL_TRY(ncclGather(c->send[g], c->recv, (size_t)c->per, ncclDouble, 0, c->comms[g], devs[g]->stream));
+    NCCL_TRY(ncclGroupEnd());
+    HIP_TRY(hipSetDevice(c->devices[0]));
+    std::vector<double> tmp((size_t)c->n * c->per);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), c->recv, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, devs[0]->stream));
+    HIP_TRY(hipStreamSynchronize(devs[0]->stream));
+    for(int g = 0; g < c->n; g++) memcpy(host + first[g], tmp.data() + (size_t)g * c->per, sizeof(double) * counts[g]);
+    return 0;
+}
+
 }  // extern "C"
+

@@ -179,6 +179,15 @@ int ilqg_dev_boxqp_wave_batch(int device, int n, int count, const double *H, con
 int ilqg_dev_dense(int device, int op, int shape, const double *in0, int n_in0, const double *in1, int n_in1,
                    const double *in2, int n_in2, double *out, int n_out, int *flag);
 
+/* Several GPUs in one process: an RCCL communicator over n distinct devices (ncclCommInitAll) and the path's single
+ * collective: the caller fills device g's send buffer (per doubles, e.g. with ilqg_dev_copy_scalar_to) and waits for
+ * the copies; ilqg_comm_gather then moves all of them to device 0 by one ncclGather and on to the host. */
+typedef struct ilqg_comm ilqg_comm_t;
+int ilqg_comm_create(ilqg_comm_t **out, int n, const int *devices, int per);
+void ilqg_comm_destroy(ilqg_comm_t *c);
+void *ilqg_comm_send_buffer(ilqg_comm_t *c, int g);  /* device g's `per` doubles, on device g */
+int ilqg_comm_gather(ilqg_comm_t *c, ilqg_dev_t *const *devs, const int *first, const int *counts, double *host);
+
 /* unit-test entry for the device sincos that the generated callbacks' sin()/cos() are routed through */
 int ilqg_dev_sincos_batch(int device, int n, const double *x, double *s, double *c);
 

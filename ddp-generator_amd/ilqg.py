@@ -116,6 +116,21 @@ def load_library(problem="carparking", full_ddp=0, strict=False):
     lib.ilqg_boxqp_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _ip]
     lib.ilqg_boxqp_wave_batch.argtypes = lib.ilqg_boxqp_batch.argtypes
     lib.ilqg_sincos_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+    lib.ilqg_multi_create.restype = v
+    lib.ilqg_multi_create.argtypes = [C.c_int, _ip, C.c_int, C.c_int]
+    lib.ilqg_multi_destroy.argtypes = [v]
+    lib.ilqg_multi_error.restype = C.c_char_p
+    lib.ilqg_multi_error.argtypes = [v]
+    lib.ilqg_multi_devices.argtypes = [v]
+    lib.ilqg_multi_set_option.argtypes = [v, C.c_char_p, _dp, C.c_int]
+    lib.ilqg_multi_set_param.argtypes = [v, C.c_char_p, _dp, C.c_int]
+    for f in ("set_x0", "set_u", "get_x", "get_u", "gather_costs"):
+        getattr(lib, "ilqg_multi_" + f).argtypes = [v, _dp]
+    for f in ("init", "solve", "sync"):
+        getattr(lib, "ilqg_multi_" + f).argtypes = [v]
+    lib.ilqg_multi_iterate.argtypes = [v, C.c_int]
+    lib.ilqg_multi_active.argtypes = [v, _ip]
+    lib.ilqg_multi_get_int.argtypes = [v, C.c_char_p, _ip]
     lib.ilqg_solve_single.argtypes = [C.c_int, _dp, _dp, C.POINTER(_Named), C.c_int, C.POINTER(_Named), C.c_int, _dp, _dp,
                                       _dp, _ip, _dp, C.c_char_p, C.c_int]
     _libs[path] = lib
@@ -333,6 +348,86 @@ class BatchSolver:
             self._ck(self.lib.ilqg_batch_get_timing(self.h, k, n, ms))
             out[self.lib.ilqg_batch_kernel_name(k).decode()] = (int(n[0]), float(ms[0]))
         return out
+
+
+class MultiSolver:
+    """B trajectories sharded over several GPUs of one node in ONE process (ilqg_multi_*): contiguous blocks of
+    ceil(B / G) trajectories per device, no exchange except costs() = one RCCL gather to the first device."""
+
+    def __init__(self, problem="carparking", full_ddp=0, batch=2, n_hor=500, devices=(0,), params=None, opts=None):
+        self.problem = Problem(problem, full_ddp)
+        self.lib = self.problem.lib
+        self.B, self.N = int(batch), int(n_hor)
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        self.h = self.lib.ilqg_multi_create(devs.size, devs, self.B, self.N)
+        if not self.h:
+            raise IlqgError(self.lib.ilqg_multi_error(None).decode())
+        for k, val in (params or {}).items():
+            a = np.ascontiguousarray(np.atleast_1d(val), dtype=np.float64)
+            self._ck(self.lib.ilqg_multi_set_param(self.h, k.encode(), a, a.size))
+        for k, val in (opts or {}).items():
+            a = np.ascontiguousarray(np.atleast_1d(val), dtype=np.float64)
+            self._ck(self.lib.ilqg_multi_set_option(self.h, k.encode(), a, a.size))
+
+    def _ck(self, rc):
+        if rc:
+            raise IlqgError(self.lib.ilqg_multi_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ilqg_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def devices(self):
+        return int(self.lib.ilqg_multi_devices(self.h))
+
+    def init(self, x0, u0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(self.B, self.problem.nx)
+        u0 = np.ascontiguousarray(u0, dtype=np.float64).reshape(self.B, self.N, self.problem.nu)
+        self._ck(self.lib.ilqg_multi_set_x0(self.h, x0))
+        self._ck(self.lib.ilqg_multi_set_u(self.h, u0))
+        self._ck(self.lib.ilqg_multi_init(self.h))
+
+    def iterate(self, n=1):
+        self._ck(self.lib.ilqg_multi_iterate(self.h, int(n)))
+
+    def solve(self):
+        self._ck(self.lib.ilqg_multi_solve(self.h))
+
+    def sync(self):
+        self._ck(self.lib.ilqg_multi_sync(self.h))
+
+    def active(self):
+        n = np.zeros(1, dtype=np.int32)
+        self._ck(self.lib.ilqg_multi_active(self.h, n))
+        return int(n[0])
+
+    def costs(self):
+        """the single collective: per-trajectory costs of all devices, gathered over RCCL"""
+        out = np.zeros(self.B)
+        self._ck(self.lib.ilqg_multi_gather_costs(self.h, out))
+        return out
+
+    def x(self):
+        out = np.zeros((self.B, self.N + 1, self.problem.nx))
+        self._ck(self.lib.ilqg_multi_get_x(self.h, out))
+        return out
+
+    def u(self):
+        out = np.zeros((self.B, self.N, self.problem.nu))
+        self._ck(self.lib.ilqg_multi_get_u(self.h, out))
+        return out
+
+    def ints(self, name):
+        out = np.zeros((self.B, MAX_ALPHA if name == "alpha_ok" else 1), dtype=np.int32)
+        self._ck(self.lib.ilqg_multi_get_int(self.h, name.encode(), out))
+        return out if name == "alpha_ok" else out[:, 0]
 
 
 def solve_single(x0, u_nom, params, opts=None, problem="carparking", full_ddp=0, strict=False):

@@ -128,6 +128,33 @@ int ilqg_batch_scalar_to_device(ilqg_batch_t *c, const char *name, void *dst_dev
 void *ilqg_batch_cost_device_ptr(ilqg_batch_t *c);
 void *ilqg_batch_stream(ilqg_batch_t *c);
 
+/* ---- several GPUs of one node, ONE process (no reference counterpart) -----------------------------
+ * The batch is sharded in contiguous blocks of ceil(batch / n_devices) trajectories; device g advances its block with
+ * the interface above and shares nothing with the others.  The single exchange is ilqg_multi_gather_costs: one
+ * ncclGather (RCCL, xGMI) of the per-trajectory costs to the first device, delivered to the host.  devices = NULL:
+ * devices 0..n_devices-1.  Host arrays are those of the batch interface for the WHOLE batch. */
+#define ILQG_MULTI_MAX 16
+typedef struct ilqg_multi ilqg_multi_t;
+ilqg_multi_t *ilqg_multi_create(int n_devices, const int *devices, int batch, int n_hor); /* NULL: ilqg_multi_error(NULL) */
+void ilqg_multi_destroy(ilqg_multi_t *m);
+const char *ilqg_multi_error(const ilqg_multi_t *m);
+int ilqg_multi_devices(const ilqg_multi_t *m);
+/* the batch object of device g and its block of the batch (for everything not forwarded below) */
+ilqg_batch_t *ilqg_multi_shard(ilqg_multi_t *m, int g, int *first, int *count);
+int ilqg_multi_set_option(ilqg_multi_t *m, const char *name, const double *value, int n);
+int ilqg_multi_set_param(ilqg_multi_t *m, const char *name, const double *value, int n);
+int ilqg_multi_set_x0(ilqg_multi_t *m, const double *x0);
+int ilqg_multi_set_u(ilqg_multi_t *m, const double *u);
+int ilqg_multi_init(ilqg_multi_t *m);
+int ilqg_multi_iterate(ilqg_multi_t *m, int n);   /* asynchronous on every device; the devices are served in turn */
+int ilqg_multi_solve(ilqg_multi_t *m);
+int ilqg_multi_sync(ilqg_multi_t *m);
+int ilqg_multi_active(ilqg_multi_t *m, int *n_active);
+int ilqg_multi_get_x(ilqg_multi_t *m, double *x);
+int ilqg_multi_get_u(ilqg_multi_t *m, double *u);
+int ilqg_multi_get_int(ilqg_multi_t *m, const char *name, int *out);
+int ilqg_multi_gather_costs(ilqg_multi_t *m, double *cost /* [batch] */);
+
 /* The reference's MEX entry for a C caller (iLQG_mex.c:19-144):
  *     [success, x, u, cost] = iLQG<Problem>(x0, u_nom, params, opts)
  * One trajectory through the drop-in iLQG() (outer loop on the host, back_pass() / line_search() on the GPU).

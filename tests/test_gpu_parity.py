@@ -482,6 +482,30 @@ def test_dropin_ilqg_symbols(ilqg, oracle_built):
         dd.close()
 
 
+def test_multi_gpu_single_process(ilqg, synth):
+    """ilqg_multi_*: the batch sharded over the GPUs of the node in one process, costs by ONE RCCL gather — equal to the
+    single-GPU batch bit for bit (trajectories are independent).  Uses two devices where the box has them; with one
+    device the same code runs as a communicator of one rank (ncclCommInitAll, ncclGather and the host hand-over)."""
+    ndev = min(2, ilqg.Problem("carparking", 0).device_count())
+    B, iters = 150, 4
+    x0, u0 = synth.car_batch(B, first=300)
+    one = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=iters))
+    one.init(x0, u0)
+    one.iterate(iters)
+    m = ilqg.MultiSolver("carparking", 0, batch=B, n_hor=500, devices=list(range(ndev)), params=ilqg.CAR_PARAMS,
+                         opts=dict(max_iter=iters))
+    assert m.devices() == ndev
+    m.init(x0, u0)
+    m.iterate(iters)
+    assert np.array_equal(m.costs(), one.scalar("cost"))
+    assert np.array_equal(m.x(), one.x()) and np.array_equal(m.ints("alpha_idx"), one.ints("alpha_idx"))
+    assert m.active() == one.active()
+    m.close()
+    one.close()
+    with pytest.raises(ilqg.IlqgError):
+        ilqg.MultiSolver("carparking", 0, batch=4, n_hor=10, devices=[0, 0])  # RCCL refuses a device twice
+
+
 def test_mex_entry_without_mex(ilqg, oracle_built):
     """ilqg_solve_single = the call sequence of the reference's MEX entry (iLQG_mex.c:55-137) on the product's drop-in
     iLQG(): same solve as the oracle's, the MEX entry's messages for refused arguments"""
