@@ -91,7 +91,13 @@ def almix_case(batch=None, seed=3):
 
 
 def lib_path(kind, problem="carparking", full_ddp=0):
-    """kind: 'ref' (reference sources) or 'oracle' (CPU restatement)"""
+    """kind: 'ref' (reference sources), 'oracle' (CPU restatement), 'ref_fma' (reference sources built with FMA
+    contraction, CarParking FULL_DDP=0 only), 'pure' (the reference's cholesky.c / matMult.c / printMat.c alone: no MEX
+    stand-in, no generated file)"""
+    if kind == "pure":
+        return os.path.join(HERE, "_ref", "libref_pure.so")
+    if kind == "ref_fma":
+        return os.path.join(HERE, "_ref", "libref_%s_fd%d_fma.so" % (problem, full_ddp))
     if kind == "ref":
         return os.path.join(HERE, "_ref", "libref_%s_fd%d.so" % (problem, full_ddp))
     if kind == "oracle":
@@ -282,7 +288,8 @@ class Kernels:
         self.lib = lib
         lib.cholesky_tri.argtypes = [_dp, C.c_int, _dp]
         lib.cholesky_tri_inv.argtypes = [_dp, _dp, C.c_int, _dp]
-        lib.boxQP.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, C.c_int]
+        if hasattr(lib, "boxQP"):  # (the 'pure' reference build has the dense helpers only)
+            lib.boxQP.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, C.c_int]
         lib.addMulVec.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int]
         lib.addSquareTri.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, _dp]
         lib.addMul2Tri.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp]

@@ -56,7 +56,9 @@ class quiet:
 
 
 # --------------------------------------------------------------------------
-def kernel_goldens(K):
+def kernel_goldens(K, Kpure):
+    """K: the reference's solver sources (stub mex.h + generated problem file: needed for boxQP.c);
+    Kpure: cholesky.c / matMult.c alone, compiled without any stand-in — the Cholesky and matMult vectors are its"""
     rng = np.random.default_rng(20261003)
     out = {}
 
@@ -67,8 +69,8 @@ def kernel_goldens(K):
             A = rng.standard_normal((n, n))
             M = A @ A.T + 0.1 * np.eye(n) if trial % 2 == 0 else (A + A.T) / 2
             P = pack_sym(M)
-            ok, U = K.cholesky(P, n)
-            inv = K.cholesky_inv(U, n) if ok else np.zeros_like(P)
+            ok, U = Kpure.cholesky(P, n)
+            inv = Kpure.cholesky_inv(U, n) if ok else np.zeros_like(P)
             pad = lambda v: np.pad(v, (0, 36 - len(v)))
             ch_n.append(n); ch_A.append(pad(P)); ch_ok.append(ok); ch_U.append(pad(U) if ok else pad(np.zeros_like(P))); ch_inv.append(pad(inv))
     out.update(chol_n=np.array(ch_n), chol_A=np.array(ch_A), chol_ok=np.array(ch_ok), chol_U=np.array(ch_U), chol_inv=np.array(ch_inv))
@@ -105,7 +107,30 @@ def kernel_goldens(K):
         if rc in want and have[rc] < want[rc]:
             have[rc] += 1
             cases.append((n, H, g, lo, hi, x0, r))
-    print("boxQP return codes captured:", have, "(rc 1 = 100 iterations was never reached in %d random problems)" % trial)
+    print("boxQP return codes captured:", have, "in %d random problems" % trial)
+    # rc 1 (100 iterations, boxQP.c:237) needs a Hessian that passes the Cholesky test but is numerically singular, so
+    # that the computed inverse gives poor search directions and the iteration crawls: almost rank-one matrices
+    rng1 = np.random.default_rng(20261004)
+    got1 = 0
+    for t in range(200000):
+        if got1 >= 3:
+            break
+        n = 8
+        v = rng1.standard_normal(n)
+        M = np.outer(v, v) * (1 + 10.0 ** rng1.uniform(-16, -8) * rng1.standard_normal((n, n)))
+        M = (M + M.T) / 2 + 10.0 ** rng1.uniform(-17, -12) * np.eye(n)
+        g = rng1.standard_normal(n) * 10.0 ** rng1.uniform(-6, 6)
+        lo = -np.abs(rng1.standard_normal(n)) * 10.0 ** rng1.uniform(-3, 6)
+        hi = np.abs(rng1.standard_normal(n)) * 10.0 ** rng1.uniform(-3, 6)
+        x0 = rng1.uniform(lo, hi)
+        H = pack_sym(M)
+        with quiet():
+            r = K.boxqp(H, g, lo, hi, x0)
+        if r["rc"] == 1:
+            got1 += 1
+            cases.append((n, H, g, lo, hi, x0, r))
+    print("boxQP rc 1 (100 iterations) cases:", got1)
+    assert got1 == 3
     p8 = lambda v: np.pad(np.asarray(v, dtype=np.float64), (0, 8 - len(v)))
     p36 = lambda v: np.pad(np.asarray(v, dtype=np.float64), (0, 36 - len(v)))
     out.update(
@@ -133,10 +158,10 @@ def kernel_goldens(K):
         mm[tag + "_base_uu"] = rng.standard_normal(m * (m + 1) // 2)
         mm[tag + "_base_xx"] = rng.standard_normal(n * (n + 1) // 2)
         mm[tag + "_base_xu"] = rng.standard_normal(n * m)
-        mm[tag + "_mulvec"] = K.add_mul_vec(mm[tag + "_base_u"], vx, fu, n, m)
-        mm[tag + "_sq_uu"] = K.add_square_tri(mm[tag + "_base_uu"], V, fu, n, m)
-        mm[tag + "_sq_xx"] = K.add_square_tri(mm[tag + "_base_xx"], V, fx, n, n)
-        mm[tag + "_mul2"] = K.add_mul2_tri(mm[tag + "_base_xu"], V, fx, n, n, fu, n, m)
+        mm[tag + "_mulvec"] = Kpure.add_mul_vec(mm[tag + "_base_u"], vx, fu, n, m)
+        mm[tag + "_sq_uu"] = Kpure.add_square_tri(mm[tag + "_base_uu"], V, fu, n, m)
+        mm[tag + "_sq_xx"] = Kpure.add_square_tri(mm[tag + "_base_xx"], V, fx, n, n)
+        mm[tag + "_mul2"] = Kpure.add_mul2_tri(mm[tag + "_base_xu"], V, fx, n, n, fu, n, m)
     out.update({"mm_" + k: v for k, v in mm.items()})
     np.savez_compressed(os.path.join(HERE, "kernels.npz"), **out)
 
@@ -231,6 +256,21 @@ def solve_goldens(fd, n_traj=16, max_iter=600):
             arr[b, :len(t[name])] = t[name]
         res["tr_" + name] = arr
     res["tr_len"] = np.array([len(t["cost"]) for t in traces])
+    if fd == 0:
+        # the same starts solved by the reference built with FMA contraction (-O3 -march=native): how far two CPU
+        # builds of the reference drift apart over a full solve is the yardstick for the GPU's own drift
+        fx, fc, fi = [], [], []
+        for b in range(n_traj):
+            d = Driver(lib_path("ref_fma", full_ddp=0), 500, CAR_PARAMS, dict(max_iter=max_iter))
+            assert d.init(x0s[b], u0s[b]) == 1
+            d.solve()
+            fx.append(d.traj(0)[0]); fc.append(d.scalars()["cost"]); fi.append(int(d.scalars()["iterations"]))
+            d.close()
+        res["fma_x"] = np.array(fx); res["fma_cost"] = np.array(fc); res["fma_iterations"] = np.array(fi)
+        rel = np.abs(res["fma_cost"] / res["cost"] - 1)
+        print("fd0: reference with FMA vs without: iterations %s, cost rel. deviation max %.3g median %.3g, "
+              "state deviation max %.3g" % (res["fma_iterations"].tolist(), rel.max(), np.median(rel),
+                                            np.abs(res["fma_x"] - res["x"]).max()))
     np.savez_compressed(os.path.join(HERE, "car_solves_fd%d.npz" % fd), **res)
     print("fd%d solves: rc %s iterations %s" % (fd, res["rc"].tolist(), res["iterations"].tolist()))
 
@@ -416,7 +456,7 @@ def main(argv):
     groups = {
         "brachi": brachi_goldens,
         "almix": almix_goldens,
-        "kernels": lambda: kernel_goldens(Kernels(lib_path("ref", full_ddp=0))),
+        "kernels": lambda: kernel_goldens(Kernels(lib_path("ref", full_ddp=0)), Kernels(lib_path("pure"))),
         "car": lambda: [(single_pass_goldens(fd), solve_goldens(fd)) for fd in (0, 1)],
         "lockstep": lambda: lockstep_goldens(0),
         "hx": lambda: [hx_goldens(fd) for fd in (0, 1)],

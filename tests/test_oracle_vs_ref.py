@@ -45,3 +45,31 @@ def test_random_boxqp_match_reference(oracle_built):
         a, o = Kr.boxqp(H, g, lo, hi, x0), Ko.boxqp(H, g, lo, hi, x0)
         assert a["rc"] == o["rc"] and a["n_free"] == o["n_free"]
         assert np.array_equal(a["x"], o["x"]) and np.array_equal(a["clamp"], o["clamp"])
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(lib_path("pure")), reason="oracle/_ref/libref_pure.so not built")
+def test_dense_helpers_match_the_reference_built_without_any_stand_in(oracle_built):
+    """cholesky.c, matMult.c and printMat.c are the reference files that include neither mex.h nor a generated header:
+    _ref/libref_pure.so is those three compiled with nothing but -I/root/reference -DPRNT=printf.  The restatement's
+    cholesky_tri / cholesky_tri_inv / addMulVec / addSquareTri / addMul2Tri equal it exactly on fresh inputs."""
+    Kp, Ko = Kernels(lib_path("pure")), Kernels(lib_path("oracle"))
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        n = int(rng.integers(1, 17))
+        A = rng.standard_normal((n, n))
+        M = A @ A.T + 10.0 ** rng.uniform(-8, 0) * np.eye(n) if trial % 3 else (A + A.T) / 2
+        P = np.array([M[r, c] for c in range(n) for r in range(c + 1)])
+        okp, Up = Kp.cholesky(P, n)
+        oko, Uo = Ko.cholesky(P, n)
+        assert okp == oko
+        if okp:
+            assert np.array_equal(Up, Uo) and np.array_equal(Kp.cholesky_inv(Up, n), Ko.cholesky_inv(Uo, n))
+        m = int(rng.integers(1, n + 1))
+        V = np.array([(A @ A.T)[r, c] for c in range(n) for r in range(c + 1)])
+        fx, fu, vx = rng.standard_normal(n * n), rng.standard_normal(n * m), rng.standard_normal(n)
+        assert np.array_equal(Kp.add_mul_vec(rng.standard_normal(m) * 0 + 1.5, vx, fu, n, m), Ko.add_mul_vec(np.full(m, 1.5), vx, fu, n, m))
+        b_uu, b_xx, b_xu = rng.standard_normal(m * (m + 1) // 2), rng.standard_normal(n * (n + 1) // 2), rng.standard_normal(n * m)
+        assert np.array_equal(Kp.add_square_tri(b_uu, V, fu, n, m), Ko.add_square_tri(b_uu, V, fu, n, m))
+        assert np.array_equal(Kp.add_square_tri(b_xx, V, fx, n, n), Ko.add_square_tri(b_xx, V, fx, n, n))
+        assert np.array_equal(Kp.add_mul2_tri(b_xu, V, fx, n, n, fu, n, m), Ko.add_mul2_tri(b_xu, V, fx, n, n, fu, n, m))
+
