@@ -45,16 +45,24 @@ def main():
 
     if traffic_json:
         import json
-        # per bench label: mean over ALL launches of that kernel (the batch runs as several groups of
-        # trajectories, so grids differ slightly).  The general roll-out kernel is launched for the first search
-        # stage (largest grids), the second stage and the winner pass: only the first is labelled.
-        grids = [int(g) for (k, g) in acc if k == "void k_rollout<0>" and g]
-        search_min = 0.9 * max(grids) if grids else 0
+        # per bench label: mean over ALL launches of that kernel (the batch runs as several groups of trajectories, so
+        # grids differ slightly).  The general roll-out kernel is launched three ways, told apart by their grids: the
+        # winner pass has one lane per trajectory of the group (grid = Bp), the first search stage ls_split (3) lanes
+        # per trajectory (grid = 3 Bp), the second stage n_alpha - ls_split (5) lanes for the WORST case (grid = 5 Bp,
+        # most of its blocks return at once).
+        ls_split, n_alpha = 3, 8
+        grids = sorted({int(g) for (k, g) in acc if k == "void k_rollout<0>" and g})
+        bases = [b for b in grids if b * ls_split in grids and b * (n_alpha - ls_split) in grids]
+        roll_label = {}
+        for b in bases:
+            roll_label[b] = "k_rollout[winner]"
+            roll_label[b * ls_split] = "k_rollout[search]"
+            roll_label[b * (n_alpha - ls_split)] = "k_rollout[search stage 2]"
         per_label = collections.defaultdict(lambda: collections.defaultdict(list))
         for (k, g), cs in acc.items():
             label = KERNEL_LABELS.get(k)
-            if k == "void k_rollout<0>" and g and int(g) >= search_min:
-                label = "k_rollout[search]"
+            if k == "void k_rollout<0>" and g:
+                label = roll_label.get(int(g))
             if not label:
                 continue
             for cname in ("FETCH_SIZE", "WRITE_SIZE"):
