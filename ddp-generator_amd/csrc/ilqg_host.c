@@ -256,11 +256,17 @@ ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int gro
     c->fuse_derivs = c->resweep ? 0 : 1;
     c->ls_split = 3;
     standard_parameters(&c->opt);
+    ilqg_dev_dims(dims);
     if(groups <= 0) {
+        /* lane mapping: 3 (see above).  Wave mapping: 1 — two groups whose backward passes take turns (they share the
+         * device's derivative work buffer) so that the roll-outs of one run beside the backward pass of the other were
+         * measured SLOWER on the n = 16 problem (1.98 -> 1.53 it/s): a workgroup of the backward kernel takes all the
+         * registers of its CU (8 wavefronts x 250) and the whole LDS, so roll-out wavefronts (256 registers) find no
+         * room beside it, while each group's roll-outs keep the full chain latency of n_hor steps. */
         const char *e = getenv("ILQG_GROUPS");
-        ilqg_dev_dims(dims);
         groups = e ? atoi(e) : ((batch >= 8192 && !dims[7]) ? 3 : 1);
     }
+
     if(groups < 1) groups = 1;
     if(groups > ILQG_MAX_GROUPS) groups = ILQG_MAX_GROUPS;
     /* whole tiles of 64 trajectories per group */

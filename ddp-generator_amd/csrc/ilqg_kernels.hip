@@ -1864,6 +1864,28 @@ __global__ __launch_bounds__(64) void k_boxqp_rows_test(int count, const double 
 // ===========================================================================
 // shim
 // ===========================================================================
+#if ILQG_WAVE_MAP
+// Wave mapping: the derivative records of a chunk of trajectories (trajEl_t structs, 48 KB each with the tensors of the
+// n = 16 problem) live in ONE work buffer per device, shared by all solver contexts on it.  A context owns the buffer
+// from the start of a derivatives + backward pass to its end; the hand-over is an event on the streams, so a second
+// context's pass starts when the first one's has finished — which is also the schedule that pays: the backward pass
+// fills the chip, the roll-outs (one lane per trajectory and step size) cannot, so with the batch advancing as two
+// groups of trajectories the roll-outs of one run beside the backward pass of the other.
+struct SharedWork {
+    trajEl_t *buf;
+    size_t bytes;
+    hipEvent_t free_ev;  // recorded when the current owner is done with the buffer
+    int refs;
+    // which constant record entries (init_running) the buffer holds: for whom, and where
+    bool whole, half[2], factored, pv_set;
+    int N, part;
+    ParamValues pv;
+};
+static SharedWork g_work[64];
+#else
+struct SharedWork;
+#endif
+
 struct ilqg_dev {
     int device, B, Bp, N;
     hipStream_t stream;
@@ -1890,6 +1912,16 @@ struct ilqg_dev {
     bool half_consts[2];  // wave mapping: the same per half of the work buffer (chunks alternate between the halves)
     hipStream_t stream2;  // wave mapping: second stream of the chunk pipeline, fork / join events
     hipEvent_t fork, join;
+    // Wave mapping: the roll-outs run through the generated callbacks with a trajEl_t per lane in scratch memory
+    // (48 KB per lane for the n = 16 problem with its tensors) and the runtime reserves scratch per queue for every
+    // wavefront the chip can hold — one queue works, a second one runs out of resources.  All roll-outs of all
+    // contexts (groups) of a device therefore share ONE stream, tied to each context's own stream by events; the
+    // backward passes of the other groups overlap with them.
+    hipStream_t roll;
+    hipEvent_t roll_in, roll_out;
+    struct SharedWork *shared;  // wave mapping: the device's derivative work buffer (see SharedWork)
+    int own_chunk;              // trajectories whose records fit the context's private buffer P.work (stage-by-stage calls)
+    bool per_step_params;       // some problem parameter has one value per time step
     bool timing;
     struct Span { int kernel; hipEvent_t a, b; };
     std::vector<Span> spans;
@@ -2047,6 +2079,7 @@ int drain_spans(ilqg_dev *d) {
     if(d->spans.empty()) return 0;
     HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream2));
+    if(d->roll) HIP_TRY(hipStreamSynchronize(d->roll));
     for(auto &s : d->spans) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, s.a, s.b);
@@ -2098,7 +2131,6 @@ const char *ilqg_dev_kernel_name(int k) {
 }
 
 static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor);
-
 int ilqg_dev_create(ilqg_dev_t **out, int device, int batch, int n_hor) {
     *out = nullptr;
     if(batch < 1 || n_hor < 2) {
@@ -2152,27 +2184,54 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
     }
 #endif
     d->chunk = 0;
+    d->own_chunk = 0;
+    d->shared = nullptr;
+    d->per_step_params = false;
     d->work_consts = false;
     d->work_factored = false;
     d->half_consts[0] = d->half_consts[1] = false;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&d->fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d->join, hipEventDisableTiming));
+    if(WAVE_MAP) {
+        static std::vector<hipStream_t> shared_roll(64, nullptr);  // one per device, for the life of the process
+        if(!shared_roll[device]) HIP_TRY(hipStreamCreateWithFlags(&shared_roll[device], hipStreamNonBlocking));
+        d->roll = shared_roll[device];
+        HIP_TRY(hipEventCreateWithFlags(&d->roll_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&d->roll_out, hipEventDisableTiming));
+    }
     for(int f = 0; f < ILQG_F_COUNT; f++) {
         if(WAVE_MAP && f == ILQG_F_DER) {
-            // derivative records = device trajEl_t structs for as many trajectories as fit the budget
-            // budget: ILQG_WORK_GB if set, else half of the free device memory
-            const char *e = getenv("ILQG_WORK_GB");
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const double budget = e ? atof(e) * 1e9 : 0.5 * (double)free_b;
+#if ILQG_WAVE_MAP
+            // derivative records = device trajEl_t structs for as many trajectories as fit the device's work buffer
+            // (allocated by the first context: ILQG_WORK_GB if set, else half of the free device memory, at most what
+            // this context needs); a private buffer for stage-by-stage calls is allocated when one is made
+            SharedWork &W = g_work[device];
             const size_t per_traj = (size_t)d->N * sizeof(trajEl_t);
-            size_t c = (size_t)(budget / (double)per_traj);
-            if(c < 1) c = 1;
-            if(c > (size_t)d->B) c = d->B;
-            d->chunk = (int)c;
-            HIP_TRY(hipMalloc((void **)&d->P.work, c * per_traj));
-            HIP_TRY(hipMemsetAsync(d->P.work, 0, c * per_traj, d->stream));
+            if(!W.buf) {
+                const char *e = getenv("ILQG_WORK_GB");
+                size_t free_b = 0, total_b = 0;
+                HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                const double budget = e ? atof(e) * 1e9 : 0.5 * (double)free_b;
+                size_t c = (size_t)(budget / (double)per_traj);
+                if(c < 1) c = 1;
+                if(c > (size_t)d->B) c = d->B;
+                memset(&W, 0, sizeof(W));
+                HIP_TRY(hipMalloc((void **)&W.buf, c * per_traj));
+                W.bytes = c * per_traj;
+                HIP_TRY(hipMemsetAsync(W.buf, 0, W.bytes, d->stream));
+                HIP_TRY(hipStreamSynchronize(d->stream));
+                HIP_TRY(hipEventCreateWithFlags(&W.free_ev, hipEventDisableTiming));
+            }
+            W.refs++;
+            d->shared = &W;
+            size_t c = W.bytes / per_traj;
+            if(c < 1) {
+                g_err = "ilqg_dev_create: the device's derivative work buffer (made for a shorter horizon) does not hold one trajectory";
+                return 1;
+            }
+            d->chunk = (int)(c > (size_t)d->B ? (size_t)d->B : c);
+#endif
             d->P.f[f] = nullptr;
             continue;
         }
@@ -2220,6 +2279,13 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     for(int f = 0; f < ILQG_F_COUNT; f++)
         if(d->P.f[f]) hipFree(d->P.f[f]);
     if(d->P.work) hipFree(d->P.work);
+#if ILQG_WAVE_MAP
+    if(d->shared && --d->shared->refs == 0) {  // the last context on the device: release the shared work buffer
+        hipFree(d->shared->buf);
+        hipEventDestroy(d->shared->free_ev);
+        memset(d->shared, 0, sizeof(SharedWork));
+    }
+#endif
     if(d->P.nom) hipFree(d->P.nom);
     for(int f = 0; f < ILQG_I_COUNT; f++)
         if(d->P.i[f]) hipFree(d->P.i[f]);
@@ -2235,6 +2301,9 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     if(d->stream2) hipStreamDestroy(d->stream2);
     if(d->fork) hipEventDestroy(d->fork);
     if(d->join) hipEventDestroy(d->join);
+    if(d->roll) hipStreamSynchronize(d->roll);
+    if(d->roll_in) hipEventDestroy(d->roll_in);
+    if(d->roll_out) hipEventDestroy(d->roll_out);
     delete d;
 }
 
@@ -2260,6 +2329,8 @@ int ilqg_dev_set_params(ilqg_dev_t *d, int n_params, const int *sizes, const dou
             }
             for(int j = 0; j < sizes[i]; j++) d->pv.v[offs[i] + j] = values[i][j];
         }
+        d->per_step_params = false;
+        for(int i = 0; i < n_params; i++) d->per_step_params |= (sizes[i] == -1);
     }
     for(int i = 0; i < n_params; i++) {
         const int sz = sizes[i] == -1 ? d->N + 1 : sizes[i];
@@ -2335,12 +2406,28 @@ static int nom_io(ilqg_dev *d, int field, double *host_rw, const double *host_ro
 #define REC_FIELDS_FULL(OP)
 #endif
 
-static int der_io(ilqg_dev *d, double *host_rw, const double *host_ro) {
-    if(d->B > d->chunk) {
-        g_err = "derivative records of the whole batch do not fit the work buffer (wave mapping): read/write them "
-                "with a batch <= the chunk size";
+// The context's PRIVATE record buffer, for calls that leave records behind or find them there (ilqg_dev_derivs, the
+// single sweep of the drop-in back_pass(), reading / writing records): allocated when the first such call is made,
+// for the whole batch (these calls exist for tests and for the single-trajectory drop-in path).
+static int own_work(ilqg_dev *d) {
+    if(d->P.work) return 0;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t per_traj = (size_t)d->N * sizeof(trajEl_t);
+    if((double)d->B * (double)per_traj > 0.5 * (double)free_b) {
+        g_err = "derivative records of the whole batch do not fit the device (wave mapping): stage-by-stage calls and "
+                "record transfers need a smaller batch; ilqg_dev_iterate / ilqg_dev_backward(mode 2) work in chunks";
         return 1;
     }
+    HIP_TRY(hipMalloc((void **)&d->P.work, (size_t)d->B * per_traj));
+    HIP_TRY(hipMemsetAsync(d->P.work, 0, (size_t)d->B * per_traj, d->stream));
+    d->own_chunk = d->B;
+    d->work_consts = false;
+    return 0;
+}
+
+static int der_io(ilqg_dev *d, double *host_rw, const double *host_ro) {
+    if(own_work(d)) return 1;
     const size_t n = (size_t)d->B * d->N;
     std::vector<trajEl_t> tmp(n);
     HIP_TRY(hipMemcpy(tmp.data(), d->P.work, n * sizeof(trajEl_t), hipMemcpyDeviceToHost));
@@ -2506,6 +2593,21 @@ int ilqg_dev_reset(ilqg_dev_t *d) {
     return 0;
 }
 
+// the stream the roll-out family of a context runs on, and the two hand-overs with the context's own stream
+static hipStream_t roll_stream(ilqg_dev_t *d) { return d->roll ? d->roll : d->stream; }
+static int roll_enter(ilqg_dev_t *d) {  // what is queued on the context's stream happens before the roll-outs
+    if(!d->roll) return 0;
+    HIP_TRY(hipEventRecord(d->roll_in, d->stream));
+    HIP_TRY(hipStreamWaitEvent(d->roll, d->roll_in, 0));
+    return 0;
+}
+static int roll_leave(ilqg_dev_t *d) {  // ... and the roll-outs before whatever the context's stream gets next
+    if(!d->roll) return 0;
+    HIP_TRY(hipEventRecord(d->roll_out, d->roll));
+    HIP_TRY(hipStreamWaitEvent(d->stream, d->roll_out, 0));
+    return 0;
+}
+
 static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_alpha, hipStream_t stream = nullptr) {
     if(!stream) stream = d->stream;
     Timed t(d, kernel_id, stream);
@@ -2522,29 +2624,57 @@ static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_
 int ilqg_dev_rollout_init(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipMemsetAsync(d->P.i[ILQG_I_STATUS], 0, d->Bp * sizeof(int), d->stream));
-    launch_rollout(d, ROLL_INIT, ILQG_K_ROLLOUT_INIT, 0, 1);
+    if(roll_enter(d)) return 1;
+    HIP_TRY(hipMemsetAsync(d->P.i[ILQG_I_STATUS], 0, d->Bp * sizeof(int), roll_stream(d)));
+    launch_rollout(d, ROLL_INIT, ILQG_K_ROLLOUT_INIT, 0, 1, roll_stream(d));
     HIP_TRY(hipGetLastError());
-    return 0;
+    return roll_leave(d);
 }
 
 #if ILQG_WAVE_MAP
 // wave mapping: derivative records are evaluated chunk by chunk into the work buffer and consumed by
 // the backward kernel of the same chunk.  do_derivs = 0 uses the records already in the buffer.
 static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_backward) {
-    // factored records (FACTORED builds, option fuse_derivs): only where records are produced and consumed in one go —
-    // records the caller reads or writes (ilqg_dev_derivs, the drop-in back_pass()) are always the complete ones
-    const bool fact = FACTORED && d->O.fuse_derivs && do_derivs && do_backward;
-    if(do_derivs && fact != d->work_factored) {
-        d->work_consts = d->half_consts[0] = d->half_consts[1] = false;  // the products of a step overwrite the start of fxx
-        d->work_factored = fact;
+    // Records produced and consumed in one go use the device's shared work buffer, chunk by chunk; records that are
+    // left behind or found (ilqg_dev_derivs, the drop-in back_pass()) the context's private one, whole batch.
+    const bool transient = do_derivs && do_backward;
+    // factored records (FACTORED builds, option fuse_derivs): only in the transient case — records the caller reads or
+    // writes are always the complete ones
+    const bool fact = FACTORED && d->O.fuse_derivs && transient;
+    SharedWork *W = transient ? d->shared : nullptr;
+    trajEl_t *work;
+    int chunk;
+    if(transient) {
+        work = W->buf;
+        chunk = d->chunk;
+        HIP_TRY(hipStreamWaitEvent(d->stream, W->free_ev, 0));  // the previous owner's pass has finished
+    } else {
+        if(own_work(d)) return 1;
+        work = d->P.work;
+        chunk = d->own_chunk;
     }
     // A batch that needs several chunks alternates between the two halves of the work buffer on two streams.  The
     // trajectories of a chunk need very different numbers of sweeps (lambda retries), so a chunk on its own ends in a
     // long tail of a few busy wavefronts; with the next chunk already running on the other stream the tail is filled
     // (measured on the n = 16 problem: one chunk of 1 024 trajectories takes 41 ms, the average trajectory 14 ms).
-    const bool split = d->B > d->chunk && d->chunk >= 2 && do_derivs && do_backward;
-    const int part = split ? d->chunk / 2 : d->chunk;
+    const bool split = d->B > chunk && chunk >= 2 && transient;
+    const int part = split ? chunk / 2 : chunk;
+    // which constant entries (init_running) the buffer already holds for this context
+    bool *whole = &d->work_consts, *half = d->half_consts;
+    if(transient) {
+        const bool same = W->pv_set && W->N == d->N && W->part == part && W->factored == fact && !d->per_step_params &&
+                          memcmp(&W->pv, &d->pv, sizeof(ParamValues)) == 0;
+        if(!same) {
+            W->whole = W->half[0] = W->half[1] = false;
+            W->pv = d->pv;
+            W->pv_set = !d->per_step_params;
+            W->N = d->N;
+            W->part = part;
+            W->factored = fact;
+        }
+        whole = &W->whole;
+        half = W->half;
+    }
     if(split) {
         HIP_TRY(hipEventRecord(d->fork, d->stream));
         HIP_TRY(hipStreamWaitEvent(d->stream2, d->fork, 0));
@@ -2555,24 +2685,24 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
         const int h = split ? (piece & 1) : 0;
         hipStream_t st = h ? d->stream2 : d->stream;
         DevPtrs P = d->P;
-        P.work = d->P.work + (size_t)h * part * d->N;
+        P.work = work + (size_t)h * part * d->N;
         if(do_derivs) {
             Timed t(d, ILQG_K_DERIVS, st);
             const size_t total = (size_t)cnt * (d->N + 1);
-            const bool have_consts = d->work_consts || (split && d->half_consts[h]);
+            const bool have_consts = *whole || (split && half[h]);
             hipLaunchKernelGGL(k_derivs_wave, grid1(total, 64), dim3(64), 0, st, P, d->O, d->pv, c0, cnt, have_consts ? 0 : 1,
                                fact ? 1 : 0);
             if(cnt == part) {  // every element of this (half of the) buffer has its constants now
-                if(split) d->half_consts[h] = true;
-                else d->work_consts = d->half_consts[0] = d->half_consts[1] = true;
+                if(split) half[h] = true;
+                else *whole = half[0] = half[1] = true;
             }
         }
         if(do_backward) {
             Timed t(d, ILQG_K_BACKWARD, st);
             if(fact) {
-                constexpr int W = ILQG_FACT_WAVES;
-                const size_t lds = (size_t)(TABLE_DOUBLES + W * WAVE_LDS_DOUBLES) * sizeof(double);
-                hipLaunchKernelGGL(k_backward_wave<FACTORED>, dim3((cnt + W - 1) / W), dim3(64 * W), lds, st, P, d->O,
+                constexpr int WV = ILQG_FACT_WAVES;
+                const size_t lds = (size_t)(TABLE_DOUBLES + WV * WAVE_LDS_DOUBLES) * sizeof(double);
+                hipLaunchKernelGGL(k_backward_wave<FACTORED>, dim3((cnt + WV - 1) / WV), dim3(64 * WV), lds, st, P, d->O,
                                    single_sweep, c0, cnt);
             } else {
                 hipLaunchKernelGGL(k_backward_wave<false>, dim3(cnt), dim3(64), (size_t)WAVE_LDS_DOUBLES * sizeof(double), st,
@@ -2584,6 +2714,7 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
         HIP_TRY(hipEventRecord(d->join, d->stream2));
         HIP_TRY(hipStreamWaitEvent(d->stream, d->join, 0));
     }
+    if(transient) HIP_TRY(hipEventRecord(W->free_ev, d->stream));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2593,10 +2724,6 @@ int ilqg_dev_derivs(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
 #if ILQG_WAVE_MAP
-    if(d->B > d->chunk) {
-        g_err = "ilqg_dev_derivs: the batch does not fit the work buffer; use ilqg_dev_backward(mode 2) / iterate";
-        return 1;
-    }
     return wave_backward(d, 0, 1, 0);
 #else
     {
@@ -2618,10 +2745,6 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
     if(mode == 2) NEED_PARAMS(d);
 
 #if ILQG_WAVE_MAP
-    if(mode != 2 && d->B > d->chunk) {
-        g_err = "ilqg_dev_backward: stored records need the whole batch in the work buffer; use mode 2";
-        return 1;
-    }
     return wave_backward(d, mode == 1, mode == 2, 1);
 #else
     {
@@ -2652,44 +2775,49 @@ int ilqg_dev_search(ilqg_dev_t *d) {
     HIP_TRY(hipSetDevice(d->device));
     const int A = d->O.n_alpha;
     const int s1 = (d->O.ls_split > 0 && d->O.ls_split < A) ? d->O.ls_split : A;
-    HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), d->stream));
-    launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, 0, s1);
+    hipStream_t rs = roll_stream(d);
+    if(roll_enter(d)) return 1;
+    HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), rs));
+    launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, 0, s1, rs);
     {
-        Timed t(d, ILQG_K_SELECT);
-        hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O, 0, s1, 0);
+        Timed t(d, ILQG_K_SELECT, rs);
+        hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O, 0, s1, 0);
     }
     if(s1 < A) {
         // The grid covers the worst case; blocks beyond the pending count return at once.
-        launch_rollout(d, ROLL_SEARCH_LIST, ILQG_K_ROLLOUT_SEARCH2, s1, A - s1);
-        Timed t(d, ILQG_K_SELECT);
-        hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O, s1, A, 1);
+        launch_rollout(d, ROLL_SEARCH_LIST, ILQG_K_ROLLOUT_SEARCH2, s1, A - s1, rs);
+        Timed t(d, ILQG_K_SELECT, rs);
+        hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O, s1, A, 1);
     }
     HIP_TRY(hipGetLastError());
-    return 0;
+    return roll_leave(d);
 }
 
 int ilqg_dev_winner(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
-    launch_rollout(d, ROLL_WINNER, ILQG_K_ROLLOUT_WINNER, 0, 1);
+    if(roll_enter(d)) return 1;
+    launch_rollout(d, ROLL_WINNER, ILQG_K_ROLLOUT_WINNER, 0, 1, roll_stream(d));
     HIP_TRY(hipGetLastError());
-    return 0;
+    return roll_leave(d);
 }
 
 int ilqg_dev_update(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
+    hipStream_t rs = roll_stream(d);
+    if(roll_enter(d)) return 1;
     {
-        Timed t(d, ILQG_K_UPDATE);
-        hipLaunchKernelGGL(k_update, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O);
+        Timed t(d, ILQG_K_UPDATE, rs);
+        hipLaunchKernelGGL(k_update, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O);
     }
     if(HAS_MUL) {
-        Timed t(d, ILQG_K_MULTIPLIERS);
-        hipLaunchKernelGGL(k_multipliers, dim3(d->Bp / WAVE), dim3(WAVE), 0, d->stream, d->P, d->O, d->pv, 0);
+        Timed t(d, ILQG_K_MULTIPLIERS, rs);
+        hipLaunchKernelGGL(k_multipliers, dim3(d->Bp / WAVE), dim3(WAVE), 0, rs, d->P, d->O, d->pv, 0);
     }
-    if(d->O.resweep || HAS_MUL) launch_rollout(d, ROLL_COST, ILQG_K_ROLLOUT_COST, 0, 1);
+    if(d->O.resweep || HAS_MUL) launch_rollout(d, ROLL_COST, ILQG_K_ROLLOUT_COST, 0, 1, rs);
     HIP_TRY(hipGetLastError());
-    return 0;
+    return roll_leave(d);
 }
 
 int ilqg_dev_iterate(ilqg_dev_t *d, int n) {

@@ -388,7 +388,7 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
 #pragma unroll
         for(int q = 0; q < NTC; q++) dxu[q] = 0.0;
 #ifndef ILQG_ROW_UNROLL
-#define ILQG_ROW_UNROLL 2
+#define ILQG_ROW_UNROLL 8
 #endif
 #pragma unroll ILQG_ROW_UNROLL
         for(int i = 0; i < NX; i++) {
