@@ -1303,9 +1303,19 @@ enum { RK_GENERAL = 0, RK_INIT = 1, RK_COST = 2 };
 #define ILQG_ROLLOUT_ATTR
 #endif
 
+// Wavefronts per workgroup of the roll-outs (experiments).  One: in the wave mapping a roll-out wavefront fills the
+// register file of its SIMD and the backward kernel's workgroup needs a whole CU, so four per workgroup (one CU
+// instead of four blocked) was tried to let the roll-outs of one group of trajectories share the chip with the
+// backward pass of another — 1.86 it/s (one group) and 1.92 (two groups, 8 hardware queues) against 1.98 as is:
+// the backward kernel keeps the SIMDs it runs on busy, there is little idle issue time to give away.
+#ifndef ILQG_ROLL_WAVES
+#define ILQG_ROLL_WAVES 1
+#endif
+constexpr int ROLL_BLOCK = WAVE * ILQG_ROLL_WAVES;
+
 template <int KIND>
-__global__ __launch_bounds__(WAVE) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int mode, int a0) {
-    int b = blockIdx.x * WAVE + threadIdx.x;
+__global__ __launch_bounds__(ROLL_BLOCK) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int mode, int a0) {
+    int b = blockIdx.x * ROLL_BLOCK + threadIdx.x;
     const int ai = a0 + blockIdx.y;
     if(mode == ROLL_SEARCH_LIST) {
         if(b >= *P.n_pending) return;
@@ -2611,7 +2621,7 @@ static int roll_leave(ilqg_dev_t *d) {  // ... and the roll-outs before whatever
 static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_alpha, hipStream_t stream = nullptr) {
     if(!stream) stream = d->stream;
     Timed t(d, kernel_id, stream);
-    const dim3 grid(d->Bp / WAVE, n_alpha), block(WAVE);
+    const dim3 grid((d->Bp + ROLL_BLOCK - 1) / ROLL_BLOCK, n_alpha), block(ROLL_BLOCK);
     if(mode == ROLL_INIT)
         hipLaunchKernelGGL(k_rollout<RK_INIT>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
     else if(mode == ROLL_COST)
