@@ -282,7 +282,9 @@ struct DevPtrs {
     int *pending;        // trajectories that go to the second line-search stage
     int *n_pending;      // their count (read by the second stage)
     int *n_pending_next; // counter the first-stage selection appends with (same word as n_pending)
-    trajEl_t *work;      // wave mapping: derivative records of one chunk of trajectories, [chunk][N]
+    trajEl_t *work;      // wave mapping: derivative records of one chunk of trajectories, [chunk][N], work_stride apart
+    size_t work_stride;  //   sizeof(trajEl_t), or less for factored records (see FACT_STRIDE)
+    int *queue;          // wave mapping: next trajectory of the chunk to be taken by a wavefront of the backward kernel
     double *nom;         // packed trajectory records, see nomp()
     double **p;
     int B, Bp, N;
@@ -980,6 +982,32 @@ __global__ __launch_bounds__(WAVE *PACK_WAVES) void k_pack_records(DevPtrs P) {
 // wave mapping: calc_derivs straight into the device trajEl_t records, one lane per
 // (trajectory of the chunk, time step); step N is the final record
 // ---------------------------------------------------------------------------
+// Factored records use the head of trajEl_t (x .. fu and the NBASIS products at the start of fxx) and its tail (the
+// members behind fxu: the auxiliaries) — the 38 KB of tensors in between are never touched.  Such records are laid
+// down OVERLAPPING, FACT_STRIDE < sizeof(trajEl_t) apart, the head of one record inside the unused middle of an
+// earlier one: the smallest distance at which no head (offsets [0, A) modulo the distance) meets a tail (offsets
+// [TAIL mod distance, + T)).  4x as many trajectories per chunk of the work buffer for the n = 16 problem
+// (11 992 instead of 47 944 bytes per step).  Only when init_running() stores nothing in the tensors (generator
+// hint ILQG_TENSOR_INIT_WRITES).
+#if ILQG_FACTORED && defined(ILQG_TENSOR_INIT_WRITES) && !ILQG_TENSOR_INIT_WRITES
+constexpr size_t fact_stride() {
+    const size_t A = offsetof(trajEl_t, fxx) + NBASIS * sizeof(double);
+    const size_t TAIL = offsetof(trajEl_t, fxu) + sizeof(double) * NX * NXU, T = sizeof(trajEl_t) - TAIL;
+    if(T == 0) return (A + 7) / 8 * 8;
+    for(size_t S = (A + T + 7) / 8 * 8; S < sizeof(trajEl_t); S += 8) {
+        const size_t r = TAIL % S;
+        if(r >= A && r + T <= S) return S;
+    }
+    return sizeof(trajEl_t);
+}
+constexpr size_t FACT_STRIDE = fact_stride();
+#else
+constexpr size_t FACT_STRIDE = sizeof(trajEl_t);
+#endif
+__device__ __forceinline__ trajEl_t *work_rec(const DevPtrs &P, int bw, int k) {
+    return reinterpret_cast<trajEl_t *>(reinterpret_cast<char *>(P.work) + ((size_t)bw * P.N + k) * P.work_stride);
+}
+
 // factored: the first-order part of the record and, in place of the tensors, the products they are multiples of
 // (NBASIS doubles at the start of the record's fxx member)
 __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first,
@@ -998,7 +1026,7 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
         multipliersEl_t mk;
         load_mul(P, k, b, mk);
         multipliersEl_t *const mp = HAS_MUL ? &mk : nullptr;
-        trajEl_t *t = P.work + (size_t)bw * P.N + k;
+        trajEl_t *t = work_rec(P, bw, k);
         if(init_consts) init_running(t, &C.o1);  // constant entries, once per buffer (init_opt, iLQG_func.tem:402-415)
         auto body = [&]() {
             for(int i = 0; i < NX; i++) t->x[i] = nomp(P, k, b)[NOM_X + i];
@@ -1125,7 +1153,7 @@ __device__ __forceinline__ int backward_sweep_wave(StepLds &S, const double *tab
     Prof *pf = nullptr;
 #endif
     auto fields = [&](int k) {
-        const trajEl_t *t = P.work + (size_t)bw * N + k;
+        const trajEl_t *t = work_rec(P, bw, k);
         StepFields<NX, NU> F;
         F.cx = t->cx; F.cxx = t->cxx; F.cu = t->cu; F.cuu = t->cuu; F.cxu = t->cxu;
         F.fx = t->fx; F.fu = t->fu; F.lower = t->lower; F.upper = t->upper;
@@ -1180,25 +1208,11 @@ __device__ __forceinline__ int backward_sweep_wave(StepLds &S, const double *tab
 #define ILQG_WAVE_ATTR
 #endif
 // FACT: factored records (see FactoredSource); ILQG_FACT_WAVES wavefronts per workgroup share the coefficient tables
+// back_pass + retry loop of ONE trajectory (b; slot bw of the chunk's records) on the calling wavefront
 template <bool FACT>
-__global__ __launch_bounds__(64 * (FACT ? ILQG_FACT_WAVES : 1), FACT ? 1 : ILQG_WAVE_OCC) ILQG_WAVE_ATTR
-void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_first, int chunk_count) {
-    extern __shared__ double wave_lds[];  // [coefficient tables][per wavefront: step block, products]
-    constexpr int WAVES = FACT ? ILQG_FACT_WAVES : 1;
-#if ILQG_FACTORED
-    if(FACT) {
-        for(int i = threadIdx.x; i < NX * SXX; i += 64 * WAVES) wave_lds[i] = ilqg_tensor_coef_xx[i];
-        for(int i = threadIdx.x; i < NX * SUU; i += 64 * WAVES) wave_lds[NX * SXX + i] = ilqg_tensor_coef_uu[i];
-        for(int i = threadIdx.x; i < NX * NXU; i += 64 * WAVES) wave_lds[NX * (SXX + SUU) + i] = ilqg_tensor_coef_xu[i];
-        __syncthreads();  // the only meeting of the workgroup's wavefronts
-    }
-#endif
-    const int wave = threadIdx.x >> 6;
-    StepLds &S = *reinterpret_cast<StepLds *>(wave_lds + (FACT ? TABLE_DOUBLES : 0) + wave * WAVE_LDS_DOUBLES);
-    const int bw = blockIdx.x * WAVES + wave;
-    const int b = chunk_first + bw;
+__device__ __forceinline__ void backward_of_trajectory(StepLds &S, const double *tables, const DevPtrs &P, const ilqg_dev_opts_t &O,
+                                                       int single_sweep, int b, int bw) {
     const int lane = threadIdx.x & 63;
-    if(bw >= chunk_count || b >= P.B) return;
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
     if(P.derivs_failed[b]) {
         if(lane == 0) {
@@ -1211,7 +1225,7 @@ void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_f
     double dV0 = 0.0, dV1 = 0.0, g_norm = P.f[ILQG_F_GNORM][b];
     int calls = 0, rc, status = ILQG_ST_ACTIVE;
     for(;;) {
-        rc = backward_sweep_wave<FACT>(S, wave_lds, P, b, bw, lambda, O.regType, dV0, dV1, g_norm);
+        rc = backward_sweep_wave<FACT>(S, tables, P, b, bw, lambda, O.regType, dV0, dV1, g_norm);
         calls++;
         if(single_sweep || rc != 1) break;
         const double t1 = dlambda * O.lambdaFactor;
@@ -1241,6 +1255,36 @@ void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_f
         P.f[ILQG_F_GNORM][b] = g_norm;
         P.i[ILQG_I_BP_CALLS][b] = calls;
         P.i[ILQG_I_BP_RC][b] = rc;
+    }
+}
+
+// The trajectories of a chunk need very different numbers of sweeps (lambda retries: 1 to 4 and more), so wavefronts
+// are not tied to trajectories: each takes the next one of the chunk from a counter (P.queue, zeroed before the
+// launch) until the chunk is used up — the grid is at most what the chip holds at once, and a wavefront whose
+// trajectory was quick does not wait for the slow ones of its workgroup.  Every wavefront leaves the loop: the counter
+// only grows.
+template <bool FACT>
+__global__ __launch_bounds__(64 * (FACT ? ILQG_FACT_WAVES : 1), FACT ? 1 : ILQG_WAVE_OCC) ILQG_WAVE_ATTR
+void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_first, int chunk_count) {
+    extern __shared__ double wave_lds[];  // [coefficient tables][per wavefront: step block, products]
+    constexpr int WAVES = FACT ? ILQG_FACT_WAVES : 1;
+#if ILQG_FACTORED
+    if(FACT) {
+        for(int i = threadIdx.x; i < NX * SXX; i += 64 * WAVES) wave_lds[i] = ilqg_tensor_coef_xx[i];
+        for(int i = threadIdx.x; i < NX * SUU; i += 64 * WAVES) wave_lds[NX * SXX + i] = ilqg_tensor_coef_uu[i];
+        for(int i = threadIdx.x; i < NX * NXU; i += 64 * WAVES) wave_lds[NX * (SXX + SUU) + i] = ilqg_tensor_coef_xu[i];
+        __syncthreads();  // the only meeting of the workgroup's wavefronts
+    }
+#endif
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    StepLds &S = *reinterpret_cast<StepLds *>(wave_lds + (FACT ? TABLE_DOUBLES : 0) + wave * WAVE_LDS_DOUBLES);
+    for(;;) {
+        int bw = 0;
+        if(lane == 0) bw = atomicAdd(P.queue, 1);
+        bw = __builtin_amdgcn_readfirstlane(bw);
+        if(bw >= chunk_count || chunk_first + bw >= P.B) break;
+        backward_of_trajectory<FACT>(S, wave_lds, P, O, single_sweep, chunk_first + bw, bw);
+        wave_sync();  // the LDS block goes to the next trajectory
     }
 }
 #endif  // ILQG_WAVE_MAP
@@ -1888,13 +1932,15 @@ struct SharedWork {
     int refs;
     // which constant record entries (init_running) the buffer holds: for whom, and where
     bool whole, half[2], factored, pv_set;
-    int N, part;
+    int N, part, half_cap;
     ParamValues pv;
 };
 static SharedWork g_work[64];
 #else
 struct SharedWork;
 #endif
+
+constexpr int QUEUE_CELL = 32;  // ints between two counters: a cache line each
 
 struct ilqg_dev {
     int device, B, Bp, N;
@@ -1916,6 +1962,8 @@ struct ilqg_dev {
     struct PendingRead { void *dst; const void *src; size_t bytes; int transpose_w; };
     std::vector<PendingRead> pending;
     int *counter;
+    int *queues;          // wave mapping: the backward kernel's trajectory counters (DevPtrs::queue), QUEUE_CELL ints apart
+    int cus;              // compute units of the device
     int chunk;            // wave mapping: trajectories whose derivative records fit the work buffer
     bool work_consts;     // wave mapping: constant entries of the records written (init_running)
     bool work_factored;   // wave mapping: the records in the work buffer are factored ones (see FACTORED)
@@ -2267,6 +2315,12 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
     HIP_TRY(hipMalloc((void **)&d->P.derivs_failed, d->Bp * sizeof(int)));
     HIP_TRY(hipMemsetAsync(d->P.derivs_failed, 0, d->Bp * sizeof(int), d->stream));
     HIP_TRY(hipMalloc((void **)&d->counter, sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d->queues, 2 * QUEUE_CELL * sizeof(int)));  // one cell per stream of the chunk pipeline
+    {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        d->cus = cus > 0 ? cus : 256;
+    }
     HIP_TRY(hipMalloc((void **)&d->P.pending, d->Bp * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&d->P.n_pending, sizeof(int)));
     HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), d->stream));
@@ -2301,6 +2355,7 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
         if(d->P.i[f]) hipFree(d->P.i[f]);
     if(d->P.derivs_failed) hipFree(d->P.derivs_failed);
     if(d->counter) hipFree(d->counter);
+    if(d->queues) hipFree(d->queues);
     if(d->P.pending) hipFree(d->P.pending);
     if(d->P.n_pending) hipFree(d->P.n_pending);
     for(double *p : d->param_bufs) hipFree(p);
@@ -2652,34 +2707,47 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
     // writes are always the complete ones
     const bool fact = FACTORED && d->O.fuse_derivs && transient;
     SharedWork *W = transient ? d->shared : nullptr;
-    trajEl_t *work;
+    const size_t stride = fact ? FACT_STRIDE : sizeof(trajEl_t);
+    char *work;
     int chunk;
     if(transient) {
-        work = W->buf;
-        chunk = d->chunk;
+        work = reinterpret_cast<char *>(W->buf);
+        // (the last record reaches sizeof(trajEl_t) beyond its start whatever the distance between records)
+        const size_t fit = (W->bytes - sizeof(trajEl_t)) / ((size_t)d->N * stride);
+        chunk = (int)(fit > (size_t)d->B ? (size_t)d->B : fit);
+        if(chunk < 1) {
+            g_err = "the device's derivative work buffer does not hold one trajectory of this horizon";
+            return 1;
+        }
         HIP_TRY(hipStreamWaitEvent(d->stream, W->free_ev, 0));  // the previous owner's pass has finished
     } else {
         if(own_work(d)) return 1;
-        work = d->P.work;
+        work = reinterpret_cast<char *>(d->P.work);
         chunk = d->own_chunk;
     }
-    // A batch that needs several chunks alternates between the two halves of the work buffer on two streams.  The
-    // trajectories of a chunk need very different numbers of sweeps (lambda retries), so a chunk on its own ends in a
-    // long tail of a few busy wavefronts; with the next chunk already running on the other stream the tail is filled
-    // (measured on the n = 16 problem: one chunk of 1 024 trajectories takes 41 ms, the average trajectory 14 ms).
+    // A batch that needs several chunks alternates between the two halves of the work buffer on two streams, so that
+    // the derivatives of one chunk are evaluated while the other's backward pass runs and the end of one backward
+    // kernel (few wavefronts still busy) is filled by the next.  The pieces are of equal size.
     const bool split = d->B > chunk && chunk >= 2 && transient;
-    const int part = split ? chunk / 2 : chunk;
+    const int half_cap = split ? chunk / 2 : chunk;              // trajectories a half of the buffer holds
+    const int pieces = (d->B + half_cap - 1) / half_cap;
+    int part = chunk;
+    if(split) {
+        part = ((d->B + pieces - 1) / pieces + 7) / 8 * 8;  // whole workgroups of the factored backward kernel
+        if(part > half_cap) part = half_cap;
+    }
     // which constant entries (init_running) the buffer already holds for this context
     bool *whole = &d->work_consts, *half = d->half_consts;
     if(transient) {
-        const bool same = W->pv_set && W->N == d->N && W->part == part && W->factored == fact && !d->per_step_params &&
-                          memcmp(&W->pv, &d->pv, sizeof(ParamValues)) == 0;
+        const bool same = W->pv_set && W->N == d->N && W->part == part && W->half_cap == half_cap && W->factored == fact &&
+                          !d->per_step_params && memcmp(&W->pv, &d->pv, sizeof(ParamValues)) == 0;
         if(!same) {
             W->whole = W->half[0] = W->half[1] = false;
             W->pv = d->pv;
             W->pv_set = !d->per_step_params;
             W->N = d->N;
             W->part = part;
+            W->half_cap = half_cap;
             W->factored = fact;
         }
         whole = &W->whole;
@@ -2695,28 +2763,33 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
         const int h = split ? (piece & 1) : 0;
         hipStream_t st = h ? d->stream2 : d->stream;
         DevPtrs P = d->P;
-        P.work = work + (size_t)h * part * d->N;
+        P.work = reinterpret_cast<trajEl_t *>(work + (size_t)h * half_cap * d->N * stride);
+        P.work_stride = stride;
+        P.queue = d->queues + h * QUEUE_CELL;
         if(do_derivs) {
             Timed t(d, ILQG_K_DERIVS, st);
             const size_t total = (size_t)cnt * (d->N + 1);
             const bool have_consts = *whole || (split && half[h]);
             hipLaunchKernelGGL(k_derivs_wave, grid1(total, 64), dim3(64), 0, st, P, d->O, d->pv, c0, cnt, have_consts ? 0 : 1,
                                fact ? 1 : 0);
-            if(cnt == part) {  // every element of this (half of the) buffer has its constants now
+            if(cnt == part) {  // every element of this (half of the) buffer that is ever used has its constants now
                 if(split) half[h] = true;
                 else *whole = half[0] = half[1] = true;
             }
         }
         if(do_backward) {
+            HIP_TRY(hipMemsetAsync(P.queue, 0, sizeof(int), st));
             Timed t(d, ILQG_K_BACKWARD, st);
             if(fact) {
                 constexpr int WV = ILQG_FACT_WAVES;
                 const size_t lds = (size_t)(TABLE_DOUBLES + WV * WAVE_LDS_DOUBLES) * sizeof(double);
-                hipLaunchKernelGGL(k_backward_wave<FACTORED>, dim3((cnt + WV - 1) / WV), dim3(64 * WV), lds, st, P, d->O,
+                const int wgs = (cnt + WV - 1) / WV;  // one workgroup per CU at a time (LDS)
+                hipLaunchKernelGGL(k_backward_wave<FACTORED>, dim3(wgs < d->cus ? wgs : d->cus), dim3(64 * WV), lds, st, P, d->O,
                                    single_sweep, c0, cnt);
             } else {
-                hipLaunchKernelGGL(k_backward_wave<false>, dim3(cnt), dim3(64), (size_t)WAVE_LDS_DOUBLES * sizeof(double), st,
-                                   P, d->O, single_sweep, c0, cnt);
+                const int cap = d->cus * 8;
+                hipLaunchKernelGGL(k_backward_wave<false>, dim3(cnt < cap ? cnt : cap), dim3(64),
+                                   (size_t)WAVE_LDS_DOUBLES * sizeof(double), st, P, d->O, single_sweep, c0, cnt);
             }
         }
     }

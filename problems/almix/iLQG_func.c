@@ -33,22 +33,22 @@ tParamDesc *paramdesc[]= {&p_name1, &p_name2, &p_name3, &p_name4, &p_name5, &p_n
 #define aux_pfe_2 t->pfe_2
 #define aux_hfi_1 t->hfi_1
 #define aux_pfi_1 t->pfi_1
-#define daux_dpli_2_x1 t->dpli_2_x1
 #define daux_dhle_1_x1 t->dhle_1_x1
 #define daux_dple_1_x1 t->dple_1_x1
 #define daux_dpli_1_x1 t->dpli_1_x1
+#define daux_dpli_2_x1 t->dpli_2_x1
 #define daux_dple_1_u1 t->dple_1_u1
 #define daux_dple_1_x1x1 t->dple_1_x1x1
-#define daux_dpli_2_x1x1 t->dpli_2_x1x1
 #define daux_dpli_1_x1x1 t->dpli_1_x1x1
+#define daux_dpli_2_x1x1 t->dpli_2_x1x1
 #define daux_dple_1_u1u1 t->dple_1_u1u1
 #define daux_dple_1_u1x1 t->dple_1_u1x1
 #define daux_dpfe_2_x0 t->dpfe_2_x0
 #define daux_dpfi_1_x0 t->dpfi_1_x0
 #define daux_dpfe_1_x1 t->dpfe_1_x1
 #define daux_dpfe_2_x2 t->dpfe_2_x2
-#define daux_dpfi_1_x0x0 t->dpfi_1_x0x0
 #define daux_dpfe_2_x0x0 t->dpfe_2_x0x0
+#define daux_dpfi_1_x0x0 t->dpfi_1_x0x0
 #define daux_dpfe_2_x0x2 t->dpfe_2_x0x2
 #define daux_dpfe_1_x1x1 t->dpfe_1_x1x1
 #define daux_dpfe_2_x2x2 t->dpfe_2_x2x2
@@ -298,13 +298,6 @@ static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
     const double w_pen= o->w_pen_l;
     double **const p= o->p;
 
-    daux_dpli_2_x1= -((aux_hli_2 >= 0.0) ? (
-   aux_hli_2*m->mu_li[1]*w_pen + m->mu_li[1]*(aux_hli_2*w_pen + 1.0)
-)
-: (
-   aux_hli_2*m->mu_li[1]*w_pen/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0)) + m->mu_li[1]/(-aux_hli_2*w_pen + 1.0)
-));
-    if(isNANorINF(daux_dpli_2_x1)) { PRNT("    @k %d: daux_dpli_2_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpli_2_x1); return 0; }
     daux_dhle_1_x1= -1.0/2.0*p[6][k];
     if(isNANorINF(daux_dhle_1_x1)) { PRNT("    @k %d: daux_dhle_1_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dhle_1_x1); return 0; }
     daux_dple_1_x1= daux_dhle_1_x1*(1.0*aux_hle_1*w_pen + m->mu_le[0]);
@@ -316,17 +309,17 @@ static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
    aux_hli_1*m->mu_li[0]*w_pen/((-aux_hli_1*w_pen + 1.0)*(-aux_hli_1*w_pen + 1.0)) + m->mu_li[0]/(-aux_hli_1*w_pen + 1.0)
 ));
     if(isNANorINF(daux_dpli_1_x1)) { PRNT("    @k %d: daux_dpli_1_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpli_1_x1); return 0; }
+    daux_dpli_2_x1= -((aux_hli_2 >= 0.0) ? (
+   aux_hli_2*m->mu_li[1]*w_pen + m->mu_li[1]*(aux_hli_2*w_pen + 1.0)
+)
+: (
+   aux_hli_2*m->mu_li[1]*w_pen/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0)) + m->mu_li[1]/(-aux_hli_2*w_pen + 1.0)
+));
+    if(isNANorINF(daux_dpli_2_x1)) { PRNT("    @k %d: daux_dpli_2_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpli_2_x1); return 0; }
     daux_dple_1_u1= 1.0*aux_hle_1*w_pen + m->mu_le[0];
     if(isNANorINF(daux_dple_1_u1)) { PRNT("    @k %d: daux_dple_1_u1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dple_1_u1); return 0; }
     daux_dple_1_x1x1= 1.0*(daux_dhle_1_x1*daux_dhle_1_x1)*w_pen;
     if(isNANorINF(daux_dple_1_x1x1)) { PRNT("    @k %d: daux_dple_1_x1x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dple_1_x1x1); return 0; }
-    daux_dpli_2_x1x1= ((aux_hli_2 >= 0.0) ? (
-   2.0*m->mu_li[1]*w_pen
-)
-: (
-   2.0*aux_hli_2*m->mu_li[1]*(w_pen*w_pen)/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0)) + 2.0*m->mu_li[1]*w_pen/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0))
-));
-    if(isNANorINF(daux_dpli_2_x1x1)) { PRNT("    @k %d: daux_dpli_2_x1x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpli_2_x1x1); return 0; }
     daux_dpli_1_x1x1= ((aux_hli_1 >= 0.0) ? (
    2.0*m->mu_li[0]*w_pen
 )
@@ -334,6 +327,13 @@ static int calcLAuxDeriv(trajEl_t *t, multipliersEl_t *m, int k, tOptSet *o) {
    2.0*aux_hli_1*m->mu_li[0]*(w_pen*w_pen)/((-aux_hli_1*w_pen + 1.0)*(-aux_hli_1*w_pen + 1.0)*(-aux_hli_1*w_pen + 1.0)) + 2.0*m->mu_li[0]*w_pen/((-aux_hli_1*w_pen + 1.0)*(-aux_hli_1*w_pen + 1.0))
 ));
     if(isNANorINF(daux_dpli_1_x1x1)) { PRNT("    @k %d: daux_dpli_1_x1x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpli_1_x1x1); return 0; }
+    daux_dpli_2_x1x1= ((aux_hli_2 >= 0.0) ? (
+   2.0*m->mu_li[1]*w_pen
+)
+: (
+   2.0*aux_hli_2*m->mu_li[1]*(w_pen*w_pen)/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0)) + 2.0*m->mu_li[1]*w_pen/((-aux_hli_2*w_pen + 1.0)*(-aux_hli_2*w_pen + 1.0))
+));
+    if(isNANorINF(daux_dpli_2_x1x1)) { PRNT("    @k %d: daux_dpli_2_x1x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpli_2_x1x1); return 0; }
     daux_dple_1_u1u1= 1.0*w_pen;
     if(isNANorINF(daux_dple_1_u1u1)) { PRNT("    @k %d: daux_dple_1_u1u1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dple_1_u1u1); return 0; }
     daux_dple_1_u1x1= 1.0*daux_dhle_1_x1*w_pen;
@@ -407,6 +407,8 @@ static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
     if(isNANorINF(daux_dpfe_1_x1)) { PRNT("    @k %d: daux_dpfe_1_x1 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_1_x1); return 0; }
     daux_dpfe_2_x2= -1.0*aux_hfe_2*w_pen - m->mu_fe[1];
     if(isNANorINF(daux_dpfe_2_x2)) { PRNT("    @k %d: daux_dpfe_2_x2 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_2_x2); return 0; }
+    daux_dpfe_2_x0x0= 1.0*w_pen;
+    if(isNANorINF(daux_dpfe_2_x0x0)) { PRNT("    @k %d: daux_dpfe_2_x0x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_2_x0x0); return 0; }
     daux_dpfi_1_x0x0= ((aux_hfi_1 >= 0.0) ? (
    2.0*m->mu_fi[0]*w_pen
 )
@@ -414,8 +416,6 @@ static int calcFAuxDeriv(trajFin_t *t, multipliersFin_t *m, tOptSet *o) {
    2.0*aux_hfi_1*m->mu_fi[0]*(w_pen*w_pen)/((-aux_hfi_1*w_pen + 1.0)*(-aux_hfi_1*w_pen + 1.0)*(-aux_hfi_1*w_pen + 1.0)) + 2.0*m->mu_fi[0]*w_pen/((-aux_hfi_1*w_pen + 1.0)*(-aux_hfi_1*w_pen + 1.0))
 ));
     if(isNANorINF(daux_dpfi_1_x0x0)) { PRNT("    @k %d: daux_dpfi_1_x0x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfi_1_x0x0); return 0; }
-    daux_dpfe_2_x0x0= 1.0*w_pen;
-    if(isNANorINF(daux_dpfe_2_x0x0)) { PRNT("    @k %d: daux_dpfe_2_x0x0 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_2_x0x0); return 0; }
     daux_dpfe_2_x0x2= -1.0*w_pen;
     if(isNANorINF(daux_dpfe_2_x0x2)) { PRNT("    @k %d: daux_dpfe_2_x0x2 in line %d is nan or inf: %g\n", k, __LINE__-1, daux_dpfe_2_x0x2); return 0; }
     daux_dpfe_1_x1x1= 1.0*w_pen;

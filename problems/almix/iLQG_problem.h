@@ -24,6 +24,7 @@
 #define ILQG_PROBLEM_NAME "AlMix"
 #define ILQG_STATE_DEPENDENT_LIMITS 0
 #define ILQG_TENSOR_NBASIS 0  /* > 0: iLQG_func.c has the factored tensor tables */
+#define ILQG_TENSOR_INIT_WRITES 1  /* init_running() writes constant entries of fxx / fuu / fxu */
 
 typedef struct {
     double x[N_X];
@@ -57,14 +58,14 @@ typedef struct {
     double pli_1;
     double hli_2;
     double pli_2;
-    double dpli_2_x1;
     double dhle_1_x1;
     double dple_1_x1;
     double dpli_1_x1;
+    double dpli_2_x1;
     double dple_1_u1;
     double dple_1_x1x1;
-    double dpli_2_x1x1;
     double dpli_1_x1x1;
+    double dpli_2_x1x1;
     double dple_1_u1u1;
     double dple_1_u1x1;
 #if FULL_DDP
@@ -88,8 +89,8 @@ typedef struct {
     double dpfi_1_x0;
     double dpfe_1_x1;
     double dpfe_2_x2;
-    double dpfi_1_x0x0;
     double dpfe_2_x0x0;
+    double dpfi_1_x0x0;
     double dpfe_2_x0x2;
     double dpfe_1_x1x1;
     double dpfe_2_x2x2;

@@ -24,6 +24,7 @@
 #define ILQG_PROBLEM_NAME "Brachi"
 #define ILQG_STATE_DEPENDENT_LIMITS 0
 #define ILQG_TENSOR_NBASIS 0  /* > 0: iLQG_func.c has the factored tensor tables */
+#define ILQG_TENSOR_INIT_WRITES 1  /* init_running() writes constant entries of fxx / fuu / fxu */
 
 typedef struct {
     double x[N_X];

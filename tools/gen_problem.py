@@ -179,7 +179,7 @@ class Deriver:
 
     def total_diff(self, e, z):
         r = sp.diff(e, z)
-        for s in [s for s in e.free_symbols if s in self.defs]:
+        for s in sorted((s for s in e.free_symbols if s in self.defs), key=lambda q: q.name):  # sets have no order
             pd = sp.diff(e, s)
             if pd != 0:
                 ds = self.dsym(s, z)
@@ -537,6 +537,7 @@ class Emitter:
 #define ILQG_PROBLEM_NAME "{self.p.name}"
 #define ILQG_STATE_DEPENDENT_LIMITS {1 if self.has_hx else 0}
 #define ILQG_TENSOR_NBASIS {len(self.tensor_tables["basis"]) if self.tensor_tables else 0}  /* > 0: iLQG_func.c has the factored tensor tables */
+#define ILQG_TENSOR_INIT_WRITES {1 if self.tensor_init_writes() else 0}  /* init_running() writes constant entries of fxx / fuu / fxu */
 
 typedef struct {{
     double x[N_X];
@@ -832,6 +833,12 @@ int calc_derivs(tOptSet *o) {
         out += self.block(self.grad_items("cx", self.Fx), True) + "\n" + self.block(self.hess_items("cxx", self.Fxx), True)
         out += "    return 1;\n}\n\n"
         return out
+
+    def tensor_init_writes(self):
+        """whether init_running() stores anything in the second-derivative tensors of the dynamics (a back-end that
+        works from the factored tables never reads them and may then leave them out of its records)"""
+        return any(self.all_zero(ten) or self.block(self.jaco2_items(nm, ten), False, ind=8).strip() != ""
+                   for nm, ten in (("fxx", self.fxx), ("fuu", self.fuu), ("fxu", self.fxu)))
 
     def emit_constants(self):
         """entries that do not change along a trajectory are written once (init_opt), element by element"""
