@@ -52,7 +52,7 @@ struct ilqg_batch {
     int device, B, N;
     tOptSet opt;                     /* option holder, filled through setOptParam() */
     double alpha_store[ILQG_MAX_ALPHA];
-    int resweep, fuse_derivs, ls_split;
+    int resweep, fuse_derivs, ls_split, ls_keep;
     double **p;                      /* owned copies of the problem parameters */
     char *p_given;                   /* which of them the caller has set */
     int params_pushed;
@@ -255,6 +255,7 @@ ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int gro
      * (65 536 Brachistochrone solves 0.137 s with stored records, 0.156 s fused) */
     c->fuse_derivs = c->resweep ? 0 : 1;
     c->ls_split = 3;
+    c->ls_keep = 1;
     standard_parameters(&c->opt);
     ilqg_dev_dims(dims);
     if(groups <= 0) {
@@ -357,6 +358,11 @@ int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value
         c->ls_split = (int)value[0];
         return 0;
     }
+    if(strcmp(name, "ls_keep") == 0) {
+        if(n != 1) return fail_msg(c, err_scalar);
+        c->ls_keep = value[0] != 0.0;
+        return 0;
+    }
     if(strcmp(name, "fuse_derivs") == 0) {
         if(n != 1) return fail_msg(c, err_scalar);
         c->fuse_derivs = value[0] != 0.0;
@@ -413,6 +419,7 @@ static int push_config(ilqg_batch_t *c) {
     d.resweep = c->resweep;
     d.fuse_derivs = c->fuse_derivs;
     d.ls_split = c->ls_split;
+    d.ls_keep = c->ls_keep;
     { int g; EACH_GROUP(g) if(ilqg_dev_set_opts(c->dev[g], &d)) return fail(c, "options"); }
     if(!c->params_pushed) {
         int sizes[64];

@@ -282,6 +282,9 @@ struct DevPtrs {
     int *pending;        // trajectories that go to the second line-search stage
     int *n_pending;      // their count (read by the second stage)
     int *n_pending_next; // counter the first-stage selection appends with (same word as n_pending)
+    double *cand;        // second line-search stage: the trajectories its lanes roll out, [step size][step 0..N][x u]
+                         //   [entry of pending] (entry fastest: a wavefront stores whole rows) — the accepted one is
+                         //   copied, not rolled out again (k_adopt)
     trajEl_t *work;      // wave mapping: derivative records of one chunk of trajectories, [chunk][N], work_stride apart
     size_t work_stride;  //   sizeof(trajEl_t), or less for factored records (see FACT_STRIDE)
     int *queue;          // wave mapping: next trajectory of the chunk to be taken by a wavefront of the backward kernel
@@ -1017,17 +1020,19 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
     const int k = (int)(tid % (P.N + 1));
     const int b = chunk_first + bw;
     if(bw >= chunk_count || b >= P.B) return;
-    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
     ILQG_CALLBACKS(C, H);
     load_penalty_weights_der(C, P, b);
     tOptSet &o = C.o;
+    // constant entries, once per buffer (init_opt, iLQG_func.tem:402-415) — of EVERY record of the chunk: the slot of a
+    // trajectory that is finished serves another one in a later chunk
+    if(init_consts && k < P.N) init_running(work_rec(P, bw, k), &C.o1);
+    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
     int ok = 1;
     if(k < P.N) {
         multipliersEl_t mk;
         load_mul(P, k, b, mk);
         multipliersEl_t *const mp = HAS_MUL ? &mk : nullptr;
         trajEl_t *t = work_rec(P, bw, k);
-        if(init_consts) init_running(t, &C.o1);  // constant entries, once per buffer (init_opt, iLQG_func.tem:402-415)
         auto body = [&]() {
             for(int i = 0; i < NX; i++) t->x[i] = nomp(P, k, b)[NOM_X + i];
             for(int i = 0; i < NU; i++) t->u[i] = nomp(P, k, b)[NOM_U + i];
@@ -1278,6 +1283,13 @@ void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_f
 #endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     StepLds &S = *reinterpret_cast<StepLds *>(wave_lds + (FACT ? TABLE_DOUBLES : 0) + wave * WAVE_LDS_DOUBLES);
+#ifdef ILQG_LDS_POISON  // debugging: whatever reads LDS it has not written gets this (a NaN, or any other pattern)
+    {
+        double *w = wave_lds + (FACT ? TABLE_DOUBLES : 0) + wave * WAVE_LDS_DOUBLES;
+        for(int i = lane; i < WAVE_LDS_DOUBLES; i += 64) w[i] = __longlong_as_double(ILQG_LDS_POISON);
+        wave_sync();
+    }
+#endif
     for(;;) {
         int bw = 0;
         if(lane == 0) bw = atomicAdd(P.queue, 1);
@@ -1292,7 +1304,8 @@ void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_f
 // ---------------------------------------------------------------------------
 // forward_pass: one lane per (trajectory, step size)
 // ---------------------------------------------------------------------------
-enum { ROLL_INIT = 0, ROLL_SEARCH = 1, ROLL_WINNER = 2, ROLL_COST = 3, ROLL_SEARCH_LIST = 4 };
+enum { ROLL_INIT = 0, ROLL_SEARCH = 1, ROLL_WINNER = 2, ROLL_COST = 3, ROLL_SEARCH_LIST = 4, ROLL_SECOND = 5 };
+constexpr int CAND_W = NX + NU;  // doubles per step of a kept second-stage roll-out
 
 // nominal data of one step (what forward_pass reads of the nominal trajectory, iLQG_func.tem:145-155)
 struct NomStep {
@@ -1335,6 +1348,12 @@ __device__ __forceinline__ void load_nominal(NomStep &s, const NomPtrs &q) {
 //   ROLL_WINNER       lane = trajectory, accepted step size, rolled out again and stored in place of the nominal
 //                     trajectory: accepted = overwritten, no candidate buffer and no swap (iLQG.c:381-386)
 //   ROLL_INIT / ROLL_COST  lane = trajectory
+//   ROLL_SECOND       both at once, by blockIdx.y: 0 = ROLL_WINNER for the trajectories the first stage settled,
+//                     1.. = ROLL_SEARCH_LIST for step size a0 + blockIdx.y - 1, each lane KEEPING its trajectory in
+//                     P.cand.  The two are independent (different trajectories), and each is a latency-bound chain of
+//                     N steps that leaves most of the chip idle: side by side they cost one chain instead of two, and
+//                     the few trajectories the second stage settles are copied from P.cand (k_adopt) instead of a
+//                     third chain.
 // Keeping the candidates of the search instead of re-rolling the winner was measured and dropped: a whole-batch copy
 // of X and U per step size costs more HBM write time than the winner pass, and candidates of the compacted second
 // stage can only be written or copied back as scattered 8-byte pieces.
@@ -1360,7 +1379,17 @@ constexpr int ROLL_BLOCK = WAVE * ILQG_ROLL_WAVES;
 template <int KIND>
 __global__ __launch_bounds__(ROLL_BLOCK) ILQG_ROLLOUT_ATTR void k_rollout(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int mode, int a0) {
     int b = blockIdx.x * ROLL_BLOCK + threadIdx.x;
-    const int ai = a0 + blockIdx.y;
+    int ai = a0 + blockIdx.y;
+    double *keep = nullptr;  // second stage: where this lane's trajectory is kept
+    if(mode == ROLL_SECOND) {
+        if(blockIdx.y == 0) {
+            mode = ROLL_WINNER;
+        } else {
+            mode = ROLL_SEARCH_LIST;
+            ai = a0 + blockIdx.y - 1;
+            if(b < *P.n_pending) keep = P.cand + (size_t)(blockIdx.y - 1) * (P.N + 1) * CAND_W * P.Bp + b;
+        }
+    }
     if(mode == ROLL_SEARCH_LIST) {
         if(b >= *P.n_pending) return;
         b = P.pending[b];
@@ -1516,6 +1545,12 @@ __global__ __launch_bounds__(ROLL_BLOCK) ILQG_ROLLOUT_ATTR void k_rollout(DevPtr
 #pragma unroll
                 for(int i = 0; i < NU; i++) ro[NOM_U + i] = ct.u[i];
             }
+        } else if(KIND == RK_GENERAL && keep) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) keep[(size_t)i * P.Bp] = ct.x[i];
+#pragma unroll
+            for(int i = 0; i < NU; i++) keep[(size_t)(NX + i) * P.Bp] = ct.u[i];
+            keep += (size_t)CAND_W * P.Bp;
         }
         if(!cost_only) {
 #pragma unroll
@@ -1573,6 +1608,9 @@ __global__ __launch_bounds__(ROLL_BLOCK) ILQG_ROLLOUT_ATTR void k_rollout(DevPtr
 #pragma unroll
                 for(int i = 0; i < NX; i++) ro[NOM_X + i] = cf.x[i];
             }
+        } else if(KIND == RK_GENERAL && keep) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) keep[(size_t)i * P.Bp] = cf.x[i];
         }
     }
     // forward_pass returns 0 as soon as a guarded value is NaN or Inf (genenerator_main.mac:193-198)
@@ -1628,6 +1666,27 @@ __global__ void k_select(DevPtrs P, ilqg_dev_opts_t O, int a0, int a1, int from_
     P.f[ILQG_F_NEW_COST][b] = cnew;
     P.f[ILQG_F_DCOST][b] = dcost;
     P.f[ILQG_F_EXPECTED][b] = expected;
+}
+
+// After the second stage's selection: the trajectory of the accepted step size, kept by the lane that rolled it out
+// (ROLL_SECOND), becomes the current one.  One thread per (entry of P.pending, step).  n2 = step sizes of the stage,
+// a0 = its first.
+__global__ void k_adopt(DevPtrs P, int a0, int n2) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = (int)(tid % P.Bp), k = (int)(tid / P.Bp);  // consecutive threads: consecutive entries, one step
+    if(e >= *P.n_pending || k > P.N) return;
+    const int b = P.pending[e];
+    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) return;
+    const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1 - a0;
+    const double *src = P.cand + ((size_t)a * (P.N + 1) + k) * CAND_W * P.Bp + e;
+    double *xo = cur_x(P, k, b);
+#pragma unroll
+    for(int i = 0; i < NX; i++) xo[i * XSI] = src[(size_t)i * P.Bp];
+    if(k < P.N) {
+        double *uo = cur_u(P, k, b);
+#pragma unroll
+        for(int i = 0; i < NU; i++) uo[i * XSI] = src[(size_t)(NX + i) * P.Bp];
+    }
 }
 
 // iLQG.c:311-361 and the loop bookkeeping of iLQG.c:239,365-378
@@ -1962,6 +2021,8 @@ struct ilqg_dev {
     struct PendingRead { void *dst; const void *src; size_t bytes; int transpose_w; };
     std::vector<PendingRead> pending;
     int *counter;
+    size_t cand_bytes;    // size of P.cand
+    bool winner_done;     // the last search ended with the accepted trajectories in place (two-stage search)
     int *queues;          // wave mapping: the backward kernel's trajectory counters (DevPtrs::queue), QUEUE_CELL ints apart
     int cus;              // compute units of the device
     int chunk;            // wave mapping: trajectories whose derivative records fit the work buffer
@@ -2275,15 +2336,17 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
                 if(c < 1) c = 1;
                 if(c > (size_t)d->B) c = d->B;
                 memset(&W, 0, sizeof(W));
-                HIP_TRY(hipMalloc((void **)&W.buf, c * per_traj));
-                W.bytes = c * per_traj;
+                // (+ one record: records may lie closer together than their size, see FACT_STRIDE, and the last one
+                // still reaches sizeof(trajEl_t) beyond its start)
+                HIP_TRY(hipMalloc((void **)&W.buf, c * per_traj + sizeof(trajEl_t)));
+                W.bytes = c * per_traj + sizeof(trajEl_t);
                 HIP_TRY(hipMemsetAsync(W.buf, 0, W.bytes, d->stream));
                 HIP_TRY(hipStreamSynchronize(d->stream));
                 HIP_TRY(hipEventCreateWithFlags(&W.free_ev, hipEventDisableTiming));
             }
             W.refs++;
             d->shared = &W;
-            size_t c = W.bytes / per_traj;
+            size_t c = (W.bytes - sizeof(trajEl_t)) / per_traj;
             if(c < 1) {
                 g_err = "ilqg_dev_create: the device's derivative work buffer (made for a shorter horizon) does not hold one trajectory";
                 return 1;
@@ -2356,6 +2419,7 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     if(d->P.derivs_failed) hipFree(d->P.derivs_failed);
     if(d->counter) hipFree(d->counter);
     if(d->queues) hipFree(d->queues);
+    if(d->P.cand) hipFree(d->P.cand);
     if(d->P.pending) hipFree(d->P.pending);
     if(d->P.n_pending) hipFree(d->P.n_pending);
     for(double *p : d->param_bufs) hipFree(p);
@@ -2866,11 +2930,35 @@ int ilqg_dev_search(ilqg_dev_t *d) {
         Timed t(d, ILQG_K_SELECT, rs);
         hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O, 0, s1, 0);
     }
-    if(s1 < A) {
-        // The grid covers the worst case; blocks beyond the pending count return at once.
+    d->winner_done = false;
+    if(s1 < A && !d->O.ls_keep) {
+        // the grid covers the worst case; blocks beyond the pending count return at once
         launch_rollout(d, ROLL_SEARCH_LIST, ILQG_K_ROLLOUT_SEARCH2, s1, A - s1, rs);
         Timed t(d, ILQG_K_SELECT, rs);
         hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O, s1, A, 1);
+    } else if(s1 < A) {
+        // Second stage and the winner pass of the trajectories the first stage settled in ONE launch (ROLL_SECOND);
+        // the grid covers the worst case, blocks beyond the pending count return at once.
+        const int n2 = A - s1;
+        const size_t need = (size_t)d->Bp * n2 * (d->N + 1) * CAND_W * sizeof(double);
+        if(d->cand_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(rs));
+            if(d->P.cand) HIP_TRY(hipFree(d->P.cand));
+            d->P.cand = nullptr;
+            d->cand_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&d->P.cand, need));
+            d->cand_bytes = need;
+        }
+        launch_rollout(d, ROLL_SECOND, ILQG_K_ROLLOUT_SEARCH2, s1, n2 + 1, rs);
+        {
+            Timed t(d, ILQG_K_SELECT, rs);
+            hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O, s1, A, 1);
+        }
+        {
+            Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
+            hipLaunchKernelGGL(k_adopt, grid1((size_t)d->Bp * (d->N + 1), 256), dim3(256), 0, rs, d->P, s1, n2);
+        }
+        d->winner_done = true;
     }
     HIP_TRY(hipGetLastError());
     return roll_leave(d);
@@ -2879,6 +2967,10 @@ int ilqg_dev_search(ilqg_dev_t *d) {
 int ilqg_dev_winner(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
+    if(d->winner_done) {  // the two-stage search has stored the accepted trajectories already (ROLL_SECOND, k_adopt)
+        d->winner_done = false;
+        return 0;
+    }
     if(roll_enter(d)) return 1;
     launch_rollout(d, ROLL_WINNER, ILQG_K_ROLLOUT_WINNER, 0, 1, roll_stream(d));
     HIP_TRY(hipGetLastError());

@@ -32,6 +32,8 @@ typedef struct {
     int resweep; /* 1: repeat the reference's cost-only sweep after an accepted step (iLQG.c:338) */
     int ls_split; /* step sizes rolled out for every trajectory in the first line-search stage; the rest only
                    * for trajectories still without an acceptable one (0 or >= n_alpha: single stage) */
+    int ls_keep; /* 1: the second stage keeps the trajectories it rolls out and runs side by side with the winner pass
+                  * of the first stage's trajectories; 0: second stage, then one winner pass for all */
     int fuse_derivs; /* 1: ilqg_dev_iterate evaluates derivatives inside the backward kernel (no records in HBM) */
 } ilqg_dev_opts_t;
 

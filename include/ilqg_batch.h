@@ -65,6 +65,10 @@ const char *ilqg_batch_error(const ilqg_batch_t *c);
  *                 the remaining ones only for trajectories that found none acceptable among
  *                 them; 0 = all step sizes for every trajectory.  The accepted step size is the
  *                 same either way (first acceptable, line_search.c:37-60).
+ *   "ls_keep"     default 1: the second stage runs side by side with the roll-out that stores the
+ *                 accepted trajectories of the first stage, and keeps what it rolls out, so that
+ *                 its own accepted trajectories are copied instead of rolled out once more;
+ *                 0: second stage, then one storing roll-out for all.  Same results either way.
  * Defaults = standard_parameters() (iLQG.c:57-78). */
 int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value, int n);
 /* problem parameter by name, shared by all trajectories (iLQG_mex.c:70-84) */

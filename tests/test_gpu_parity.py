@@ -889,6 +889,40 @@ def test_failure_paths_are_per_trajectory_with_uniform_guards(ilqg, fd):
         assert np.array_equal(a[ok], b[ok])
 
 
+@pytest.mark.parametrize("fd", [0, 1])
+def test_chunked_records_with_a_finished_trajectory(ilqg, fd, monkeypatch):
+    """a work buffer that holds a fraction of the batch (records evaluated and consumed chunk by chunk, the chunks
+    taking turns in the two halves of the buffer): same results as with room for everything, also when a
+    trajectory that is out of the race (failed initial roll-out) sits in a slot another one uses later — the constant
+    entries of the records are written for every slot, not only for the active trajectories' (regression)."""
+    import gc
+    B, N, iters = 70, 32, 2
+    x0, u0 = syn_inputs(B, N)
+    u0 = u0.copy()
+    u0[5, 10, 3] = np.nan
+    runs = []
+    for work_gb in (None, 0.012 if fd == 0 else 0.02):
+        gc.collect()  # the device's work buffer goes with its last user and is sized by the next first one
+        if work_gb is None:
+            monkeypatch.delenv("ILQG_WORK_GB", raising=False)
+        else:
+            monkeypatch.setenv("ILQG_WORK_GB", str(work_gb))
+        s = ilqg.BatchSolver("synth16x8", fd, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters + 1))
+        s.timing(True)
+        s.init(x0, u0)
+        s.iterate(iters)
+        l, L = s.gains()
+        launches = s.kernel_times()["k_backward"][0]
+        runs.append((s.ints("status"), s.scalar("cost"), s.x(), s.u(), l, L, launches))
+        s.close()
+    whole, chunked = runs
+    assert whole[0][5] == 7
+    assert whole[6] == iters and chunked[6] > 2 * iters, "the second run was meant to go chunk by chunk"
+    ok = np.ones(B, dtype=bool); ok[5] = False
+    for a, b in zip(whole[:6], chunked[:6]):
+        assert np.array_equal(a[ok], b[ok])
+
+
 # all inside the first 8 iterations, before free-running paths can drift apart (test_lockstep20_teacher_forced)
 @pytest.mark.parametrize("opts", [dict(max_iter=0), dict(max_iter=8, alpha=[1.0], zMin=0.99, lambdaMax=3.0), dict(max_iter=6, lambdaInit=1e9),
                                   dict(max_iter=8, tolFun=0.5), dict(max_iter=8, alpha=[1.0, 0.5]), dict(max_iter=8, zMin=0.6)])
