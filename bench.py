@@ -120,6 +120,13 @@ def cpu_baseline(batch_per_gpu, iters, problem, fd, params, n_hor, make_inputs, 
     }
 
 
+def with_split(opts, args):
+    """the solver options of a run: the library's line-search split unless --ls-split asks for another"""
+    if args.ls_split is not None:
+        opts["ls_split"] = args.ls_split
+    return opts
+
+
 def kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, iters, **opts):
     """{kernel: (launches, total ms)} of `iters` iterations run as ONE group of trajectories: every launch covers the
     whole batch and nothing else is on the GPU while it is timed"""
@@ -209,7 +216,7 @@ def single_process(args, ilqg, synth):
     B = per * G
     x0, u0 = synth.car_batch(B, n_hor)
     m = ilqg.MultiSolver("carparking", 0, batch=B, n_hor=n_hor, devices=list(range(G)), params=ilqg.CAR_PARAMS,
-                         opts=dict(max_iter=max(K, W) + 1, ls_split=args.ls_split))
+                         opts=with_split(dict(max_iter=max(K, W) + 1), args))
     m.init(x0, u0)
     if W > 0:
         m.iterate(W)
@@ -254,7 +261,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resweep", type=int, default=-1, help="-1: library default (off without multipliers)")
     ap.add_argument("--fuse-derivs", type=int, default=1)
-    ap.add_argument("--ls-split", type=int, default=3)
+    ap.add_argument("--ls-split", type=int, default=None, help="default: the library's (3; 1 in the wave mapping)")
     ap.add_argument("--ls-keep", type=int, default=1, help="0: second line-search stage and winner pass one after the other")
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary runs (kernels alone, config 5, drop-in)")
     ap.add_argument("--no-config5", action="store_true")
@@ -292,7 +299,7 @@ def main():
     x0, u0 = synth.car_batch(B, n_hor, first=first) if car else synth.synth16_batch(B, n_hor, first=first)
     params = ilqg.CAR_PARAMS if car else synth.SYNTH16_PARAMS
     s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=n_hor, device=local, params=params,
-                         opts=dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_split=args.ls_split, ls_keep=args.ls_keep),
+                         opts=with_split(dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_keep=args.ls_keep), args),
                          strict=("wave" if args.mapping == "wave" else False), groups=args.groups)
     if args.resweep >= 0:
         s.set_option("resweep", args.resweep)
@@ -371,7 +378,7 @@ def main():
             # the dominant kernel ALONE: one group of trajectories, so a launch covers the whole batch and shares the
             # GPU with nothing (in the timed window above three groups overlap and launch times are inflated)
             iters1 = 8
-            t1 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, iters1, fuse_derivs=1, ls_split=args.ls_split)
+            t1 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, iters1, **with_split(dict(fuse_derivs=1), args))
             name = "k_backward[fused derivs]"
             n_launch, total_ms = t1[name]
             avg_ms = total_ms / n_launch
@@ -405,7 +412,7 @@ def main():
             }
             out["kernels_ms_per_iteration_alone"] = {k: v[1] / iters1 for k, v in t1.items() if v[0]}
             # the HBM-bound kernels of the unfused path, each alone
-            t2 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, 5, fuse_derivs=0, ls_split=args.ls_split)
+            t2 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, 5, **with_split(dict(fuse_derivs=0), args))
             unfused = {}
             for kname in ("k_derivs", "k_backward"):
                 n, ms = t2[kname]

@@ -2244,7 +2244,7 @@ void ilqg_dev_dims(int *out) {
 const char *ilqg_dev_kernel_name(int k) {
     static const char *names[ILQG_K_COUNT] = {"k_derivs", "k_backward", "k_rollout[search]", "k_select",
                                               "k_rollout[winner]", "k_update", "k_rollout[cost]", "k_rollout[init]",
-                                              "layout kernels", "k_backward[fused derivs]", "k_rollout[search stage 2]",
+                                              "layout kernels", "k_backward[fused derivs]", "k_rollout[stage 2 | winner]",
                                               "k_multipliers"};
     return (k >= 0 && k < ILQG_K_COUNT) ? names[k] : "?";
 }
@@ -2331,15 +2331,24 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
                 const char *e = getenv("ILQG_WORK_GB");
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-                const double budget = e ? atof(e) * 1e9 : 0.5 * (double)free_b;
-                size_t c = (size_t)(budget / (double)per_traj);
-                if(c < 1) c = 1;
-                if(c > (size_t)d->B) c = d->B;
+                // Without ILQG_WORK_GB: what the whole batch needs in the record form ilqg_dev_iterate uses, if the device
+                // has it once this context's other arrays (the packed records, the second line-search stage's kept
+                // roll-outs, and a margin) are counted; else what is left then, but at least half of what is free.
+                const double need = (double)d->B * (double)d->N * (double)FACT_STRIDE;
+                const double others = (double)d->Bp * (d->N + 1) * (RN + (ILQG_MAX_ALPHA - 1) * CAND_W) * sizeof(double) + 6e9;
+                double budget = (double)free_b - others;
+                if(budget < 0.5 * (double)free_b) budget = 0.5 * (double)free_b;
+                if(budget > need) budget = need;
+                if(e) budget = atof(e) * 1e9;
+                size_t bytes = (size_t)budget;
+                if(bytes < per_traj) bytes = per_traj;
+                if(bytes > (size_t)d->B * per_traj) bytes = (size_t)d->B * per_traj;
                 memset(&W, 0, sizeof(W));
                 // (+ one record: records may lie closer together than their size, see FACT_STRIDE, and the last one
                 // still reaches sizeof(trajEl_t) beyond its start)
-                HIP_TRY(hipMalloc((void **)&W.buf, c * per_traj + sizeof(trajEl_t)));
-                W.bytes = c * per_traj + sizeof(trajEl_t);
+                bytes += sizeof(trajEl_t);
+                HIP_TRY(hipMalloc((void **)&W.buf, bytes));
+                W.bytes = bytes;
                 HIP_TRY(hipMemsetAsync(W.buf, 0, W.bytes, d->stream));
                 HIP_TRY(hipStreamSynchronize(d->stream));
                 HIP_TRY(hipEventCreateWithFlags(&W.free_ev, hipEventDisableTiming));
@@ -2792,7 +2801,8 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
     // A batch that needs several chunks alternates between the two halves of the work buffer on two streams, so that
     // the derivatives of one chunk are evaluated while the other's backward pass runs and the end of one backward
     // kernel (few wavefronts still busy) is filled by the next.  The pieces are of equal size.
-    const bool split = d->B > chunk && chunk >= 2 && transient;
+    // (a batch that fits as a whole goes in two pieces as well, if it is large enough to fill the chip twice)
+    const bool split = transient && chunk >= 2 && (d->B > chunk || d->B >= 16 * d->cus);
     const int half_cap = split ? chunk / 2 : chunk;              // trajectories a half of the buffer holds
     const int pieces = (d->B + half_cap - 1) / half_cap;
     int part = chunk;

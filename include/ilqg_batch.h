@@ -61,7 +61,8 @@ const char *ilqg_batch_error(const ilqg_batch_t *c);
  *   "fuse_derivs" 0/1: ilqg_batch_iterate/solve evaluate the derivatives inside the backward
  *                 kernel instead of materialising the records in HBM.  Default 1, 0 for problems
  *                 with multipliers (measured faster there); same results either way.
- *   "ls_split"    default 3: step sizes alpha[0..ls_split) are rolled out for every trajectory,
+ *   "ls_split"    default 3 (1 for builds with one wavefront per trajectory): step sizes
+ *                 alpha[0..ls_split) are rolled out for every trajectory,
  *                 the remaining ones only for trajectories that found none acceptable among
  *                 them; 0 = all step sizes for every trajectory.  The accepted step size is the
  *                 same either way (first acceptable, line_search.c:37-60).
