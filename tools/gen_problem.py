@@ -34,6 +34,7 @@ Usage:  python tools/gen_problem.py problems/defs/carparking.py problems/carpark
 import importlib.util
 import itertools
 import os
+import re
 import sys
 
 import sympy as sp
@@ -440,14 +441,30 @@ class Emitter:
                     % (pad, v, v.replace('"', ""), v, ret))
         return out
 
-    def block(self, items, want_time_var, ind=4, cse=None):
+    def block(self, items, want_time_var, ind=4, cse=None, pair=False):
         """items: list of (lhs, expr). emit those whose time-variance matches; cse: a SharedTerms that names
-        the products the entries have in common"""
-        out = ""
-        for lhs, e in items:
-            if want_time_var is None or self.is_time_var(e) == want_time_var:
-                out += self.assign(lhs, cse.rewrite(e) if cse else e, ind)
+        the products the entries have in common.  pair: two neighbouring array entries are assigned first and
+        guarded afterwards (same values, same guards; a back-end that writes the records to device memory gets one
+        16-byte store instead of two of 8 bytes)"""
+        todo = [(lhs, cse.rewrite(e) if cse else e) for lhs, e in items
+                if want_time_var is None or self.is_time_var(e) == want_time_var]
+        out, i = "", 0
+        while i < len(todo):
+            if pair and i + 1 < len(todo) and self._neighbours(todo[i][0], todo[i + 1][0]):
+                a, b = self.assign(todo[i][0], todo[i][1], ind).split("\n")[:-1], self.assign(todo[i + 1][0], todo[i + 1][1], ind).split("\n")[:-1]
+                # (each is the assignment, then its guard unless the value is a plain number)
+                guards = [g.replace("__LINE__-1", "__LINE__-2") for g in a[1:] + b[1:]]
+                out += "\n".join([a[0], b[0]] + guards) + "\n"
+                i += 2
+            else:
+                out += self.assign(todo[i][0], todo[i][1], ind)
+                i += 1
         return out
+
+    @staticmethod
+    def _neighbours(l1, l2):
+        m1, m2 = re.fullmatch(r"(.*)\[(\d+)\]", l1), re.fullmatch(r"(.*)\[(\d+)\]", l2)
+        return bool(m1 and m2 and m1.group(1) == m2.group(1) and int(m2.group(2)) == int(m1.group(2)) + 1)
 
     def jaco_items(self, name, mat):
         nr, nc = len(mat), len(mat[0])
@@ -795,12 +812,13 @@ int calc_derivs(tOptSet *o) {
         out = "static int bp_derivsL(trajEl_t *t, int k, double **p) {\n    const double *const x= t->x;\n    const double *const u= t->u;\n\n"
         if cse:
             cse.use("first")
-        first = (self.block(self.jaco_items("fx", self.fx), True, cse=cse) + "\n" +
-                 self.block(self.jaco_items("fu", self.fu), True, cse=cse) + "\n")
+        pair = bool(self.tensor_tables)  # the function batched back-ends call per step (bp_derivsL_first)
+        first = (self.block(self.jaco_items("fx", self.fx), True, cse=cse, pair=pair) + "\n" +
+                 self.block(self.jaco_items("fu", self.fu), True, cse=cse, pair=pair) + "\n")
         cost = ""
         for items in (self.grad_items("cx", self.Lx), self.hess_items("cxx", self.Lxx), self.grad_items("cu", self.Lu),
                       self.hess_items("cuu", self.Luu), self.hess_items("cxu", self.Lxu)):
-            cost += self.block(items, True, cse=cse) + "\n"
+            cost += self.block(items, True, cse=cse, pair=pair) + "\n"
         cse2 = cse
         if self.tensor_tables:
             cse2 = SharedTerms(self, "ct")  # a function of its own (bp_derivsL_second): its own names
@@ -1034,8 +1052,7 @@ def _emit_factored_tensors(self):
            " * and bp_tensor_basis() evaluates the ILQG_TENSOR_NBASIS products of one step exactly as bp_derivsL does. */\n"
            "static int bp_tensor_basis(double *basis, trajEl_t *t, int k, double **p) {\n"
            "    const double *const x= t->x;\n    const double *const u= t->u;\n\n")
-    for i, prod in enumerate(T["basis"]):
-        out += self.assign("basis[%d]" % i, prod)
+    out += self.block([("basis[%d]" % i, prod) for i, prod in enumerate(T["basis"])], None, pair=True)
     out += "    return 1;\n}\n\n"
     for nm in ("xx", "uu", "xu"):
         coef, slices = T[nm]
