@@ -46,18 +46,18 @@ def main():
     if traffic_json:
         import json
         # per bench label: mean over ALL launches of that kernel (the batch runs as several groups of trajectories, so
-        # grids differ slightly).  The general roll-out kernel is launched three ways, told apart by their grids: the
-        # winner pass has one lane per trajectory of the group (grid = Bp), the first search stage ls_split (3) lanes
-        # per trajectory (grid = 3 Bp), the second stage n_alpha - ls_split (5) lanes for the WORST case (grid = 5 Bp,
-        # most of its blocks return at once).
+        # grids differ slightly).  The general roll-out kernel is launched two ways, told apart by their grids: the
+        # first search stage has ls_split (3) lanes per trajectory of the group (grid = 3 Bp); the second launch is the
+        # winner pass of the trajectories that stage settled (Bp lanes) side by side with the second stage, n_alpha -
+        # ls_split (5) lanes per trajectory for the WORST case (most of those blocks return at once): grid = 6 Bp.
         ls_split, n_alpha = 3, 8
         grids = sorted({int(g) for (k, g) in acc if k == "void k_rollout<0>" and g})
-        bases = [b for b in grids if b * ls_split in grids and b * (n_alpha - ls_split) in grids]
+        second = n_alpha - ls_split + 1
+        bases = [g // ls_split for g in grids if g % ls_split == 0 and (g // ls_split) * second in grids]
         roll_label = {}
         for b in bases:
-            roll_label[b] = "k_rollout[winner]"
             roll_label[b * ls_split] = "k_rollout[search]"
-            roll_label[b * (n_alpha - ls_split)] = "k_rollout[search stage 2]"
+            roll_label[b * second] = "k_rollout[stage 2 | winner]"
         per_label = collections.defaultdict(lambda: collections.defaultdict(list))
         for (k, g), cs in acc.items():
             label = KERNEL_LABELS.get(k)
