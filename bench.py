@@ -359,7 +359,7 @@ def main():
                        "batch_per_gpu": B, "n_hor": n_hor, "n_x": nx, "n_u": nu, "full_ddp": fd,
                        "mapping": ("one wavefront per trajectory" if wave_mapping else
                                    "one lane per trajectory (64 trajectories per wavefront)"),
-                       "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split, "ls_keep": args.ls_keep, "resweep": args.resweep,
+                       "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split if args.ls_split is not None else "library default (3; 1 in the wave mapping)", "ls_keep": args.ls_keep, "resweep": args.resweep,
                        "stream_groups": stream_groups,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             # PRIMARY: the whole iteration against the HBM roofline, algorithmic bytes of SURVEY 8(d)

@@ -1672,20 +1672,22 @@ __global__ void k_select(DevPtrs P, ilqg_dev_opts_t O, int a0, int a1, int from_
 // (ROLL_SECOND), becomes the current one.  One thread per (entry of P.pending, step).  n2 = step sizes of the stage,
 // a0 = its first.
 __global__ void k_adopt(DevPtrs P, int a0, int n2) {
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = (int)(tid % P.Bp), k = (int)(tid / P.Bp);  // consecutive threads: consecutive entries, one step
-    if(e >= *P.n_pending || k > P.N) return;
-    const int b = P.pending[e];
-    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) return;
-    const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1 - a0;
-    const double *src = P.cand + ((size_t)a * (P.N + 1) + k) * CAND_W * P.Bp + e;
-    double *xo = cur_x(P, k, b);
+    const size_t n = (size_t)*P.n_pending, total = n * (P.N + 1), stride = (size_t)gridDim.x * blockDim.x;
+    // a fixed grid walks over (step, entry), entry fastest: consecutive threads read consecutive entries of one row
+    for(size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
+        const int e = (int)(w % n), k = (int)(w / n);
+        const int b = P.pending[e];
+        if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) continue;
+        const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1 - a0;
+        const double *src = P.cand + ((size_t)a * (P.N + 1) + k) * CAND_W * P.Bp + e;
+        double *xo = cur_x(P, k, b);
 #pragma unroll
-    for(int i = 0; i < NX; i++) xo[i * XSI] = src[(size_t)i * P.Bp];
-    if(k < P.N) {
-        double *uo = cur_u(P, k, b);
+        for(int i = 0; i < NX; i++) xo[i * XSI] = src[(size_t)i * P.Bp];
+        if(k < P.N) {
+            double *uo = cur_u(P, k, b);
 #pragma unroll
-        for(int i = 0; i < NU; i++) uo[i * XSI] = src[(size_t)(NX + i) * P.Bp];
+            for(int i = 0; i < NU; i++) uo[i * XSI] = src[(size_t)(NX + i) * P.Bp];
+        }
     }
 }
 
@@ -2966,7 +2968,7 @@ int ilqg_dev_search(ilqg_dev_t *d) {
         }
         {
             Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
-            hipLaunchKernelGGL(k_adopt, grid1((size_t)d->Bp * (d->N + 1), 256), dim3(256), 0, rs, d->P, s1, n2);
+            hipLaunchKernelGGL(k_adopt, dim3(8 * d->cus), dim3(256), 0, rs, d->P, s1, n2);
         }
         d->winner_done = true;
     }
