@@ -1659,8 +1659,17 @@ __global__ void k_select(DevPtrs P, ilqg_dev_opts_t O, int a0, int a1, int from_
         if(z > O.zMin) break;
         ok = 0;
     }
-    // to the second stage.  (Appending in trajectory order instead of atomic order was measured: no gain.)
-    if(!ok && a1 < O.n_alpha) P.pending[atomicAdd(P.n_pending_next, 1)] = b;
+    // To the second stage: one atomicAdd per wavefront, its trajectories in order behind each other (the entries of
+    // one wavefront are trajectories of one 64-trajectory tile: what k_adopt copies for them lands in the same rows of
+    // X and U).  No measurable gain over one atomicAdd per trajectory; kept for the 64x fewer atomics.
+    if(!ok && a1 < O.n_alpha) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(true);  // the lanes in here
+        const int rank = __builtin_popcountll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+        int base = 0;
+        if(rank == 0) base = atomicAdd(P.n_pending_next, __builtin_popcountll(m));
+        base = __builtin_amdgcn_readfirstlane(base);  // the first lane in here is the one of rank 0
+        P.pending[base + rank] = b;
+    }
     P.i[ILQG_I_ALPHA_IDX][b] = i + 1;
     P.i[ILQG_I_ACCEPTED][b] = ok;
     P.f[ILQG_F_NEW_COST][b] = cnew;
