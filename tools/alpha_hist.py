@@ -1,8 +1,8 @@
 """Which step size each trajectory accepts, per iteration (decides how the line search should be staged).
-python tools/scratch/alpha_hist.py [carparking|synth16x8]"""
+python tools/alpha_hist.py [carparking|synth16x8]"""
 import sys, os, importlib
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("ddp-generator_amd")
 name = sys.argv[1] if len(sys.argv) > 1 else "carparking"
 if name == "carparking":

@@ -30,3 +30,24 @@ done
 cd $R
 python3 tools/pmc_summary.py $OUT/traffic_synth/FETCH_SIZE $OUT/traffic_synth/WRITE_SIZE > $OUT/traffic_synth.txt 2>&1
 grep -A3 "k_backward_wave\|k_derivs_wave" $OUT/traffic_synth.txt | head -40
+echo "== timelines (kernel trace with time stamps)"
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_car -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-unfused > $OUT/trace_car.log 2>&1 || echo "trace (car) failed"
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_synth -- python3 $R/bench.py --workload synth --steps 3 --warmup 1 --no-cpu-baseline --no-unfused > $OUT/trace_synth.log 2>&1 || echo "trace (synth) failed"
+cd $R
+python3 tools/timeline.py $OUT/trace_car --last 16 --min 0.05 > $OUT/timeline_car.txt
+python3 tools/timeline.py $OUT/trace_synth --last 850 --min 0.3 > $OUT/timeline_config5.txt
+tail -25 $OUT/timeline_config5.txt
+echo "== SQ counters, config 5"
+cd /tmp
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
+  n=$(echo $c | cut -d" " -f1)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/sq_synth/$n -- python3 $R/bench.py --workload synth --steps 1 --warmup 0 --no-cpu-baseline --no-unfused > $OUT/sq_synth_$n.log 2>&1 || echo "sq $n failed"
+done
+cd $R
+python3 tools/pmc_kernels.py $OUT/sq_synth > $OUT/pmc_config5_sq.txt
+cat $OUT/pmc_config5_sq.txt | cut -c1-400
+echo "== accepted step sizes"
+python3 tools/alpha_hist.py carparking > $OUT/alpha_hist_car.txt 2>&1
+python3 tools/alpha_hist.py synth16x8 > $OUT/alpha_hist_synth.txt 2>&1
+tail -1 $OUT/alpha_hist_car.txt; tail -2 $OUT/alpha_hist_synth.txt
