@@ -49,6 +49,10 @@ ilqg_batch_t *ilqg_batch_create(int device, int batch, int n_hor); /* NULL on fa
  * not depend on it.  groups = 0 (what ilqg_batch_create passes): ILQG_GROUPS from the environment, else 3 for
  * batches >= 8192 in the one-lane-per-trajectory mapping (measured best at 65 536 trajectories), else 1.  At most 4. */
 ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int groups);
+/* Builds with one wavefront per trajectory (N_X > 8) keep the derivative records of the trajectories in flight in ONE
+ * work buffer per device, shared by all batches on it, allocated by the first and released with the last: sized to hold
+ * the first batch in the record form ilqg_batch_iterate uses if the device has the memory, else what is free after
+ * that batch's other arrays (at least half of what is free).  ILQG_WORK_GB in the environment sets its size. */
 int ilqg_batch_groups(const ilqg_batch_t *c);
 void ilqg_batch_destroy(ilqg_batch_t *c);
 const char *ilqg_batch_error(const ilqg_batch_t *c);
