@@ -2002,7 +2002,7 @@ struct SharedWork {
     int refs;
     // which constant record entries (init_running) the buffer holds: for whom, and where
     bool whole, half[2], factored, pv_set;
-    int N, part, half_cap;
+    int N, B, part, half_cap;
     ParamValues pv;
 };
 static SharedWork g_work[64];
@@ -2824,13 +2824,14 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
     // which constant entries (init_running) the buffer already holds for this context
     bool *whole = &d->work_consts, *half = d->half_consts;
     if(transient) {
-        const bool same = W->pv_set && W->N == d->N && W->part == part && W->half_cap == half_cap && W->factored == fact &&
-                          !d->per_step_params && memcmp(&W->pv, &d->pv, sizeof(ParamValues)) == 0;
+        const bool same = W->pv_set && W->N == d->N && W->B == d->B && W->part == part && W->half_cap == half_cap &&
+                          W->factored == fact && !d->per_step_params && memcmp(&W->pv, &d->pv, sizeof(ParamValues)) == 0;
         if(!same) {
             W->whole = W->half[0] = W->half[1] = false;
             W->pv = d->pv;
             W->pv_set = !d->per_step_params;
             W->N = d->N;
+            W->B = d->B;
             W->part = part;
             W->half_cap = half_cap;
             W->factored = fact;
@@ -2877,6 +2878,10 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
                                    (size_t)WAVE_LDS_DOUBLES * sizeof(double), st, P, d->O, single_sweep, c0, cnt);
             }
         }
+    }
+    if(do_derivs) {  // every slot a batch of this size and division uses has been visited
+        if(split) half[0] = half[1] = true;
+        else *whole = half[0] = half[1] = true;
     }
     if(split) {
         HIP_TRY(hipEventRecord(d->join, d->stream2));
