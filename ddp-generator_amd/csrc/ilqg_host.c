@@ -52,7 +52,7 @@ struct ilqg_batch {
     int device, B, N;
     tOptSet opt;                     /* option holder, filled through setOptParam() */
     double alpha_store[ILQG_MAX_ALPHA];
-    int resweep, fuse_derivs, ls_split, ls_keep;
+    int resweep, fuse_derivs, ls_split, ls_keep, bw_split;
     double **p;                      /* owned copies of the problem parameters */
     char *p_given;                   /* which of them the caller has set */
     int params_pushed;
@@ -255,6 +255,10 @@ ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int gro
      * (65 536 Brachistochrone solves 0.137 s with stored records, 0.156 s fused) */
     c->fuse_derivs = c->resweep ? 0 : 1;
     c->ls_keep = 1;
+    /* measured: no gain (the fused backward kernel alone 2.65 ms on one wavefront per tile, 2.73 ms on two; headline
+     * 135.6 against 130-133 it/s) — the Riccati update with its box QP is the chain that bounds a step, the derivative
+     * evaluation already hides behind it in one instruction stream */
+    c->bw_split = 0;
     standard_parameters(&c->opt);
     ilqg_dev_dims(dims);
     /* first line-search stage: 3 step sizes in the lane mapping (CarParking accepts 85 % of the steps there); 1 in
@@ -361,6 +365,11 @@ int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value
         c->ls_split = (int)value[0];
         return 0;
     }
+    if(strcmp(name, "bw_split") == 0) {
+        if(n != 1) return fail_msg(c, err_scalar);
+        c->bw_split = value[0] != 0.0;
+        return 0;
+    }
     if(strcmp(name, "ls_keep") == 0) {
         if(n != 1) return fail_msg(c, err_scalar);
         c->ls_keep = value[0] != 0.0;
@@ -423,6 +432,7 @@ static int push_config(ilqg_batch_t *c) {
     d.fuse_derivs = c->fuse_derivs;
     d.ls_split = c->ls_split;
     d.ls_keep = c->ls_keep;
+    d.bw_split = c->bw_split;
     { int g; EACH_GROUP(g) if(ilqg_dev_set_opts(c->dev[g], &d)) return fail(c, "options"); }
     if(!c->params_pushed) {
         int sizes[64];

@@ -937,6 +937,247 @@ __global__ __launch_bounds__(WAVE, 1) void k_backward(DevPtrs P, ilqg_dev_opts_t
     P.i[ILQG_I_BP_RC][b] = rc;
 }
 
+// ---------------------------------------------------------------------------
+// Mode 2 on TWO wavefronts per tile of 64 trajectories ("split"; problems whose header lists the entries bp_derivsL
+// writes, no multipliers, constant limits).  65 536 trajectories are one wavefront per SIMD, and that wavefront's step is
+// a chain of ~1 265 dependent-ish instructions: the derivative evaluation of step k-1 and the Riccati update of step k
+// are independent, and the software pipeline of backward_sweep_fused only lets the scheduler interleave them.  Here the
+// PRODUCER wavefront evaluates the record of step k-1 (same generated callbacks, same arithmetic) while the CONSUMER
+// wavefront of the same workgroup — on another SIMD of the CU — does step k; the time-varying entries of a record
+// (ILQG_TIME_VARYING: 14 of 55 doubles for CarParking), x_k, u_k and a failure flag cross over in LDS, two slots, one
+// s_barrier per step.  The consumer fills the constant entries from init_running() as before, so what the optimiser
+// folds stays folded.  Control flow is the consumer's: it publishes "some lane still sweeps" / "another sweep" and both
+// wavefronts leave their loops together.  Results, memory effects and failure behaviour are those of mode 2.
+// MEASURED: no gain — 2.73 ms alone against 2.65 ms for k_backward<2>, headline 130-133 against 135.6 it/s: what bounds
+// a step is the chain of dependent operations of the Riccati update with its box QP (~5.3 us), behind which the
+// derivative evaluation already hides in ONE instruction stream.  Off by default (option bw_split), kept with its test.
+// ---------------------------------------------------------------------------
+#if defined(ILQG_TIME_VARYING) && !ILQG_STATE_DEPENDENT_LIMITS
+#define ILQG_HAVE_SPLIT 1
+#define ILQG_COUNT_ENTRY(member, index) +1
+constexpr int SPLIT_VARY = 0 ILQG_TIME_VARYING(ILQG_COUNT_ENTRY) ILQG_TIME_VARYING_FULL(ILQG_COUNT_ENTRY);
+constexpr int SPLIT_SLOT = SPLIT_VARY + NX + NU + 1;  // + x_k, u_k, failure flag
+
+__global__ __launch_bounds__(2 * WAVE) void k_backward_split(DevPtrs P, ilqg_dev_opts_t O, ParamValues A) {
+    __shared__ double ring[2][SPLIT_SLOT][WAVE];
+    // the consumer's word: [k & 1] "some lane goes on after step k" (two cells: the producer reads the one of step k+1
+    // while the consumer may already write the one of step k), [2] "some lane needs another sweep"
+    __shared__ int ctl[3];
+    const int role = threadIdx.x >> 6, lane = threadIdx.x & 63;  // 0 consumer, 1 producer
+    const int b = blockIdx.x * WAVE + lane;
+    const int N = P.N;
+    const bool mine = b < P.B && P.i[ILQG_I_STATUS][b] == ILQG_ST_ACTIVE;
+    if(__builtin_amdgcn_ballot_w64(mine) == 0ull) return;  // the same for both wavefronts: they hold the same trajectories
+    ILQG_CALLBACKS(C, H);
+    const size_t xs = cur_xstride(P), us = cur_ustride(P);
+
+    if(role == 1) {
+        // ---------------- producer: records of steps N-1, N-2, ..., 0 of every sweep ----------------
+        trajEl_t t;
+        init_running(&t, &C.o1);
+        for(;;) {  // sweeps
+            H.nonfinite = 0.0;
+            const double *xp = cur_x(P, N - 1, b), *up = cur_u(P, N - 1, b);
+            double xn[NX], un[NU];
+#pragma unroll
+            for(int i = 0; i < NX; i++) xn[i] = xp[i * XSI];
+#pragma unroll
+            for(int i = 0; i < NU; i++) un[i] = up[i * XSI];
+            for(int k = N - 1; k >= 0; k--) {
+                // (x, u) of the step after this one, in flight while this record is evaluated
+                double xnn[NX], unn[NU];
+                const int back = (k > 0) ? 1 : 0;
+#pragma unroll
+                for(int i = 0; i < NX; i++) xnn[i] = (xp - back * xs)[i * XSI];
+#pragma unroll
+                for(int i = 0; i < NU; i++) unn[i] = (up - back * us)[i * XSI];
+#pragma unroll
+                for(int i = 0; i < NX; i++) t.x[i] = xn[i];
+#pragma unroll
+                for(int i = 0; i < NU; i++) t.u[i] = un[i];
+                const int ok = derivs_step(t, nullptr, C, H, k, N, [] {});
+                double(*slot)[WAVE] = ring[k & 1];
+                int j = 0;
+#define ILQG_PUT_ENTRY(member, index) slot[j++][lane] = t.member[index];
+                ILQG_TIME_VARYING(ILQG_PUT_ENTRY) ILQG_TIME_VARYING_FULL(ILQG_PUT_ENTRY)
+#undef ILQG_PUT_ENTRY
+#pragma unroll
+                for(int i = 0; i < NX; i++) slot[SPLIT_VARY + i][lane] = xn[i];
+#pragma unroll
+                for(int i = 0; i < NU; i++) slot[SPLIT_VARY + NX + i][lane] = un[i];
+                slot[SPLIT_VARY + NX + NU][lane] = (!ok || H.nonfinite != 0.0) ? 1.0 : 0.0;
+                __syncthreads();  // record k is there; the consumer is done with record k+1 (whose slot is written next)
+                // The consumer's word on step k+1.  If every lane left there, the consumer has matched the barrier
+                // above with one of its own and is on its way to the end of the sweep.
+                if(k < N - 1 && !ctl[(k + 1) & 1]) break;
+                xp -= back * xs;
+                up -= back * us;
+#pragma unroll
+                for(int i = 0; i < NX; i++) xn[i] = xnn[i];
+#pragma unroll
+                for(int i = 0; i < NU; i++) un[i] = unn[i];
+            }
+            // the consumer's last step (0, or the one every lane left at) and its decision about another sweep
+            __syncthreads();
+            if(!ctl[2]) break;
+        }
+        return;
+    }
+
+    // ---------------- consumer: back_pass + retry loop of k_backward<2>, records from the ring ----------------
+    load_penalty_weights_der(C, P, b);
+    if(mine) P.i[ILQG_I_NEED_DERIVS][b] = 0;
+    // iLQG.c:247-249.  (The status is written at the end: the producer reads it when it starts.)
+    const bool dead = mine && P.derivs_failed[b];
+    bool sweeping = mine && !dead;  // this lane wants (another) sweep
+    double lambda = mine ? P.f[ILQG_F_LAMBDA][b] : 1.0, dlambda = mine ? P.f[ILQG_F_DLAMBDA][b] : 1.0;
+    double dV0 = 0.0, dV1 = 0.0, g_norm = mine ? P.f[ILQG_F_GNORM][b] : 0.0;
+    int calls = 0, rc = 0;
+    const bool took_part = sweeping;
+    trajEl_t t;
+    init_running(&t, &C.o1);
+    for(;;) {  // sweeps of the tile: the lanes that want one take part, the others idle through it
+        bool in_sweep = sweeping;
+        int result = 0;
+        double Vx[NX], Vxx[SXX], l[NU], K[NXU], gsum = 0.0;
+        H.nonfinite = 0.0;
+        if(in_sweep) {
+            const double *xp = cur_x(P, N, b);
+            trajFin_t fin;
+            init_final(&fin, &C.o);
+#pragma unroll
+            for(int i = 0; i < NX; i++) fin.x[i] = xp[i * XSI];
+            double *recN = nomp(P, N, b);
+#pragma unroll
+            for(int i = 0; i < NX; i++) recN[NOM_X + i] = fin.x[i];
+            const int ok = derivs_final(fin, nullptr, C, H, N);
+            if(!ok || H.nonfinite != 0.0) {
+                result = 2;
+                in_sweep = false;
+            }
+#pragma unroll
+            for(int i = 0; i < NX; i++) Vx[i] = fin.cx[i];
+#pragma unroll
+            for(int i = 0; i < SXX; i++) Vxx[i] = fin.cxx[i];
+        }
+#pragma unroll
+        for(int i = 0; i < NU; i++) l[i] = 0.0;
+        if(sweeping) {  // (a lane that is done keeps the results of ITS last sweep)
+            dV0 = 0.0;
+            dV1 = 0.0;
+        }
+        double *rec_k = nomp(P, N - 1, b);
+        // gains of the step before (k+1), stored once the record of step k is known to be good — the order of
+        // backward_sweep_fused: a failed record of step k ends the sweep before the gains of step k+1 are stored
+        double lp[NU], Kp[NXU], xkp[NX], ukp[NU];
+        int rcp = 1;
+        bool pending = false;
+        auto commit = [&]() {  // what backward_sweep_fused does behind record_of(k-1) for step k
+            store_gains(lp, Kp, rec_k + NOM_L, rec_k + NOM_K);
+#pragma unroll
+            for(int i = 0; i < NX; i++) rec_k[NOM_X + i] = xkp[i];
+#pragma unroll
+            for(int i = 0; i < NU; i++) rec_k[NOM_U + i] = ukp[i];
+            rec_k -= RN;
+            pending = false;
+            if(rcp < 1) {
+                result = 1;
+                in_sweep = false;
+            }
+        };
+        for(int k = N - 1; k >= 0; k--) {
+            __syncthreads();  // record k is in its slot
+            if(in_sweep) {
+                double(*slot)[WAVE] = ring[k & 1];
+                if(slot[SPLIT_VARY + NX + NU][lane] != 0.0) {  // the record of step k failed
+                    result = 2;
+                    in_sweep = false;
+                } else {
+                    if(pending) commit();  // step k+1
+                    if(in_sweep) {
+                        int j = 0;
+#define ILQG_GET_ENTRY(member, index) t.member[index] = slot[j++][lane];
+                        ILQG_TIME_VARYING(ILQG_GET_ENTRY) ILQG_TIME_VARYING_FULL(ILQG_GET_ENTRY)
+#undef ILQG_GET_ENTRY
+                        double xk[NX], uk[NU];
+#pragma unroll
+                        for(int i = 0; i < NX; i++) xk[i] = slot[SPLIT_VARY + i][lane];
+#pragma unroll
+                        for(int i = 0; i < NU; i++) uk[i] = slot[SPLIT_VARY + NX + i][lane];
+#pragma unroll
+                        for(int i = 0; i < NX; i++) t.x[i] = xk[i];
+#pragma unroll
+                        for(int i = 0; i < NU; i++) t.u[i] = uk[i];
+                        limitsU(&t, k, C.o.p, N);  // constant limits: parameters only
+                        double cur[REC];
+#define GETF(off, arr, cnt) _Pragma("unroll") for(int i = 0; i < (cnt); i++) cur[(off) + i] = (arr)[i];
+                        REC_COPY(GETF, t)
+#undef GETF
+                        rcp = back_step<NX, NU, FULL, HX>(cur, uk, Vx, Vxx, l, K, lambda, O.regType, dV0, dV1, gsum, nullptr);
+#pragma unroll
+                        for(int i = 0; i < NU; i++) lp[i] = l[i];
+#pragma unroll
+                        for(int i = 0; i < NXU; i++) Kp[i] = K[i];
+#pragma unroll
+                        for(int i = 0; i < NX; i++) xkp[i] = xk[i];
+#pragma unroll
+                        for(int i = 0; i < NU; i++) ukp[i] = uk[i];
+                        pending = true;
+                    }
+                }
+            }
+            const bool more = __builtin_amdgcn_ballot_w64(in_sweep) != 0ull;
+            if(lane == 0) ctl[k & 1] = more ? 1 : 0;
+            if(!more) {
+                if(k > 0) __syncthreads();  // the producer is on its way to this barrier with record k-1: meet it there
+                break;
+            }
+        }
+        if(in_sweep && pending) commit();  // step 0 (its record was checked when it arrived)
+        if(sweeping) {
+            rc = result;
+            if(!result) g_norm = gsum / ((double)(N - 1));
+            calls++;
+            // raise the regularisation and retry (iLQG.c:271-274)
+            sweeping = false;
+            if(rc == 1) {
+                const double t1 = dlambda * O.lambdaFactor;
+                dlambda = (t1 > O.lambdaFactor) ? t1 : O.lambdaFactor;
+                const double t2 = lambda * dlambda;
+                lambda = (t2 > O.lambdaMin) ? t2 : O.lambdaMin;
+                sweeping = !(lambda > O.lambdaMax);
+            }
+        }
+        const bool again = __builtin_amdgcn_ballot_w64(sweeping) != 0ull;
+        if(lane == 0) ctl[2] = again ? 1 : 0;
+        __syncthreads();
+        if(!again) break;
+    }
+    if(dead) P.i[ILQG_I_STATUS][b] = ILQG_ST_DERIVS_FAILED;
+    if(took_part) {
+        if(rc == 2) {
+            P.i[ILQG_I_STATUS][b] = ILQG_ST_DERIVS_FAILED;
+        } else if(rc) {
+            P.i[ILQG_I_STATUS][b] = ILQG_ST_NO_DESCENT;
+        } else if(g_norm < O.tolGrad && lambda < 1e-5) {  // iLQG.c:297-303
+            const double t1 = dlambda / O.lambdaFactor, t2 = 1.0 / O.lambdaFactor;
+            dlambda = (t1 < t2) ? t1 : t2;
+            lambda = lambda * dlambda * (lambda > O.lambdaMin);
+            P.i[ILQG_I_STATUS][b] = ILQG_ST_CONVERGED_GRAD;
+        }
+        P.f[ILQG_F_LAMBDA][b] = lambda;
+        P.f[ILQG_F_DLAMBDA][b] = dlambda;
+        P.f[ILQG_F_DV0][b] = dV0;
+        P.f[ILQG_F_DV1][b] = dV1;
+        P.f[ILQG_F_GNORM][b] = g_norm;
+        P.i[ILQG_I_BP_CALLS][b] = calls;
+        P.i[ILQG_I_BP_RC][b] = rc;
+    }
+}
+#else
+#define ILQG_HAVE_SPLIT 0
+#endif
+
 // After a backward pass over stored records (modes 0 and 1): the line search's packed records from the tiled
 // X, U, l, L.  One wavefront per (tile of 64 trajectories, time step): the tile's RN values per trajectory are read
 // as coalesced rows (lane = trajectory), turned through LDS, and written as whole records (16 consecutive lanes =
@@ -2927,6 +3168,10 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
             hipLaunchKernelGGL(k_backward<0>, grid, block, 0, d->stream, d->P, d->O, d->pv);
         else if(mode == 1)
             hipLaunchKernelGGL(k_backward<1>, grid, block, 0, d->stream, d->P, d->O, d->pv);
+#if ILQG_HAVE_SPLIT
+        else if(d->O.bw_split && !HAS_MUL)
+            hipLaunchKernelGGL(k_backward_split, grid, dim3(2 * WAVE), 0, d->stream, d->P, d->O, d->pv);
+#endif
         else
             hipLaunchKernelGGL(k_backward<2>, grid, block, 0, d->stream, d->P, d->O, d->pv);
     }

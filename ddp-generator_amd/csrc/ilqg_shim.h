@@ -34,6 +34,8 @@ typedef struct {
                    * for trajectories still without an acceptable one (0 or >= n_alpha: single stage) */
     int ls_keep; /* 1: the second stage keeps the trajectories it rolls out and runs side by side with the winner pass
                   * of the first stage's trajectories; 0: second stage, then one winner pass for all */
+    int bw_split; /* 1: the fused backward pass runs on two wavefronts per 64 trajectories (derivatives of step k-1 on
+                   * one, Riccati update of step k on the other) where the problem allows it; 0: on one */
     int fuse_derivs; /* 1: ilqg_dev_iterate evaluates derivatives inside the backward kernel (no records in HBM) */
 } ilqg_dev_opts_t;
 

@@ -74,6 +74,10 @@ const char *ilqg_batch_error(const ilqg_batch_t *c);
  *                 accepted trajectories of the first stage, and keeps what it rolls out, so that
  *                 its own accepted trajectories are copied instead of rolled out once more;
  *                 0: second stage, then one storing roll-out for all.  Same results either way.
+ *   "bw_split"    default 0.  1: the fused backward pass runs on two wavefronts per 64 trajectories
+ *                 (derivatives of step k-1 on one, Riccati update of step k on the other, hand-over in
+ *                 LDS) where the problem allows it (no multipliers, constant limits).  Same results;
+ *                 measured no faster.
  * Defaults = standard_parameters() (iLQG.c:57-78). */
 int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value, int n);
 /* problem parameter by name, shared by all trajectories (iLQG_mex.c:70-84) */

@@ -25,6 +25,13 @@
 #define ILQG_STATE_DEPENDENT_LIMITS 0
 #define ILQG_TENSOR_NBASIS 0  /* > 0: iLQG_func.c has the factored tensor tables */
 #define ILQG_TENSOR_INIT_WRITES 1  /* init_running() writes constant entries of fxx / fuu / fxu */
+/* the derivative entries bp_derivsL() writes, X(member, index) each: all others are written once, by init_running() */
+#define ILQG_TIME_VARYING(X) X(cx, 0) X(cxx, 0) X(cu, 0) X(cuu, 0) X(cxu, 0)
+#if FULL_DDP
+#define ILQG_TIME_VARYING_FULL(X) 
+#else
+#define ILQG_TIME_VARYING_FULL(X)
+#endif
 
 typedef struct {
     double x[N_X];

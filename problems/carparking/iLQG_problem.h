@@ -25,6 +25,13 @@
 #define ILQG_STATE_DEPENDENT_LIMITS 0
 #define ILQG_TENSOR_NBASIS 0  /* > 0: iLQG_func.c has the factored tensor tables */
 #define ILQG_TENSOR_INIT_WRITES 1  /* init_running() writes constant entries of fxx / fuu / fxu */
+/* the derivative entries bp_derivsL() writes, X(member, index) each: all others are written once, by init_running() */
+#define ILQG_TIME_VARYING(X) X(fx, 8) X(fx, 9) X(fx, 12) X(fx, 13) X(fx, 14) X(fu, 0) X(fu, 1) X(fu, 2) X(cx, 0) X(cx, 1) X(cxx, 0) X(cxx, 2) X(cu, 0) X(cu, 1)
+#if FULL_DDP
+#define ILQG_TIME_VARYING_FULL(X) X(fxx, 5) X(fxx, 8) X(fxx, 9) X(fxx, 15) X(fxx, 18) X(fxx, 19) X(fxx, 29) X(fuu, 0) X(fuu, 3) X(fuu, 6) X(fxu, 2) X(fxu, 3) X(fxu, 10) X(fxu, 11) X(fxu, 19)
+#else
+#define ILQG_TIME_VARYING_FULL(X)
+#endif
 
 typedef struct {
     double x[N_X];

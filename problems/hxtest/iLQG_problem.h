@@ -25,6 +25,13 @@
 #define ILQG_STATE_DEPENDENT_LIMITS 1
 #define ILQG_TENSOR_NBASIS 0  /* > 0: iLQG_func.c has the factored tensor tables */
 #define ILQG_TENSOR_INIT_WRITES 1  /* init_running() writes constant entries of fxx / fuu / fxu */
+/* the derivative entries bp_derivsL() writes, X(member, index) each: all others are written once, by init_running() */
+#define ILQG_TIME_VARYING(X) X(fx, 1) X(fx, 2) X(fx, 5) X(fx, 7) X(cx, 0) X(cx, 1) X(cx, 2) X(cxx, 0) X(cxx, 3) X(cxx, 5) X(cu, 0) X(cu, 1)
+#if FULL_DDP
+#define ILQG_TIME_VARYING_FULL(X) X(fxx, 6) X(fxx, 9) X(fxx, 11)
+#else
+#define ILQG_TIME_VARYING_FULL(X)
+#endif
 
 typedef struct {
     double x[N_X];

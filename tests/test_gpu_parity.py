@@ -890,6 +890,35 @@ def test_failure_paths_are_per_trajectory_with_uniform_guards(ilqg, fd):
 
 
 @pytest.mark.parametrize("fd", [0, 1])
+def test_backward_on_two_wavefronts_equals_one(ilqg, synth, fd):
+    """option bw_split: the fused backward pass with the derivatives of step k-1 on a second wavefront (hand-over of the
+    time-varying record entries in LDS, one barrier per step) — every bit as on one wavefront, through lambda retries
+    (FULL_DDP = 1: up to 6 sweeps per pass in these iterations), a ragged last tile and a trajectory whose derivatives
+    fail"""
+    B, N, iters = 97, 500, 10
+    x0, u0 = synth.car_batch(B, N, first=4100)
+    runs = []
+    for split in (0, 1):
+        s = ilqg.BatchSolver("carparking", fd, batch=B, n_hor=N, params=ilqg.CAR_PARAMS, opts=dict(max_iter=iters + 2, bw_split=split))
+        s.init(x0, u0)
+        x = s.x()
+        x[70, 300, 3] = np.inf
+        s.set_x(x)
+        snaps = []
+        for it in range(iters):
+            s.iterate(1)
+            l, L = s.gains()
+            snaps.append((l, L, s.scalar("dV0"), s.scalar("dV1"), s.scalar("lambda"), s.scalar("g_norm"), s.scalar("cost"),
+                          s.ints("bp_calls"), s.ints("bp_rc"), s.ints("status"), s.x(), s.u()))
+        runs.append(snaps)
+        s.close()
+    assert runs[0][0][9][70] == 6 and max(snap[7].max() for snap in runs[0]) >= (3 if fd else 1)  # (FULL_DDP = 0 needs no retries here)
+    for a, b in zip(*runs):
+        for p, q in zip(a, b):
+            assert np.array_equal(p, q, equal_nan=True)
+
+
+@pytest.mark.parametrize("fd", [0, 1])
 def test_chunked_records_with_a_finished_trajectory(ilqg, fd, monkeypatch):
     """a work buffer that holds a fraction of the batch (records evaluated and consumed chunk by chunk, the chunks
     taking turns in the two halves of the buffer): same results as with room for everything, also when a

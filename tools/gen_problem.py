@@ -555,6 +555,13 @@ class Emitter:
 #define ILQG_STATE_DEPENDENT_LIMITS {1 if self.has_hx else 0}
 #define ILQG_TENSOR_NBASIS {len(self.tensor_tables["basis"]) if self.tensor_tables else 0}  /* > 0: iLQG_func.c has the factored tensor tables */
 #define ILQG_TENSOR_INIT_WRITES {1 if self.tensor_init_writes() else 0}  /* init_running() writes constant entries of fxx / fuu / fxu */
+/* the derivative entries bp_derivsL() writes, X(member, index) each: all others are written once, by init_running() */
+#define ILQG_TIME_VARYING(X) {self.time_varying_list(False)}
+#if FULL_DDP
+#define ILQG_TIME_VARYING_FULL(X) {self.time_varying_list(True)}
+#else
+#define ILQG_TIME_VARYING_FULL(X)
+#endif
 
 typedef struct {{
     double x[N_X];
@@ -851,6 +858,23 @@ int calc_derivs(tOptSet *o) {
         out += self.block(self.grad_items("cx", self.Fx), True) + "\n" + self.block(self.hess_items("cxx", self.Fxx), True)
         out += "    return 1;\n}\n\n"
         return out
+
+    def time_varying_list(self, full):
+        """the entries emit_derivatives() assigns in bp_derivsL, as X(member, index) ..."""
+        if full:
+            groups = [self.jaco2_items(nm, ten) for nm, ten in (("fxx", self.fxx), ("fuu", self.fuu), ("fxu", self.fxu))
+                      if not self.all_zero(ten)]
+        else:
+            groups = [self.jaco_items("fx", self.fx), self.jaco_items("fu", self.fu), self.grad_items("cx", self.Lx),
+                      self.hess_items("cxx", self.Lxx), self.grad_items("cu", self.Lu), self.hess_items("cuu", self.Luu),
+                      self.hess_items("cxu", self.Lxu)]
+        out = []
+        for items in groups:
+            for lhs, e in items:
+                if self.is_time_var(e):
+                    m = re.fullmatch(r"t->(\w+)\[(\d+)\]", lhs)
+                    out.append("X(%s, %s)" % (m.group(1), m.group(2)))
+        return " ".join(out)
 
     def tensor_init_writes(self):
         """whether init_running() stores anything in the second-derivative tensors of the dynamics (a back-end that
