@@ -300,7 +300,7 @@ def main():
     x0, u0 = synth.car_batch(B, n_hor, first=first) if car else synth.synth16_batch(B, n_hor, first=first)
     params = ilqg.CAR_PARAMS if car else synth.SYNTH16_PARAMS
     s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=n_hor, device=local, params=params,
-                         opts=with_split(dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_keep=args.ls_keep, bw_split=args.bw_split), args),
+                         opts=with_split(dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_keep=args.ls_keep, **({"bw_split": 1} if args.bw_split else {})), args),
                          strict=("wave" if args.mapping == "wave" else False), groups=args.groups)
     if args.resweep >= 0:
         s.set_option("resweep", args.resweep)
