@@ -1622,17 +1622,27 @@ __global__ __launch_bounds__(ROLL_BLOCK) ILQG_ROLLOUT_ATTR void k_rollout(DevPtr
     int b = blockIdx.x * ROLL_BLOCK + threadIdx.x;
     int ai = a0 + blockIdx.y;
     double *keep = nullptr;  // second stage: where this lane's trajectory is kept
+    int second_row = -1;     //   and the row of the candidate buffer (its step size)
     if(mode == ROLL_SECOND) {
         if(blockIdx.y == 0) {
             mode = ROLL_WINNER;
         } else {
             mode = ROLL_SEARCH_LIST;
             ai = a0 + blockIdx.y - 1;
-            if(b < *P.n_pending) keep = P.cand + (size_t)(blockIdx.y - 1) * (P.N + 1) * CAND_W * P.Bp + b;
+            second_row = blockIdx.y - 1;
         }
     }
     if(mode == ROLL_SEARCH_LIST) {
+        // The list is short (the grid covers the worst case, most blocks return at once), and workgroups go to the CUs
+        // round robin: with the entries in the same place of every row of the grid, the busy workgroups of ALL rows
+        // landed on the same few CUs (measured, n = 16 problem, 2 676 entries: 1 / 2 / 4 / 7 rows 38 / 53 / 66 / 83 ms).
+        // Each row starts its walk over the list somewhere else.
+        const int nb = gridDim.x, rows = (int)gridDim.y - (second_row >= 0 ? 1 : 0);
+        const int row = second_row >= 0 ? second_row : (int)blockIdx.y;
+        const int first = (int)(((long long)row * nb) / rows);
+        b = ((int)blockIdx.x + first) % nb * ROLL_BLOCK + threadIdx.x;
         if(b >= *P.n_pending) return;
+        if(second_row >= 0) keep = P.cand + (size_t)second_row * (P.N + 1) * CAND_W * P.Bp + b;
         b = P.pending[b];
     }
     if(b >= P.B) return;

@@ -8,9 +8,12 @@ ilqg, synth = pkg.ilqg, pkg.synth
 B, N = 16384, 1000
 x0, u0 = synth.synth16_batch(B, N)
 full = list(10.0 ** np.linspace(0, -3, 8))
-for name, opts in (("2 alphas, nobody accepts the first (zMin 0.999)", dict(alpha=full[:2], zMin=0.999)),
-                   ("2 alphas, nobody accepts the first, no keep", dict(alpha=full[:2], zMin=0.999, ls_keep=0)),
-                   ("2 alphas", dict(alpha=full[:2]))):
+cases = []
+for n in (2, 3, 5, 8):
+    cases.append(("%d alphas, no keep" % n, dict(alpha=full[:n], ls_keep=0)))
+for n in (2, 8):
+    cases.append(("%d alphas, no keep, zMin 0.999" % n, dict(alpha=full[:n], ls_keep=0, zMin=0.999)))
+for name, opts in cases:
     s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=synth.SYNTH16_PARAMS, opts=dict(max_iter=6, **opts))
     s.init(x0, u0)
     s.iterate(1)
