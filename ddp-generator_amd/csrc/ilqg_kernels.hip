@@ -2609,7 +2609,16 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
                 // (+ one record: records may lie closer together than their size, see FACT_STRIDE, and the last one
                 // still reaches sizeof(trajEl_t) beyond its start)
                 bytes += sizeof(trajEl_t);
-                HIP_TRY(hipMalloc((void **)&W.buf, bytes));
+                // (what hipMemGetInfo calls free is not always available in one piece: take less rather than fail)
+                while(hipMalloc((void **)&W.buf, bytes) != hipSuccess) {
+                    (void)hipGetLastError();
+                    W.buf = nullptr;
+                    if(bytes / 2 < per_traj + sizeof(trajEl_t)) {
+                        g_err = "ilqg_dev_create: no device memory for the derivative work buffer";
+                        return 1;
+                    }
+                    bytes = bytes / 2 + sizeof(trajEl_t);
+                }
                 W.bytes = bytes;
                 HIP_TRY(hipMemsetAsync(W.buf, 0, W.bytes, d->stream));
                 HIP_TRY(hipStreamSynchronize(d->stream));
