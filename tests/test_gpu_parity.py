@@ -317,8 +317,10 @@ def test_line_search_staging_and_resweep_do_not_change_results(ilqg, synth):
     B, iters = 200, 6
     x0, u0 = synth.car_batch(B, first=900)
     ref = None
+    # (two stages: the second one keeps what it rolls out and the accepted trajectories are copied, ls_keep = 1, or
+    # everything accepted is rolled out again, ls_keep = 0; one stage: rolled out again)
     for opts in (dict(ls_split=0, resweep=1), dict(ls_split=3, resweep=0), dict(ls_split=1, resweep=0),
-                 dict(ls_split=5, resweep=1), dict(ls_split=8, resweep=0)):
+                 dict(ls_split=5, resweep=1), dict(ls_split=8, resweep=0), dict(ls_split=3, ls_keep=0), dict(ls_split=2, ls_keep=0)):
         s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS,
                              opts=dict(max_iter=iters, fuse_derivs=0, **opts))
         s.init(x0, u0)
@@ -887,6 +889,32 @@ def test_failure_paths_are_per_trajectory_with_uniform_guards(ilqg, fd):
     assert bad[0][5] == 7 and bad[0][40] == 6
     for a, b in zip(clean, bad):
         assert np.array_equal(a[ok], b[ok])
+
+
+def test_line_search_staging_in_the_wave_mapping(ilqg):
+    """n = 16 problem (one wavefront per trajectory in the backward pass, records only): one stage, two stages with kept
+    or re-rolled trajectories — the same bits"""
+    B, N, iters = 150, 40, 4
+    x0, u0 = syn_inputs(B, N)
+    ref = None
+    for opts in (dict(ls_split=0), dict(ls_split=1), dict(ls_split=3), dict(ls_split=1, ls_keep=0), dict(ls_split=5, ls_keep=0)):
+        # (zMin: a demanding acceptance test, so that the later step sizes are needed)
+        s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters + 1, zMin=0.97, **opts))
+        s.init(x0, u0)
+        hist = []
+        for _ in range(iters):
+            s.iterate(1)
+            hist.append((s.ints("alpha_idx").copy(), s.ints("accepted").copy(), s.scalar("cost").copy(), s.scalar("new_cost").copy()))
+        out = (hist, s.x(), s.u())
+        s.close()
+        if ref is None:
+            ref = out
+            assert np.concatenate([h[0] for h in hist]).max() >= 2  # later step sizes are needed
+            continue
+        for h, hr in zip(out[0], ref[0]):
+            for a, r in zip(h, hr):
+                assert np.array_equal(a, r), opts
+        assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2]), opts
 
 
 @pytest.mark.parametrize("fd", [0, 1])
