@@ -263,7 +263,9 @@ def main():
     ap.add_argument("--fuse-derivs", type=int, default=1)
     ap.add_argument("--ls-split", type=int, default=None, help="default: the library's (3; 1 in the wave mapping)")
     ap.add_argument("--bw-split", type=int, default=0, help="1: fused backward pass on two wavefronts per 64 trajectories (measured: no gain)")
-    ap.add_argument("--ls-keep", type=int, default=1, help="0: second line-search stage and winner pass one after the other")
+    ap.add_argument("--ls-keep", type=int, default=None,
+                    help="default: the library's (2 = step sizes of a trajectory side by side in one wavefront, lane mapping; 1 in the "
+                         "wave mapping); 1: second stage beside the re-rolled winners; 0: second stage, then winner pass")
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary runs (kernels alone, config 5, drop-in)")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--single-process", action="store_true",
@@ -300,7 +302,7 @@ def main():
     x0, u0 = synth.car_batch(B, n_hor, first=first) if car else synth.synth16_batch(B, n_hor, first=first)
     params = ilqg.CAR_PARAMS if car else synth.SYNTH16_PARAMS
     s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=n_hor, device=local, params=params,
-                         opts=with_split(dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, ls_keep=args.ls_keep, **({"bw_split": 1} if args.bw_split else {})), args),
+                         opts=with_split(dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, **({"ls_keep": args.ls_keep} if args.ls_keep is not None else {}), **({"bw_split": 1} if args.bw_split else {})), args),
                          strict=("wave" if args.mapping == "wave" else False), groups=args.groups)
     if args.resweep >= 0:
         s.set_option("resweep", args.resweep)
@@ -360,7 +362,7 @@ def main():
                        "batch_per_gpu": B, "n_hor": n_hor, "n_x": nx, "n_u": nu, "full_ddp": fd,
                        "mapping": ("one wavefront per trajectory" if wave_mapping else
                                    "one lane per trajectory (64 trajectories per wavefront)"),
-                       "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split if args.ls_split is not None else "library default (3; 1 in the wave mapping)", "ls_keep": args.ls_keep, "bw_split": args.bw_split, "resweep": args.resweep,
+                       "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split if args.ls_split is not None else "library default (3; 1 in the wave mapping)", "ls_keep": args.ls_keep if args.ls_keep is not None else "library default (2; 1 in the wave mapping)", "bw_split": args.bw_split, "resweep": args.resweep,
                        "stream_groups": stream_groups,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             # PRIMARY: the whole iteration against the HBM roofline, algorithmic bytes of SURVEY 8(d)

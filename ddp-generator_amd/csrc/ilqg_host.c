@@ -233,6 +233,16 @@ const char *ilqg_problem_param_name(int i) { return (i >= 0 && i < n_params) ? p
 int ilqg_problem_param_size(int i) { return (i >= 0 && i < n_params) ? paramdesc[i]->size : 0; }
 int ilqg_device_count(void) { return ilqg_dev_count(); }
 
+int ilqg_reference_success(int status, int iterations) {
+    switch(status) {
+    case ILQG_ST_CONVERGED_GRAD:
+    case ILQG_ST_CONVERGED_FUN:
+    case ILQG_ST_LAMBDA_MAX: return 1;
+    case ILQG_ST_DERIVS_FAILED: return iterations > 0; /* backPassDone of the previous iteration is still set */
+    default: return 0;
+    }
+}
+
 const char *ilqg_batch_error(const ilqg_batch_t *c) { return c ? c->err : g_create_err; }
 
 static int param_len(const ilqg_batch_t *c, int i) { return paramdesc[i]->size == -1 ? c->N + 1 : paramdesc[i]->size; }
@@ -265,6 +275,9 @@ ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int gro
      * the wave mapping, whose roll-outs are latency bound whatever their number (n = 16 problem: 89 % accepted at
      * the first step size; measured 2.55 it/s with 1, 2.41 with 2, 2.48 with 3, 2.53 with 4) */
     c->ls_split = dims[7] ? 1 : 3;
+    /* lane mapping: the step sizes of a trajectory in one wavefront, selection in the kernel, accepted roll-outs
+     * copied (k_search); wave mapping: second stage beside the winner pass (ROLL_SECOND) */
+    c->ls_keep = dims[7] ? 1 : 2;
     if(groups <= 0) {
         /* lane mapping: 3 (see above).  Wave mapping: 1 — two groups whose backward passes take turns (they share the
          * device's derivative work buffer) so that the roll-outs of one run beside the backward pass of the other were
@@ -372,7 +385,8 @@ int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value
     }
     if(strcmp(name, "ls_keep") == 0) {
         if(n != 1) return fail_msg(c, err_scalar);
-        c->ls_keep = value[0] != 0.0;
+        if(value[0] != 0.0 && value[0] != 1.0 && value[0] != 2.0) return fail_msg(c, "ls_keep must be 0, 1 or 2");
+        c->ls_keep = (int)value[0];
         return 0;
     }
     if(strcmp(name, "fuse_derivs") == 0) {

@@ -73,6 +73,7 @@ def load_library(problem="carparking", full_ddp=0, strict=False):
     lib.ilqg_problem_param_name.restype = C.c_char_p
     lib.ilqg_problem_param_name.argtypes = [C.c_int]
     lib.ilqg_problem_param_size.argtypes = [C.c_int]
+    lib.ilqg_reference_success.argtypes = [C.c_int, C.c_int]
     lib.ilqg_batch_create.restype = v
     lib.ilqg_batch_create.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.ilqg_batch_create_groups.restype = v
@@ -319,8 +320,7 @@ class BatchSolver:
     def success(self):
         """the reference's iLQG() return value per trajectory (what the drop-in iLQG() of this library returns too)"""
         status, iters = self.ints("status"), self.ints("iterations")
-        return np.array([(1 if it > 0 else 0) if int(s) == 6 else REFERENCE_SUCCESS.get(int(s), 0)
-                         for s, it in zip(status, iters)], dtype=np.int32)
+        return np.array([self.lib.ilqg_reference_success(int(s), int(it)) for s, it in zip(status, iters)], dtype=np.int32)
 
     # -- plumbing for collectives / profiling ------------------------------
     def cost_device_ptr(self):

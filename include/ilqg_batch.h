@@ -133,6 +133,14 @@ int ilqg_batch_set_scalar(ilqg_batch_t *c, const char *name, const double *in);
 int ilqg_batch_get_int(ilqg_batch_t *c, const char *name, int *out);
 int ilqg_batch_set_int(ilqg_batch_t *c, const char *name, const int *in);
 
+/* Per-trajectory exit reasons ("status" of ilqg_batch_get_int): 0 active; 1 gradient test passed (iLQG.c:297-303);
+ * 2 accepted step with dcost < tolFun (iLQG.c:330-335); 3 max_iter iterations done (iLQG.c:372-376); 4 backward pass:
+ * lambda > lambdaMax (iLQG.c:273-274); 5 rejected step: lambda > lambdaMax (iLQG.c:356-360); 6 NaN/Inf in calc_derivs
+ * (iLQG.c:247-249); 7 NaN/Inf in the initial roll-out (iLQG_mex.c:116).
+ * ilqg_reference_success: what the reference's iLQG() returns for that exit (1 for 1, 2, 5; 0 for 3, 4, 7; for 6 the
+ * back-pass flag of the previous iteration is still set, iLQG.c:247-249 and 365-378: 1 unless no iteration was done). */
+int ilqg_reference_success(int status, int iterations);
+
 /* For a collective over device memory: a per-trajectory scalar of the whole batch ("cost", ...) copied device to
  * device into `dst_device` (batch doubles, contiguous); synchronises.  ilqg_batch_cost_device_ptr is the address
  * of the cost vector itself while the batch is ONE group (NULL otherwise); ilqg_batch_stream the HIP stream of

@@ -316,6 +316,27 @@ void drv_get_multipliers(drv_t *d, double *el, double *fin, double *w_pen) {
     w_pen[1] = d->o.w_pen_f;
 }
 
+/* teacher forcing (lock-step parity tests): overwrite the nominal trajectory and the scalar state a single stage
+ * reads.  x is [n_hor+1][N_X], u is [n_hor][N_U]; st = {cost, lambda, w_pen_l, w_pen_f} */
+void drv_set_state(drv_t *d, const double *x, const double *u, const double *st) {
+    int k, i;
+    traj_t *tr = d->o.nominal;
+    for(k = 0; k < d->n_hor; k++) {
+        for(i = 0; i < N_X; i++) tr->t[k].x[i] = x[k * N_X + i];
+        for(i = 0; i < N_U; i++) tr->t[k].u[i] = u[k * N_U + i];
+    }
+    for(i = 0; i < N_X; i++) tr->f.x[i] = x[d->n_hor * N_X + i];
+    d->o.cost = st[0];
+    d->o.lambda = st[1];
+    d->o.w_pen_l = st[2];
+    d->o.w_pen_f = st[3];
+}
+
+void drv_set_multipliers(drv_t *d, const double *el, const double *fin) {
+    if(sizeof(multipliersEl_t) > 0) memcpy(d->o.multipliers.t, el, sizeof(multipliersEl_t) * d->n_hor);
+    if(sizeof(multipliersFin_t) > 0) memcpy(&d->o.multipliers.f, fin, sizeof(multipliersFin_t));
+}
+
 int drv_get_log_linesearch(drv_t *d, int iter) { return d->o.log_linesearch[iter]; }
 
 /* trace of the last drv_solve(): returns count; each array has room for `cap` */

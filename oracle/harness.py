@@ -135,6 +135,9 @@ def _bind(lib):
     if hasattr(lib, "drv_get_multipliers"):
         lib.drv_multiplier_dims.argtypes = [_ip]
         lib.drv_get_multipliers.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    if hasattr(lib, "drv_set_state"):
+        lib.drv_set_state.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        lib.drv_set_multipliers.argtypes = [C.c_void_p, _dp, _dp]
     if hasattr(lib, "drv_solve_many"):
         lib.drv_solve_many.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _ip, _ip]
     return lib
@@ -262,6 +265,20 @@ class Driver:
         w = np.zeros(2)
         self.lib.drv_get_multipliers(self.h, el, fin, w)
         return el[:, :dims[0]], fin[:dims[1]], (float(w[0]), float(w[1]))
+
+    def set_state(self, x, u, cost, lam, w_pen=(0.0, 0.0)):
+        """teacher forcing: nominal (x, u), cost, lambda and the penalty weights as another driver has them"""
+        st = np.array([cost, lam, w_pen[0], w_pen[1]], dtype=np.float64)
+        self.lib.drv_set_state(self.h, np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(u, dtype=np.float64), st)
+
+    def set_multipliers(self, el, fin):
+        dims = np.zeros(2, dtype=np.int32)
+        self.lib.drv_multiplier_dims(dims)
+        e = np.zeros((self.N, max(int(dims[0]), 1)))
+        f = np.zeros(max(int(dims[1]), 1))
+        e[:, :dims[0]] = el
+        f[:dims[1]] = fin
+        self.lib.drv_set_multipliers(self.h, e, f)
 
     def log_linesearch(self, it=0):
         return self.lib.drv_get_log_linesearch(self.h, it)

@@ -9,9 +9,13 @@
  * (b) shipped to the GPU box as the checker for the HIP kernels and as the CPU
  * baseline.  It is never linked into, imported by, or called from the product.
  *
- * Parity status: PINNED.  Every function below is checked against the
- * reference build on seeded inputs with exact (bitwise) equality, both
- * compiled with -ffp-contract=off.
+ * Parity status: the dense helpers (matMult.c, cholesky.c) are PINNED — checked with exact
+ * (bitwise) equality against those reference files compiled with no stand-in of any kind (oracle/_ref/libref_pure.so).
+ * The solver proper (boxQP.c, back_pass.c, line_search.c, iLQG.c) equals the reference's own sources bit for bit on
+ * every fixture and on fresh seeded inputs, both compiled with -ffp-contract=off — but that reference build needs a
+ * stand-in mex.h and this repository's generated problem file (the reference commits none and Maxima is absent), so
+ * by the rule that such a build pins nothing, PARITY OF THE SOLVER PROPER IS UNPINNED beyond the analytic known
+ * answer of the Brachistochrone demo (tests/test_known_answer.py).
  *
  * All sums run in ascending index order, fp64, no fused multiply-add
  * (SURVEY.md Appendix D).  Matrices are column-major; symmetric matrices are

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import golden, load_package
-from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver, hx_inputs, lib_path, syn_inputs
+from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS, SYN_PARAMS_TIGHT, Driver, hx_inputs, lib_path, syn_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -217,11 +217,15 @@ def test_boxqp_random_vs_oracle(ilqg, oracle_built):
 # ---------------------------------------------------------------------------
 # single backward pass + line search on the reference demo problem (goldens)
 # ---------------------------------------------------------------------------
+# variant "_plain": the same problem emitted without any additive hint or table (tools/gen_problem.py --plain, what a
+# Maxima/gentran-generated pair looks like): the kernels' general-case branches (state-dependent limits assumed, every
+# record entry treated as time varying, stored tensors)
+@pytest.mark.parametrize("variant", ["", "_plain"])
 @pytest.mark.parametrize("fd", [0, 1])
-def test_single_pass_golden(ilqg, fd):
+def test_single_pass_golden(ilqg, fd, variant):
     g = golden("car_single_fd%d.npz" % fd)
     # ls_split=0: every step size is rolled out, so all eight per-alpha costs can be compared
-    s = ilqg.BatchSolver("carparking", fd, batch=1, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(ls_split=0))
+    s = ilqg.BatchSolver("carparking" + variant, fd, batch=1, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(ls_split=0))
     s.init(g["x0"][None], g["u0"][None])
     assert close(s.scalar("cost")[0], g["init_cost"])
     assert close(s.x()[0], g["x_nom"]) and close(s.u()[0], g["u_nom"])
@@ -280,11 +284,12 @@ def test_backward_pass_from_golden_derivatives(ilqg, fd):
     s.close()
 
 
+@pytest.mark.parametrize("variant", ["", "_plain"])
 @pytest.mark.parametrize("fd", [0, 1])
-def test_fused_backward_matches_golden(ilqg, fd):
+def test_fused_backward_matches_golden(ilqg, fd, variant):
     """derivatives evaluated inside the backward kernel: same gains as from the stored records"""
     g = golden("car_single_fd%d.npz" % fd)
-    s = ilqg.BatchSolver("carparking", fd, batch=1, n_hor=500, params=ilqg.CAR_PARAMS)
+    s = ilqg.BatchSolver("carparking" + variant, fd, batch=1, n_hor=500, params=ilqg.CAR_PARAMS)
     s.init(g["x0"][None], g["u0"][None])
     s.back_pass(fused=True)
     assert s.ints("bp_rc")[0] == 0 and s.ints("bp_calls")[0] == 1
@@ -311,18 +316,24 @@ def test_fused_and_unfused_iterations_agree(ilqg, synth, fuse):
     assert np.abs(out[0][2] - out[1][2]).max() < 1e-7
 
 
-def test_line_search_staging_and_resweep_do_not_change_results(ilqg, synth):
+@pytest.mark.parametrize("strict", [False, True])
+def test_line_search_staging_and_resweep_do_not_change_results(ilqg, synth, strict):
     """two-stage line search (any split) == all step sizes for every trajectory, bit for bit;
-    the reference's cost-only re-sweep after an accepted step returns the same cost bit for bit"""
+    the reference's cost-only re-sweep after an accepted step returns the same cost bit for bit.
+    Three implementations of the stages (option ls_keep): 2 = the step sizes of a trajectory side by side in one
+    wavefront, selection inside the roll-out kernel, accepted roll-outs copied (k_search; the lane mapping's default);
+    1 = second stage beside the re-rolled winners of the first, its own winners copied; 0 = everything accepted is
+    rolled out again.  Within one implementation every split gives identical bits; ACROSS implementations (different
+    kernels around the same generated callbacks) identical bits are required of the -ffp-contract=off build, the
+    product build may contract multiply-adds differently and is held to the single-pass tolerance."""
     B, iters = 200, 6
     x0, u0 = synth.car_batch(B, first=900)
-    ref = None
-    # (two stages: the second one keeps what it rolls out and the accepted trajectories are copied, ls_keep = 1, or
-    # everything accepted is rolled out again, ls_keep = 0; one stage: rolled out again)
-    for opts in (dict(ls_split=0, resweep=1), dict(ls_split=3, resweep=0), dict(ls_split=1, resweep=0),
-                 dict(ls_split=5, resweep=1), dict(ls_split=8, resweep=0), dict(ls_split=3, ls_keep=0), dict(ls_split=2, ls_keep=0)):
+    ref = {}
+    for opts in (dict(ls_split=0, resweep=1), dict(ls_split=3, resweep=0), dict(ls_split=4, resweep=0), dict(ls_split=1, resweep=0),
+                 dict(ls_split=5, resweep=1), dict(ls_split=8, resweep=0), dict(ls_split=0, ls_keep=1), dict(ls_split=3, ls_keep=1),
+                 dict(ls_split=1, ls_keep=1), dict(ls_split=5, ls_keep=1, resweep=1), dict(ls_split=3, ls_keep=0), dict(ls_split=2, ls_keep=0)):
         s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS,
-                             opts=dict(max_iter=iters, fuse_derivs=0, **opts))
+                             opts=dict(max_iter=iters, fuse_derivs=0, **opts), strict=strict)
         s.init(x0, u0)
         hist = []
         for _ in range(iters):
@@ -331,15 +342,19 @@ def test_line_search_staging_and_resweep_do_not_change_results(ilqg, synth):
                          s.scalar("new_cost").copy(), s.scalar("lambda").copy()))
         out = (hist, s.x(), s.u())
         s.close()
-        if ref is None:
-            ref = out
+        family = 2 if opts.get("ls_keep", 2) == 2 else 1
+        if family not in ref:
+            ref[family] = out
             idx = np.concatenate([h[0] for h in hist])
             assert idx.max() >= 4  # the second stage is exercised
-            continue
-        for h, hr in zip(out[0], ref[0]):
-            for a, r in zip(h, hr):
-                assert np.array_equal(a, r), opts
-        assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2]), opts
+        for fam, r in ref.items():
+            exact = strict or fam == family
+            same = np.array_equal if exact else close
+            for h, hr in zip(out[0], r[0]):
+                assert np.array_equal(h[0], hr[0]) and np.array_equal(h[1], hr[1]), opts  # step index, accepted: always
+                for a, q in zip(h[2:], hr[2:]):
+                    assert same(a, q), (opts, fam)
+            assert same(out[1], r[1]) and same(out[2], r[2]), (opts, fam)
 
 
 @pytest.mark.parametrize("fd", [0, 1])
@@ -568,11 +583,12 @@ def test_regtype2_golden(ilqg, fd):
 # ---------------------------------------------------------------------------
 # wave mapping (one wavefront per trajectory): n=16/m=8 synthetic problem, and CarParking forced into it
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["", "_plain"])
 @pytest.mark.parametrize("fd", [0, 1])
-def test_wave_mapping_synthetic_golden(ilqg, fd):
+def test_wave_mapping_synthetic_golden(ilqg, fd, variant):
     g = golden("synth16x8_fd%d.npz" % fd)
     N = int(g["n_hor"])
-    s = ilqg.BatchSolver("synth16x8", fd, batch=1, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(ls_split=0))
+    s = ilqg.BatchSolver("synth16x8" + variant, fd, batch=1, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(ls_split=0))
     assert s.problem.wave_mapping and (s.problem.nx, s.problem.nu) == (16, 8)
     s.init(g["x0"][:1], g["u0"][:1])
     assert close(s.scalar("cost")[0], g["cost"])
@@ -599,7 +615,7 @@ def test_wave_mapping_synthetic_golden(ilqg, fd):
     # lock-step batch (ragged size) against the oracle, derivative records chunked through the work buffer
     B, iters = 5, 4
     x0, u0 = syn_inputs(B, N, first=40)
-    s = ilqg.BatchSolver("synth16x8", fd, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters))
+    s = ilqg.BatchSolver("synth16x8" + variant, fd, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters))
     s.init(x0, u0)
     s.iterate(iters)
     cost, x = s.scalar("cost"), s.x()
@@ -778,6 +794,49 @@ def test_properties_at_full_benchmark_batch(ilqg, synth, oracle_built):
     d.solve()
     assert close(prev[40000], d.scalars()["cost"], 1e-9)
     d.close(); s.close(); small.close()
+
+
+def test_properties_at_config5_size(ilqg, synth, oracle_built):
+    """BASELINE config 5 at full size (synthetic n = 16, m = 8, N = 1000, FULL_DDP = 1, 16 384 trajectories): the
+    production path of the wave mapping — two pieces of 8 192 trajectories on two streams, backward wavefronts taking
+    trajectories from the queue, factored records lying overlapped in the device's work buffer, the 7-row second search
+    stage — which the fixture-sized tests (B <= 150, N <= 40) never reach.  Accepted steps reduce the cost and rejected
+    ones leave it untouched; trajectories at the piece boundary (8 191 / 8 192), at the first and last place of a
+    backward workgroup (8 wavefronts) and at the ends of the batch equal the same trajectories solved alone, bit for
+    bit; one of them equals the CPU oracle."""
+    B, N, iters = 16384, 1000, 2
+    x0, u0 = synth.synth16_batch(B, N)
+    s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=50))
+    assert s.problem.wave_mapping
+    s.init(x0, u0)
+    prev = s.scalar("cost")
+    n_acc = 0
+    for _ in range(iters):
+        s.iterate(1)
+        c = s.scalar("cost")
+        acc = s.ints("accepted").astype(bool)
+        assert np.all(c[acc] < prev[acc]) and np.array_equal(c[~acc], prev[~acc])
+        n_acc += int(acc.sum())
+        prev = c
+    assert n_acc > B and np.all(s.ints("iterations") <= iters)
+    pick = [0, 7, 8, 8191, 8192, 8199, 12345, 16383]
+    x_big, u_big = s.x()[pick], s.u()[pick]
+    alpha_big = s.ints("alpha_idx")[pick]
+    s.close()
+    small = ilqg.BatchSolver("synth16x8", 1, batch=len(pick), n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=50))
+    small.init(x0[pick], u0[pick])
+    small.iterate(iters)
+    assert np.array_equal(small.scalar("cost"), prev[pick])
+    assert np.array_equal(small.ints("alpha_idx"), alpha_big)
+    assert np.array_equal(small.x(), x_big) and np.array_equal(small.u(), u_big)
+    small.close()
+    b = 12345
+    d = Driver(lib_path("oracle", "synth16x8", 1), N, SYN_PARAMS, dict(max_iter=iters))
+    assert d.init(x0[b], u0[b]) == 1
+    d.solve()
+    assert close(prev[b], d.scalars()["cost"], 1e-9), (prev[b], d.scalars()["cost"])
+    assert np.abs(x_big[pick.index(b)] - d.traj(0)[0]).max() < 1e-7
+    d.close()
 
 
 def test_results_do_not_depend_on_stream_groups(ilqg, synth):

@@ -257,8 +257,11 @@ class Deriver:
 # emitter
 # --------------------------------------------------------------------------
 class Emitter:
-    def __init__(self, prob):
+    def __init__(self, prob, plain=False):
+        """plain: what a Maxima/gentran-generated pair looks like — no additive hints in the header, no factored
+        tensor tables and no bp_derivsL_first() in the C file (the batched back-end then takes its general paths)"""
         self.p = prob
+        self.plain = plain
         self.n = len(prob.x)
         self.m = len(prob.u)
         self._constraints()
@@ -270,7 +273,7 @@ class Emitter:
                 self.time_syms.add(sp.Symbol("%s[k]" % nm, real=True))
         self._derive()
         self.cse = SharedTerms(self) if prob.cse else None
-        self.tensor_tables = self._factor_tensors() if prob.cse else None
+        self.tensor_tables = self._factor_tensors() if (prob.cse and not plain) else None
 
     def _factor_tensors(self):
         """{'basis': [products], 'xx': (coefficients, product number per slice), 'uu': ..., 'xu': ...} in the array
@@ -514,6 +517,25 @@ class Emitter:
         return out
 
     # ---- files -------------------------------------------------------------
+    def hints_block(self):
+        if self.plain:
+            return ""
+        return f"""/* additive hints for the batched backend (absent in Maxima-generated headers,
+ * which are then treated as the general case) */
+#define ILQG_PROBLEM_NAME "{self.p.name}"
+#define ILQG_STATE_DEPENDENT_LIMITS {1 if self.has_hx else 0}
+#define ILQG_TENSOR_NBASIS {len(self.tensor_tables["basis"]) if self.tensor_tables else 0}  /* > 0: iLQG_func.c has the factored tensor tables */
+#define ILQG_TENSOR_INIT_WRITES {1 if self.tensor_init_writes() else 0}  /* init_running() writes constant entries of fxx / fuu / fxu */
+/* the derivative entries bp_derivsL() writes, X(member, index) each: all others are written once, by init_running() */
+#define ILQG_TIME_VARYING(X) {self.time_varying_list(False)}
+#if FULL_DDP
+#define ILQG_TIME_VARYING_FULL(X) {self.time_varying_list(True)}
+#else
+#define ILQG_TIME_VARYING_FULL(X)
+#endif
+
+"""
+
     def problem_h(self):
         n, m = self.n, self.m
         run_members = "".join("    double %s;\n" % s.name for s in self.aux_syms(self.run_need, ("aux", "d1", "d2")))
@@ -549,21 +571,7 @@ class Emitter:
 #define sizeofQuu {m * (m + 1) // 2}
 #define sizeofQxu {n * m}
 
-/* additive hints for the batched backend (absent in Maxima-generated headers,
- * which are then treated as the general case) */
-#define ILQG_PROBLEM_NAME "{self.p.name}"
-#define ILQG_STATE_DEPENDENT_LIMITS {1 if self.has_hx else 0}
-#define ILQG_TENSOR_NBASIS {len(self.tensor_tables["basis"]) if self.tensor_tables else 0}  /* > 0: iLQG_func.c has the factored tensor tables */
-#define ILQG_TENSOR_INIT_WRITES {1 if self.tensor_init_writes() else 0}  /* init_running() writes constant entries of fxx / fuu / fxu */
-/* the derivative entries bp_derivsL() writes, X(member, index) each: all others are written once, by init_running() */
-#define ILQG_TIME_VARYING(X) {self.time_varying_list(False)}
-#if FULL_DDP
-#define ILQG_TIME_VARYING_FULL(X) {self.time_varying_list(True)}
-#else
-#define ILQG_TIME_VARYING_FULL(X)
-#endif
-
-typedef struct {{
+{self.hints_block()}typedef struct {{
     double x[N_X];
     double u[N_U];
     double lower[N_U];
@@ -1099,11 +1107,13 @@ def load_problem(path):
 
 
 def main(argv):
+    plain = "--plain" in argv
+    argv = [a for a in argv if a != "--plain"]
     if len(argv) != 3:
         print(__doc__)
         return 2
     prob = load_problem(argv[1])
-    em = Emitter(prob)
+    em = Emitter(prob, plain=plain)
     os.makedirs(argv[2], exist_ok=True)
     with open(os.path.join(argv[2], "iLQG_problem.h"), "w") as f:
         f.write(em.problem_h())
