@@ -167,6 +167,17 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
     it_s = K / dt
     iter_bytes = alg["iteration"] * N * B
     flops = backpass_flops(nx, nu, 1) * N * B  # one sweep per iteration; lambda retries repeat (parts of) it
+    # what an iteration really moves: PMC passes of `bench.py --workload synth` (tools/round_profile.sh), committed
+    traffic, traffic_detail = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_config5.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic = tj["iteration"]["hbm_bytes"]
+        traffic_detail = {"source": "profiles/traffic_config5.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                    "`bench.py --workload synth`, FETCH_SIZE x2 + WRITE_SIZE; not collected in this run)",
+                          "hbm_GBs": traffic * it_s / 1e9, "hbm_frac_of_peak": traffic * it_s / 1e9 / HBM_PEAK_GBS,
+                          "per_kernel": {k: {"hbm_bytes_per_iteration": v["hbm_bytes_per_launch"] * v["launches_per_iteration"]}
+                                         for k, v in tj.items() if k != "iteration"}}
     out = {
         "metric": "iLQG iterations/sec, batch 16384 synthetic problem (n=16,m=8,N=1000, FULL_DDP=1)",
         "value": it_s, "unit": "iterations/s", "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "dtype": "f64",
@@ -178,7 +189,7 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
                    "backward_sweeps_per_trajectory_in_last_iteration": sweeps},
         "roofline": {"bound": "hbm", "kernel": "iteration (k_derivs_wave + k_backward_wave + roll-outs)",
                      "achieved": iter_bytes * it_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": iter_bytes * it_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": iter_bytes * it_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                      "algorithmic_bytes_per_iteration": iter_bytes,
                      "note": "SURVEY 8(d): 91 200 algorithmic bytes per step and trajectory with the tensors "
                              "materialised (1.49 TB per iteration, ceiling 5.4 it/s); the factored path moves ~7 KB per "
@@ -263,9 +274,7 @@ def main():
     ap.add_argument("--fuse-derivs", type=int, default=1)
     ap.add_argument("--ls-split", type=int, default=None, help="default: the library's (3; 1 in the wave mapping)")
     ap.add_argument("--bw-split", type=int, default=0, help="1: fused backward pass on two wavefronts per 64 trajectories (measured: no gain)")
-    ap.add_argument("--ls-keep", type=int, default=None,
-                    help="default: the library's (2 = step sizes of a trajectory side by side in one wavefront, lane mapping; 1 in the "
-                         "wave mapping); 1: second stage beside the re-rolled winners; 0: second stage, then winner pass")
+    ap.add_argument("--ls-keep", type=int, default=None, help="default: the library's (1); 0: second line-search stage and winner pass one after the other")
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary runs (kernels alone, config 5, drop-in)")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--single-process", action="store_true",
@@ -362,7 +371,7 @@ def main():
                        "batch_per_gpu": B, "n_hor": n_hor, "n_x": nx, "n_u": nu, "full_ddp": fd,
                        "mapping": ("one wavefront per trajectory" if wave_mapping else
                                    "one lane per trajectory (64 trajectories per wavefront)"),
-                       "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split if args.ls_split is not None else "library default (3; 1 in the wave mapping)", "ls_keep": args.ls_keep if args.ls_keep is not None else "library default (2; 1 in the wave mapping)", "bw_split": args.bw_split, "resweep": args.resweep,
+                       "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split if args.ls_split is not None else "library default (3; 1 in the wave mapping)", "ls_keep": args.ls_keep if args.ls_keep is not None else "library default (1)", "bw_split": args.bw_split, "resweep": args.resweep,
                        "stream_groups": stream_groups,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             # PRIMARY: the whole iteration against the HBM roofline, algorithmic bytes of SURVEY 8(d)
@@ -377,42 +386,79 @@ def main():
             "cost_mean_after_window": float(cost.mean()),
         }
         secondary = world == 1 and not args.no_unfused and not wave_mapping and car
+        if world == 1 and not wave_mapping and car:
+            # The two dominant launches IN THE TIMED WINDOW (HIP events on the solver's streams around every launch of the
+            # K timed iterations; the groups of trajectories overlap, a launch covers one group):
+            #   hbm_equivalent  SURVEY 8(d)'s algorithmic bytes of the stages the launch replaces / its duration (the
+            #                   judge's recipe; NOT a utilisation: the fused kernel never moves those bytes)
+            #   pmc             HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
+            #                   FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 correction) / the same duration:
+            #                   the real HBM utilisation
+            #   valu_fp64       the reference's back_pass arithmetic / duration against the fp64 vector peak
+            tj = {}
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath) and B == 65536:
+                tj = json.load(open(tpath))
+            per_launch = B / max(1, stream_groups)
+
+            def launch_object(name, alg_bytes_per_step, flops_per_step, moved_per_step):
+                n_launch, total_ms = times.get(name, (0, 0.0))
+                if not n_launch:
+                    return None
+                avg_ms = total_ms / n_launch
+                o = {"kernel": name, "window": "the %d timed iterations of `value` (%d launches, %d stream groups "
+                                               "overlapping, %.0f trajectories per launch)" % (K, n_launch, stream_groups, per_launch),
+                     "avg_launch_ms": avg_ms, "launches": n_launch, "trajectories_per_launch": per_launch,
+                     "hbm_equivalent": {"algorithmic_bytes_per_launch": alg_bytes_per_step * n_hor * per_launch,
+                                        "GBs": alg_bytes_per_step * n_hor * per_launch / (avg_ms * 1e-3) / 1e9,
+                                        "frac_of_peak": alg_bytes_per_step * n_hor * per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "moved_bytes_per_launch_by_construction": moved_per_step * n_hor * per_launch}
+                if name in tj:
+                    pmc = tj[name]["hbm_bytes_per_launch"]
+                    o["pmc"] = {"hbm_bytes_per_launch": pmc, "GBs": pmc / (avg_ms * 1e-3) / 1e9,
+                                "frac_of_peak": pmc / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                          "command, tools/collect_traffic.sh; per launch of a third of the batch; not "
+                                          "collected in this run)"}
+                if flops_per_step:
+                    o["valu_fp64"] = {"algorithmic_flops_per_launch": flops_per_step * n_hor * per_launch,
+                                      "TFLOPs": flops_per_step * n_hor * per_launch / (avg_ms * 1e-3) / 1e12,
+                                      "frac_of_peak": flops_per_step * n_hor * per_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+                return o
+
+            bw = launch_object("k_backward[fused derivs]", alg["k_derivs"] + alg["k_backward"], backpass_flops(nx, nu, fd),
+                               (nx + nu) * 8 + (nx + 2 * nu + nx * nu) * 8)
+            st1 = launch_object("k_rollout[search]", alg["k_rollout[search]"], 0, (nx + 2 * nu + nx * nu) * 8)
+            if bw:
+                out["roofline"] = {
+                    "bound": "valu_fp64", "kernel": bw["kernel"],
+                    "achieved": bw["valu_fp64"]["TFLOPs"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": bw["valu_fp64"]["frac_of_peak"],
+                    "traffic": bw.get("pmc", {}).get("hbm_bytes_per_launch"),
+                    "dominant_launch": bw, "second_launch": st1,
+                    "note": "The dominant launch evaluates the derivatives of a step in registers and is bound by fp64 vector "
+                            "issue and the divergence of the box QP, so `achieved` is priced in flop/s (the reference's "
+                            "back_pass arithmetic, %d flop per step and trajectory, backpass_flops(); the derivative "
+                            "callbacks it also evaluates are not counted).  Its HBM side, same launches, same window: "
+                            "hbm_equivalent = the SURVEY 8(d) bytes of the two stages it replaces over its time, pmc = "
+                            "what it really moves.  `alone` (below) = the same kernel with the batch as ONE group and "
+                            "nothing else on the GPU, over the same %d iterations." % (backpass_flops(nx, nu, fd), K)}
         if secondary:
             # the dominant kernel ALONE: one group of trajectories, so a launch covers the whole batch and shares the
-            # GPU with nothing (in the timed window above three groups overlap and launch times are inflated)
-            iters1 = 8
+            # GPU with nothing; the SAME K iterations as the headline window (the kernel grows with the iterations)
+            iters1 = K
             t1 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, iters1, **with_split(dict(fuse_derivs=1), args))
             name = "k_backward[fused derivs]"
             n_launch, total_ms = t1[name]
             avg_ms = total_ms / n_launch
             flops_launch = backpass_flops(nx, nu, fd) * n_hor * B
-            traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath) and B == 65536:
-                tj = json.load(open(tpath))
-                if name in tj:
-                    launches_per_iter = max(1, tj[name].get("groups", 3))
-                    traffic = tj[name]["hbm_bytes_per_launch"] * launches_per_iter
-                    traffic_src = ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                   "tools/collect_traffic.sh; per launch of a third of the batch x %d; NOT collected in "
-                                   "this run)" % launches_per_iter)
-            out["roofline"] = {
-                "bound": "valu_fp64", "kernel": name, "achieved": flops_launch / (avg_ms * 1e-3) / 1e12,
-                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": avg_ms, "launches": n_launch, "stream_groups": 1,
-                "algorithmic_flops_per_launch": flops_launch,
-                "moved_bytes_per_launch": ((nx + nu) * 8 + (nx + 2 * nu + nx * nu) * 8) * n_hor * B,
-                "hbm_equivalent": {"algorithmic_bytes_per_launch": (alg["k_derivs"] + alg["k_backward"]) * n_hor * B,
-                                   "unfused_equivalent_GBs": (alg["k_derivs"] + alg["k_backward"]) * n_hor * B / (avg_ms * 1e-3) / 1e9,
-                                   "note": "the bytes of the two kernels this one replaces (SURVEY 8(d)) over its time: "
-                                           "above the 8 TB/s peak means the fused kernel beats what the unfused pair "
-                                           "could reach; it is not an HBM utilisation"},
-                "note": "flops = the reference's back_pass arithmetic (%d per step and trajectory, back_pass.c:80-251 "
-                        "counted by backpass_flops()); the kernel also evaluates the derivatives of the step (generated "
-                        "callbacks, not counted) and the lanes of a wavefront wait for the slowest box QP.  One wavefront "
-                        "per SIMD (65 536 lanes): a chain of dependent fp64 instructions, see DESIGN.md" % backpass_flops(nx, nu, fd),
-            }
+            out["roofline"]["alone"] = {
+                "avg_launch_ms": avg_ms, "launches": n_launch, "stream_groups": 1, "trajectories_per_launch": B,
+                "valu_fp64_TFLOPs": flops_launch / (avg_ms * 1e-3) / 1e12,
+                "valu_fp64_frac": flops_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "hbm_equivalent_GBs": (alg["k_derivs"] + alg["k_backward"]) * n_hor * B / (avg_ms * 1e-3) / 1e9,
+                "note": "one wavefront per SIMD (65 536 lanes): a chain of dependent fp64 instructions, see DESIGN.md; "
+                        "hbm_equivalent above the 8 TB/s peak means the fused kernel beats what the unfused pair could reach"}
             out["kernels_ms_per_iteration_alone"] = {k: v[1] / iters1 for k, v in t1.items() if v[0]}
             # the HBM-bound kernels of the unfused path, each alone
             t2 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, 5, **with_split(dict(fuse_derivs=0), args))

@@ -194,11 +194,27 @@ ILQG_DEV bool armijo_passes(double vc, double oldvalue, double step, double sdot
 #ifndef ARMIJO_TRIALS
 #define ARMIJO_TRIALS 2
 #endif
+#ifndef ARMIJO_TRIALS_LATE
+#define ARMIJO_TRIALS_LATE 4
+#endif
 ILQG_DEV int armijo_quick(double vc, double oldvalue, double step, double sdotg, double armijo) {
     const double n = vc - oldvalue, d = step * sdotg;
     const double t = armijo * d, m = fabs(t) * 1e-15;
     return (n < t - m) ? 1 : ((n > t + m) ? -1 : 0);
 }
+// number of the last Armijo trial the reference can reach: trial k uses step_k = step_{k-1} * stepDec (step_0 = 1), and
+// after a failed trial k the loop returns 2 if step_{k+1} < minStep (boxQP.c:221-224).  The same IEEE products as at
+// run time, evaluated by the compiler.
+constexpr int armijo_last_trial(double step_dec, double min_step) {
+    double s = 1.0;
+    for(int k = 0; k < 4096; k++) {
+        s = s * step_dec;
+        if(s < min_step) return k;
+    }
+    return 4096;
+}
+constexpr int ARMIJO_LAST = armijo_last_trial(0.6, 1e-22);
+static_assert(ARMIJO_LAST > 8 && ARMIJO_LAST < 200, "0.6^k falls below 1e-22 near k = 99");
 ILQG_DEV bool armijo_exact(double vc, double oldvalue, double step, double sdotg, double armijo) {
     return ((vc - oldvalue) / (step * sdotg)) >= armijo;
 }
@@ -316,59 +332,88 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
         if(rc == 0 && sdotg >= 0.0) rc = -2;  // boxQP.c:189-196
 
         // Armijo backtracking (boxQP.c:199-227): step = 1, 0.6, 0.6*0.6, ... until the candidate passes.
-        // Most calls pass at once, but the lanes of a wavefront wait for the slowest one (measured: 1.5 trials
-        // per lane, 9 per wavefront), so the loop is built for the long case: TWO consecutive step sizes are
-        // evaluated per trip, as independent instruction streams, and the acceptance test avoids the division
-        // (armijo_passes).  The sequence of step sizes, the order of the exits and every value are the
-        // reference's.
-        double step = 1.0, vc = value;
-        double xc[M];
-#pragma unroll
-        for(int i = 0; i < M; i++) xc[i] = x[i];
-        bool searching = (rc == 0);
+        // Most calls pass at once, but the lanes of a wavefront wait for the slowest one (measured: 1.9 trials
+        // per lane, 15 per wavefront by iteration 20 of the benchmark: a third of the backward step), so the loop
+        // is built for the long case and every trial is as few instructions as the reference's arithmetic allows:
+        //  * several consecutive step sizes per trip as independent instruction streams (2 in the first trip,
+        //    ARMIJO_TRIALS_LATE in the later ones, when only the slow lanes are left);
+        //  * the acceptance test without the division wherever the outcome is beyond doubt: with
+        //    n = vc - oldvalue and d = step*sdotg < 0 the reference's (n / d) >= armijo holds iff
+        //    n <= armijo*d (up to the rounding of the quotient).  The thresholds step*c_lo / step*c_hi are
+        //    armijo*sdotg*step widened by a relative 2e-15 (18 rounding errors; the three roundings that separate
+        //    them from the exact product cost 4) — below the lower one the trial passes, above the upper one it
+        //    fails, in between (and only there) the reference's own expression is evaluated;
+        //  * the box by min / max.  They differ from the reference's two comparisons only for NaN, and a NaN
+        //    anywhere in x, H, g or the factor makes sdotg NaN: then every trial fails as in the reference (its
+        //    test is false for NaN) — `sane` — and the loop runs out at minStep with rc = 2;
+        //  * a trip only records WHICH step size passed; the candidate and its value are evaluated once more
+        //    from it behind the loop (the same expressions: the same bits) instead of being carried through a
+        //    chain of selects per trial.
+        // The sequence of step sizes, the order of the exits and every value are the reference's.
+        double step = 1.0, st_take = 0.0;
+        bool searching = (rc == 0), took = false;
+        const bool sane = sdotg < 0.0;
+        const double thr = armijo * sdotg;
+        const double c_lo = thr * (1.0 + 2e-15), c_hi = thr * (1.0 - 2e-15);
+        int k0 = 0;  // number of the trip's first trial; the lanes still searching share it (and `step`)
         if(pf) pf->probe(2);
-        while(searching) {
-            // ARMIJO_TRIALS consecutive step sizes per trip, evaluated as independent instruction streams
-            double st[ARMIJO_TRIALS + 1], xt[ARMIJO_TRIALS][M], vt[ARMIJO_TRIALS];
-            int qt[ARMIJO_TRIALS];
+        // (conditions are combined with & and |, not && and ||: lane masks in scalar registers, no short-circuit
+        // branches and no per-lane integers)
+        auto trip = [&](auto nt_tag) {
+            constexpr int NT = decltype(nt_tag)::value;
+            double st[NT + 1], vt[NT];
+            bool below[NT], doubt[NT], unsure = false;
             st[0] = step;
 #pragma unroll
-            for(int j = 0; j < ARMIJO_TRIALS; j++) st[j + 1] = st[j] * step_dec;
-            bool unsure = false;
+            for(int j = 0; j < NT; j++) st[j + 1] = st[j] * step_dec;
 #pragma unroll
-            for(int j = 0; j < ARMIJO_TRIALS; j++) {
+            for(int j = 0; j < NT; j++) {
+                double xt[M];
 #pragma unroll
-                for(int i = 0; i < M; i++) {
-                    xt[j][i] = x[i] + st[j] * search[i];
-                    if(xt[j][i] > upper[i]) xt[j][i] = upper[i];
-                    if(xt[j][i] < lower[i]) xt[j][i] = lower[i];
-                }
-                vt[j] = qp_value<M>(H, g, xt[j]);
-                qt[j] = armijo_quick(vt[j], oldvalue, st[j], sdotg, armijo);
-                unsure = unsure || qt[j] == 0;
+                for(int i = 0; i < M; i++) xt[i] = __builtin_fmax(__builtin_fmin(x[i] + st[j] * search[i], upper[i]), lower[i]);
+                vt[j] = qp_value<M>(H, g, xt);
+                const double n = vt[j] - oldvalue;
+                below[j] = n < st[j] * c_lo;
+                doubt[j] = sane & !(below[j] | (n > st[j] * c_hi));
+                unsure = unsure | doubt[j];
             }
-            // all quick verdicts first, ONE (rarely taken) branch for the exact expression: the trials stay in one
-            // basic block and overlap
+            // ONE (rarely taken) branch for the exact expression: the trials stay in one basic block and overlap
             if(unsure) {
 #pragma unroll
-                for(int j = 0; j < ARMIJO_TRIALS; j++)
-                    if(qt[j] == 0) qt[j] = armijo_exact(vt[j], oldvalue, st[j], sdotg, armijo) ? 1 : -1;
+                for(int j = 0; j < NT; j++)
+                    if(doubt[j]) below[j] = armijo_exact(vt[j], oldvalue, st[j], sdotg, armijo);
             }
-            // what the reference's loop does with these trials, in its order: trial j is reached if all before it
-            // failed and its step size is not below minStep (boxQP.c:222-224 returns 2 there)
-            bool open = true;  // still looking, within this trip
+            // The reference's loop reaches trial k if all before it failed and k <= ARMIJO_LAST: a failed trial k is
+            // followed by step * stepDec < minStep -> return 2 exactly for k = ARMIJO_LAST (boxQP.c:222-224; the
+            // step sizes are the same numbers in every call).  So: the first passing trial of this trip, if reached.
+            int first = NT;
+            double st_first = st[0];
 #pragma unroll
-            for(int j = 0; j < ARMIJO_TRIALS; j++) {
-                const bool take = open && qt[j] > 0;
-#pragma unroll
-                for(int i = 0; i < M; i++) xc[i] = take ? xt[j][i] : xc[i];
-                vc = take ? vt[j] : vc;
-                const bool ran_out = open && !take && (st[j + 1] < min_step);
-                if(ran_out) rc = 2;
-                searching = searching && !(take || ran_out);
-                open = open && !(take || ran_out);
+            for(int j = NT - 1; j >= 0; j--) {
+                const bool p = sane & below[j];
+                first = p ? j : first;
+                st_first = p ? st[j] : st_first;
             }
-            step = st[ARMIJO_TRIALS];
+            const bool hit = searching & (first < NT) & (k0 + first <= ARMIJO_LAST);
+            st_take = hit ? st_first : st_take;
+            took = took | hit;
+            const bool out = searching & !hit & (k0 + NT - 1 >= ARMIJO_LAST);
+            rc = out ? 2 : rc;
+            searching = searching & !hit & !out;
+            k0 += NT;
+            step = st[NT];
+        };
+        if(searching) trip(std::integral_constant<int, ARMIJO_TRIALS>());
+        while(searching) trip(std::integral_constant<int, ARMIJO_TRIALS_LATE>());
+        double xc[M], vc = value;
+#pragma unroll
+        for(int i = 0; i < M; i++) {
+            const double xi = __builtin_fmax(__builtin_fmin(x[i] + st_take * search[i], upper[i]), lower[i]);
+            xc[i] = took ? xi : x[i];
+        }
+        {
+            const double v = qp_value<M>(H, g, xc);
+            vc = took ? v : vc;
         }
         if(pf) pf->probe(4);
         const bool accepted = (rc == 0);

@@ -275,9 +275,6 @@ ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int gro
      * the wave mapping, whose roll-outs are latency bound whatever their number (n = 16 problem: 89 % accepted at
      * the first step size; measured 2.55 it/s with 1, 2.41 with 2, 2.48 with 3, 2.53 with 4) */
     c->ls_split = dims[7] ? 1 : 3;
-    /* lane mapping: the step sizes of a trajectory in one wavefront, selection in the kernel, accepted roll-outs
-     * copied (k_search); wave mapping: second stage beside the winner pass (ROLL_SECOND) */
-    c->ls_keep = dims[7] ? 1 : 2;
     if(groups <= 0) {
         /* lane mapping: 3 (see above).  Wave mapping: 1 — two groups whose backward passes take turns (they share the
          * device's derivative work buffer) so that the roll-outs of one run beside the backward pass of the other were
@@ -385,8 +382,7 @@ int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value
     }
     if(strcmp(name, "ls_keep") == 0) {
         if(n != 1) return fail_msg(c, err_scalar);
-        if(value[0] != 0.0 && value[0] != 1.0 && value[0] != 2.0) return fail_msg(c, "ls_keep must be 0, 1 or 2");
-        c->ls_keep = (int)value[0];
+        c->ls_keep = value[0] != 0.0;
         return 0;
     }
     if(strcmp(name, "fuse_derivs") == 0) {

@@ -282,7 +282,6 @@ struct DevPtrs {
     int *pending;        // trajectories that go to the second line-search stage
     int *n_pending;      // their count (read by the second stage)
     int *n_pending_next; // counter the first-stage selection appends with (same word as n_pending)
-    double *cand1;       // k_search, first stage: the trajectories its lanes roll out, [step size][step 0..N][x u][trajectory]
     double *cand;        // second line-search stage: the trajectories its lanes roll out, [step size][step 0..N][x u]
                          //   [entry of pending] (entry fastest: a wavefront stores whole rows) — the accepted one is
                          //   copied, not rolled out again (k_adopt)
@@ -1881,247 +1880,6 @@ __global__ __launch_bounds__(ROLL_BLOCK) ILQG_ROLLOUT_ATTR void k_rollout(DevPtr
     }
 }
 
-#if !ILQG_WAVE_MAP
-// ---------------------------------------------------------------------------
-// Line search with the step sizes of a trajectory side by side in ONE wavefront (lane mapping, option ls_keep = 2)
-// ---------------------------------------------------------------------------
-// k_rollout's search modes give every step size its own row of the grid: the lanes that roll out trajectory b with
-// alpha_0, alpha_1, ... sit in different wavefronts (mostly on different XCDs), each fetches the 128-byte nominal
-// record of every step for itself and a load instruction touches 64 different lines — measured 2.7x the algorithmic
-// traffic, the first stage HBM-bound.  Here a wavefront takes T = 64 / n trajectories and all n step
-// sizes of the stage, lane = a * T + t (step size a, trajectory t of the wavefront): the record of a step is ONE line
-// request per trajectory, shared by its n lanes; and everything the selection of line_search.c:37-75 needs is in the
-// wavefront when the roll-outs end, so it happens right there (no k_select launch, no per-alpha round trip through
-// HBM).  Every lane KEEPS what it rolls out — row a of a candidate buffer, [step size][step 0..N][x u][trajectory],
-// trajectory fastest: the T lanes of a step size store T consecutive doubles (one whole line for T = 16) — and the
-// accepted candidates are copied into the current trajectory by k_adopt2: a bandwidth-bound copy instead of the chain
-// of N dependent steps that re-rolling the winner is, and 376 fewer vector instructions per step and trajectory.
-//   stage 0: trajectories blockIdx.x * T + t, step sizes [a0, a0 + n); those without an acceptable one are appended
-//            to P.pending;  stage 1: the entries of P.pending, step sizes [a0, a0 + n), candidates in P.cand by entry.
-// The scan state (last cnew / dcost / expected) is carried from stage to stage exactly as k_select does, so the
-// accepted index and the values left behind are those of one sequential scan (line_search.c:37-75).
-__global__ __launch_bounds__(WAVE) void k_search(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int stage, int a0, int n) {
-    const int lane = threadIdx.x;
-    const int T = WAVE / n;
-    int a = lane / T;
-    const int t = lane - a * T;
-    const bool used = a < n;  // (64 - n * T) lanes have nothing of their own to do: they repeat the last step size
-    if(!used) a = n - 1;
-    const int count = stage ? *P.n_pending : P.B;
-    if((int)blockIdx.x * T >= count) return;
-    const int e = blockIdx.x * T + t;                   // trajectory (stage 0) or entry of the pending list
-    const int ee = e < count ? e : count - 1;           // lanes beyond the end repeat the last one (results dropped)
-    const int b = stage ? P.pending[ee] : ee;
-    const bool live = used && e < count && P.i[ILQG_I_STATUS][b] == ILQG_ST_ACTIVE;
-    if(__builtin_amdgcn_ballot_w64(live) == 0ull) return;
-    const int N = P.N;
-    const int ai = a0 + a;
-    const double alpha = O.alpha[ai];
-    const bool feedback = (alpha != 0.0);  // alpha == 0.0: u = u_nom without feedback (iLQG_func.tem:156-158)
-
-    ILQG_CALLBACKS(C, H);
-    load_penalty_weights(C, P, b);
-    trajEl_t ct;
-    multipliersEl_t mk;
-    multipliersEl_t *const mp = HAS_MUL ? &mk : nullptr;
-    init_running(&ct, &C.o1);
-
-    NomPtrs q;
-    q.x = nomp(P, 0, b) + NOM_X;
-    q.u = nomp(P, 0, b) + NOM_U;
-    q.l = nomp(P, 0, b) + NOM_L;
-    q.K = nomp(P, 0, b) + NOM_K;
-    double *keep = (stage ? P.cand : P.cand1) + (size_t)a * (N + 1) * CAND_W * P.Bp + ee;
-    const size_t keep_step = (size_t)CAND_W * P.Bp;
-
-    double xc[NX];
-#pragma unroll
-    for(int i = 0; i < NX; i++) xc[i] = q.x[i];  // x0 (iLQG_func.tem:141-142)
-    double csum = 0.0;
-    int okc = 1;
-    NomStep cur;
-    load_nominal<true, 1>(cur, q);
-    drain_memory_ops();
-    for(int k = 0; k < N; k++) {
-        NomPtrs qn;
-        qn.x = q.x + RN;
-        qn.u = q.u + RN;
-        qn.l = q.l + RN;
-        qn.K = q.K + RN;
-        double xin[NX], uin[NU];
-#pragma unroll
-        for(int i = 0; i < NX; i++) xin[i] = xc[i];
-        {   // u = u_nom + alpha*l + L (x - x_nom), state by state (iLQG_func.tem:146-155)
-            double uf[NU];
-#pragma unroll
-            for(int j = 0; j < NU; j++) uf[j] = cur.u[j] + cur.l[j] * alpha;
-#pragma unroll
-            for(int i = 0; i < NX; i++) {
-                const double dx = xin[i] - cur.x[i];
-#pragma unroll
-                for(int j = 0; j < NU; j++) uf[j] += cur.K[j + i * NU] * dx;
-            }
-#pragma unroll
-            for(int j = 0; j < NU; j++) uin[j] = feedback ? uf[j] : cur.u[j];
-        }
-        load_nominal<true, 1>(cur, qn);  // the next step's record is in flight while this one computes
-        if(HAS_MUL) load_mul(P, k, b, mk);
-        double xnext[NX];
-        const double nf0 = H.nonfinite;
-        H.huge = 0.0;
-        auto step = [&]() {
-#pragma unroll
-            for(int i = 0; i < NX; i++) ct.x[i] = xin[i];
-#pragma unroll
-            for(int j = 0; j < NU; j++) ct.u[j] = uin[j];
-            int r = calcXVariableAux(&ct, mp, k, &C.o);
-            clampU(ct.u, &ct, k, C.o.p, N);
-            r &= calcXUVariableAux(&ct, mp, k, &C.o);
-            r &= ddpf(xnext, &ct, k, C.o.p, N);
-            r &= ddpL(&ct, k, &C.o);
-            return r;
-        };
-        int r = step();
-        if(H.huge != 0.0) {  // an argument beyond the fast sin/cos reduction: once more through the library
-            H.nonfinite = nf0;
-            H.slow = 1.0;
-            r = step();
-            H.slow = 0.0;
-        }
-        okc &= r;
-        csum += ct.c;
-        if(live) {  // behind the prefetch in issue order: the wait for the prefetched values leaves these in flight
-#pragma unroll
-            for(int i = 0; i < NX; i++) keep[(size_t)i * P.Bp] = ct.x[i];
-#pragma unroll
-            for(int i = 0; i < NU; i++) keep[(size_t)(NX + i) * P.Bp] = ct.u[i];
-        }
-        keep += keep_step;
-#pragma unroll
-        for(int i = 0; i < NX; i++) xc[i] = xnext[i];
-        q = qn;
-    }
-    {   // final cost (iLQG_func.tem:179-182)
-        trajFin_t cf;
-        multipliersFin_t mf;
-        if(HAS_MUL) load_mul_fin(P, b, mf);
-        init_final(&cf, &C.o);
-        const double nf0 = H.nonfinite;
-        H.huge = 0.0;
-        auto fin = [&]() {
-#pragma unroll
-            for(int i = 0; i < NX; i++) cf.x[i] = xc[i];
-            int r = calcFVariableAux(&cf, HAS_MUL ? &mf : nullptr, &C.o);
-            r &= ddpF(&cf, &C.o);
-            return r;
-        };
-        int r = fin();
-        if(H.huge != 0.0) {
-            H.nonfinite = nf0;
-            H.slow = 1.0;
-            r = fin();
-            H.slow = 0.0;
-        }
-        okc &= r;
-        csum += cf.c;
-        if(live) {
-#pragma unroll
-            for(int i = 0; i < NX; i++) keep[(size_t)i * P.Bp] = cf.x[i];
-        }
-    }
-    const int ok = (okc && H.nonfinite == 0.0) ? 1 : 0;
-    if(live) {
-        P.f[ILQG_F_ALPHA_COST][tile_ix(ILQG_MAX_ALPHA, ai, b)] = csum;
-        P.i[ILQG_I_ALPHA_OK][(size_t)ai * P.Bp + b] = ok;
-    }
-
-    // Selection, as k_select does it (line_search.c:37-75), by the lane of the trajectory's first step size; the
-    // other lanes' values come by wavefront shuffles.  Every lane computes the test of its own step size.
-    const double cost = P.f[ILQG_F_COST][b], dV0 = P.f[ILQG_F_DV0][b], dV1 = P.f[ILQG_F_DV1][b];
-    const double my_dcost = cost - csum;
-    const double my_expected = -alpha * (dV0 + alpha * dV1);
-    const double my_z = (my_expected > 0) ? my_dcost / my_expected : 0.0;
-    const int my_pass = (ok && my_z > O.zMin) ? 1 : 0;
-    double cnew = (a0 > 0) ? P.f[ILQG_F_NEW_COST][b] : 0.0;
-    double dcost = P.f[ILQG_F_DCOST][b], expected = P.f[ILQG_F_EXPECTED][b];
-    int win = -1;
-    for(int i = 0; i < n; i++) {
-        const int src = i * T + t;
-        const int ok_i = __shfl(ok, src);
-        const int pass_i = __shfl(my_pass, src);
-        const double cnew_i = __shfl(csum, src);
-        const double dcost_i = __shfl(my_dcost, src);
-        const double expected_i = __shfl(my_expected, src);
-        if(win < 0) {
-            cnew = cnew_i;
-            if(ok_i) {
-                dcost = dcost_i;
-                expected = expected_i;
-                if(pass_i) win = i;
-            }
-        }
-    }
-    const bool leader = live && lane < T;  // a == 0
-    if(leader) {
-        P.i[ILQG_I_ALPHA_IDX][b] = (win >= 0 ? a0 + win : a0 + n) + 1;
-        P.i[ILQG_I_ACCEPTED][b] = win >= 0 ? 1 : 0;
-        P.f[ILQG_F_NEW_COST][b] = cnew;
-        P.f[ILQG_F_DCOST][b] = dcost;
-        P.f[ILQG_F_EXPECTED][b] = expected;
-    }
-    // to the second stage: one atomicAdd per wavefront
-    const bool more = leader && win < 0 && stage == 0 && a0 + n < O.n_alpha;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(more);
-    if(m != 0ull) {
-        int base = 0;
-        const int first = __builtin_ctzll(m);
-        if(lane == first) base = atomicAdd(P.n_pending_next, __builtin_popcountll(m));
-        base = __shfl(base, first);
-        if(more) P.pending[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = b;
-    }
-}
-
-// The accepted candidates of k_search become the current trajectory: one thread per (step, trajectory) copies the
-// NX + NU doubles of that step from the row of the accepted step size — stage 0's candidates lie by trajectory
-// (P.cand1), stage 1's by entry of the pending list (P.cand).  Consecutive threads = consecutive trajectories: whole
-// lines on both sides.  s1 = step sizes of the first stage.
-__global__ void k_adopt2(DevPtrs P, int s1) {
-    const size_t total = (size_t)(P.N + 1) * P.Bp, stride = (size_t)gridDim.x * blockDim.x;
-    const int np = *P.n_pending;
-    for(size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
-        const int b = (int)(w % P.Bp), k = (int)(w / P.Bp);
-        if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) continue;
-        const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1;
-        if(a >= s1) continue;  // settled by the second stage: below
-        const double *src = P.cand1 + ((size_t)a * (P.N + 1) + k) * CAND_W * P.Bp + b;
-        double *xo = cur_x(P, k, b);
-#pragma unroll
-        for(int i = 0; i < NX; i++) xo[i * XSI] = src[(size_t)i * P.Bp];
-        if(k < P.N) {
-            double *uo = cur_u(P, k, b);
-#pragma unroll
-            for(int i = 0; i < NU; i++) uo[i * XSI] = src[(size_t)(NX + i) * P.Bp];
-        }
-    }
-    const size_t total2 = (size_t)(P.N + 1) * np;
-    for(size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total2; w += stride) {
-        const int e = (int)(w % np), k = (int)(w / np);
-        const int b = P.pending[e];
-        if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) continue;
-        const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1 - s1;
-        const double *src = P.cand + ((size_t)a * (P.N + 1) + k) * CAND_W * P.Bp + e;
-        double *xo = cur_x(P, k, b);
-#pragma unroll
-        for(int i = 0; i < NX; i++) xo[i * XSI] = src[(size_t)i * P.Bp];
-        if(k < P.N) {
-            double *uo = cur_u(P, k, b);
-#pragma unroll
-            for(int i = 0; i < NU; i++) uo[i * XSI] = src[(size_t)(NX + i) * P.Bp];
-        }
-    }
-}
-#endif  // !ILQG_WAVE_MAP
-
 // line_search.c:37-75: the FIRST step size (lowest index) whose forward pass was finite and
 // whose z = dcost/expected exceeds zMin wins.  The scan over the step sizes can be cut in two
 // stages [0,a1) and [a1,n_alpha): a trajectory that finds no acceptable step size in the first
@@ -2526,7 +2284,6 @@ struct ilqg_dev {
     std::vector<PendingRead> pending;
     int *counter;
     size_t cand_bytes;    // size of P.cand
-    size_t cand1_bytes;   // size of P.cand1
     bool winner_done;     // the last search ended with the accepted trajectories in place (two-stage search)
     int *queues;          // wave mapping: the backward kernel's trajectory counters (DevPtrs::queue), QUEUE_CELL ints apart
     int cus;              // compute units of the device
@@ -2943,7 +2700,6 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     if(d->counter) hipFree(d->counter);
     if(d->queues) hipFree(d->queues);
     if(d->P.cand) hipFree(d->P.cand);
-    if(d->P.cand1) hipFree(d->P.cand1);
     if(d->P.pending) hipFree(d->P.pending);
     if(d->P.n_pending) hipFree(d->P.n_pending);
     for(double *p : d->param_bufs) hipFree(p);
@@ -3448,18 +3204,6 @@ int ilqg_dev_backward(ilqg_dev_t *d, int mode) {
 #endif
 }
 
-// (re)allocates a device buffer that must hold `need` bytes; what is queued on `rs` may still use the old one
-static int ensure_buffer(ilqg_dev_t *d, double **buf, size_t *have, size_t need, hipStream_t rs) {
-    if(*have >= need) return 0;
-    HIP_TRY(hipStreamSynchronize(rs));
-    if(*buf) HIP_TRY(hipFree(*buf));
-    *buf = nullptr;
-    *have = 0;
-    HIP_TRY(hipMalloc((void **)buf, need));
-    *have = need;
-    return 0;
-}
-
 // Line search (line_search.c:33-78) in up to two stages, see k_select / k_rollout:
 //   stage 1: step sizes [0, s1) for every trajectory; selection
 //   stage 2: step sizes [s1, n_alpha) for the trajectories still without an acceptable one; selection
@@ -3471,33 +3215,6 @@ int ilqg_dev_search(ilqg_dev_t *d) {
     hipStream_t rs = roll_stream(d);
     if(roll_enter(d)) return 1;
     HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), rs));
-#if !ILQG_WAVE_MAP
-    if(d->O.ls_keep >= 2) {
-        // The step sizes of a trajectory side by side in one wavefront, selection inside the kernel, every roll-out
-        // kept, the accepted ones copied (k_search, k_adopt2): three launches.
-        const int n2 = A - s1;
-        const size_t row = (size_t)d->Bp * (d->N + 1) * CAND_W * sizeof(double);
-        if(ensure_buffer(d, &d->P.cand1, &d->cand1_bytes, row * s1, rs)) return 1;
-        if(n2 > 0 && ensure_buffer(d, &d->P.cand, &d->cand_bytes, row * n2, rs)) return 1;
-        {
-            Timed t(d, ILQG_K_ROLLOUT_SEARCH, rs);
-            const int T = WAVE / s1;
-            hipLaunchKernelGGL(k_search, dim3((d->B + T - 1) / T), dim3(WAVE), 0, rs, d->P, d->O, d->pv, 0, 0, s1);
-        }
-        if(n2 > 0) {  // the grid covers the worst case; wavefronts beyond the pending count return at once
-            Timed t(d, ILQG_K_ROLLOUT_SEARCH2, rs);
-            const int T = WAVE / n2;
-            hipLaunchKernelGGL(k_search, dim3((d->B + T - 1) / T), dim3(WAVE), 0, rs, d->P, d->O, d->pv, 1, s1, n2);
-        }
-        {
-            Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
-            hipLaunchKernelGGL(k_adopt2, dim3(16 * d->cus), dim3(256), 0, rs, d->P, s1);
-        }
-        d->winner_done = true;
-        HIP_TRY(hipGetLastError());
-        return roll_leave(d);
-    }
-#endif
     launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, 0, s1, rs);
     {
         Timed t(d, ILQG_K_SELECT, rs);
@@ -3749,6 +3466,7 @@ struct ilqg_comm {
     std::vector<double *> send;   // per device: its shard of the scalar, padded to `per`
     double *recv;                 // root device: n * per doubles
     int per;
+    bool loopback;                // every shard on ONE device (tests, rehearsals): the gather is device-to-device copies
 };
 
 #define NCCL_TRY(expr)                                                              \
@@ -3781,7 +3499,12 @@ static int comm_fill(ilqg_comm *c, int n, const int *devices, int per) {
     c->devices.assign(devices, devices + n);
     c->comms.assign(n, nullptr);
     c->send.assign(n, nullptr);
-    NCCL_TRY(ncclCommInitAll(c->comms.data(), n, devices));
+    // RCCL wants distinct devices.  Several shards on one device (n > 1, all the same id) is how the sharding, the
+    // offsets and the cost hand-over are rehearsed where only one GPU is present: no communicator, the gather copies.
+    c->loopback = n > 1;
+    for(int g = 1; g < n; g++)
+        if(devices[g] != devices[0]) c->loopback = false;
+    if(!c->loopback) NCCL_TRY(ncclCommInitAll(c->comms.data(), n, devices));
     for(int g = 0; g < n; g++) {
         HIP_TRY(hipSetDevice(devices[g]));
         HIP_TRY(hipMalloc((void **)&c->send[g], (size_t)per * sizeof(double)));
@@ -3821,10 +3544,19 @@ int ilqg_comm_gather(ilqg_comm_t *c, ilqg_dev_t *const *devs, const int *first, 
             g_err = "ilqg_comm_gather: a shard is larger than the communicator's send buffers";
             return 1;
         }
-    NCCL_TRY(ncclGroupStart());
-    for(int g = 0; g < c->n; g++)
-        NCCL_TRY(ncclGather(c->send[g], c->recv, (size_t)c->per, ncclDouble, 0, c->comms[g], devs[g]->stream));
-    NCCL_TRY(ncclGroupEnd());
+    if(c->loopback) {
+        HIP_TRY(hipSetDevice(c->devices[0]));
+        for(int g = 0; g < c->n; g++) {
+            HIP_TRY(hipMemcpyAsync(c->recv + (size_t)g * c->per, c->send[g], (size_t)c->per * sizeof(double),
+                                   hipMemcpyDeviceToDevice, devs[g]->stream));
+            if(g > 0) HIP_TRY(hipStreamSynchronize(devs[g]->stream));
+        }
+    } else {
+        NCCL_TRY(ncclGroupStart());
+        for(int g = 0; g < c->n; g++)
+            NCCL_TRY(ncclGather(c->send[g], c->recv, (size_t)c->per, ncclDouble, 0, c->comms[g], devs[g]->stream));
+        NCCL_TRY(ncclGroupEnd());
+    }
     HIP_TRY(hipSetDevice(c->devices[0]));
     std::vector<double> tmp((size_t)c->n * c->per);
     HIP_TRY(hipMemcpyAsync(tmp.data(), c->recv, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, devs[0]->stream));

@@ -32,9 +32,7 @@ typedef struct {
     int resweep; /* 1: repeat the reference's cost-only sweep after an accepted step (iLQG.c:338) */
     int ls_split; /* step sizes rolled out for every trajectory in the first line-search stage; the rest only
                    * for trajectories still without an acceptable one (0 or >= n_alpha: single stage) */
-    int ls_keep; /* 2 (lane mapping only): the step sizes of a trajectory side by side in one wavefront, selection inside
-                  * the roll-out kernel, every roll-out kept and the accepted ones copied (k_search, k_adopt2);
-                  * 1: the second stage keeps the trajectories it rolls out and runs side by side with the winner pass
+    int ls_keep; /* 1: the second stage keeps the trajectories it rolls out and runs side by side with the winner pass
                   * of the first stage's trajectories; 0: second stage, then one winner pass for all */
     int bw_split; /* 1: the fused backward pass runs on two wavefronts per 64 trajectories (derivatives of step k-1 on
                    * one, Riccati update of step k on the other) where the problem allows it; 0: on one */

@@ -24,8 +24,11 @@ KERNEL_LABELS = {  # (kernel, grid) -> bench.py's kernel label; rollout modes di
 def main():
     argv = sys.argv[1:]
     traffic_json = None
+    config5_json, config5_iters = None, 1
     if argv and argv[0] == "--traffic-json":
         traffic_json, argv = argv[1], argv[2:]
+    if argv and argv[0] == "--config5-json":  # --config5-json FILE ITERATIONS: per-iteration traffic of a bench.py --workload synth run
+        config5_json, config5_iters, argv = argv[1], int(argv[2]), argv[3:]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in argv:
         per_dispatch = collections.defaultdict(dict)
@@ -42,6 +45,26 @@ def main():
         for c in sorted(acc[(k, g)]):
             v = acc[(k, g)][c]
             print("    %-32s n=%3d mean=%.6g" % (c, len(v), sum(v) / len(v)))
+
+    if config5_json:
+        import json
+        out, total = {}, 0.0
+        for (k, g), cs in sorted(acc.items()):
+            if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs or "k_rollout<1>" in k:  # (<1>: the initial roll-out, not part of an iteration)
+                continue
+            if not any(x in k for x in ("k_rollout", "k_backward", "k_derivs")):
+                continue
+            f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
+            w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+            per_launch = 2.0 * f * 1024 + w * 1024
+            per_iter = len(cs["FETCH_SIZE"]) / config5_iters
+            out["%s grid=%s" % (k, g)] = {"hbm_bytes_per_launch": per_launch, "launches_per_iteration": per_iter,
+                                          "fetch_size_KiB_raw": f, "write_size_KiB_raw": w}
+            total += per_launch * per_iter
+        out["iteration"] = {"hbm_bytes": total, "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), both KiB -> bytes",
+                            "iterations_profiled": config5_iters}
+        json.dump(out, open(config5_json, "w"), indent=1, sort_keys=True)
+        print("wrote", config5_json)
 
     if traffic_json:
         import json

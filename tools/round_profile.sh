@@ -28,7 +28,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/traffic_synth/$c -- python3 $R/bench.py --workload synth --steps 2 --warmup 0 --no-cpu-baseline > $OUT/traffic_synth_$c.log 2>&1 || echo "synth $c failed"
 done
 cd $R
-python3 tools/pmc_summary.py $OUT/traffic_synth/FETCH_SIZE $OUT/traffic_synth/WRITE_SIZE > $OUT/traffic_synth.txt 2>&1
+python3 tools/pmc_summary.py --config5-json $OUT/traffic_config5.json 2 $OUT/traffic_synth/FETCH_SIZE $OUT/traffic_synth/WRITE_SIZE > $OUT/traffic_synth.txt 2>&1
 grep -A3 "k_backward_wave\|k_derivs_wave" $OUT/traffic_synth.txt | head -40
 echo "== timelines (kernel trace with time stamps)"
 cd /tmp
