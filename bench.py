@@ -243,7 +243,9 @@ def single_process(args, ilqg, synth):
     m.close()
     iter_bytes = algorithmic_bytes(4, 2, 0)["iteration"] * n_hor * per
     print(json.dumps({
-        "metric": "iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)", "value": K / dt, "unit": "iterations/s",
+        "metric": "iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)", "value": G * K / dt,
+        "unit": "iterations/s", "value_definition": "iterations of a %d-trajectory batch per second, all shards: %d x %d iterations / time" % (per, G, K),
+        "per_gpu_iterations_per_s": K / dt,
         "n_gpus": G, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "CarParking batch=%d per GPU x %d GPU, 8-alpha line search, FULL_DDP=0, first %d iterations "
@@ -324,9 +326,7 @@ def main():
     cost_dev = torch.empty(B, dtype=torch.float64, device=dev)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        pkg.dist.barrier(world, torch.cuda.synchronize)
 
     s.timing(True)  # (events come from a pool filled here: none is created inside the window)
     barrier()
@@ -337,10 +337,7 @@ def main():
     gathered = pkg.dist.gather_costs(cost_dev, rank, world)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = pkg.dist.max_over_ranks(dt, world, dev)  # MAX over ranks
 
     times = s.kernel_times()
     active = s.active()
@@ -355,8 +352,13 @@ def main():
         out = {
             "metric": ("iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)" if car else
                        "iLQG iterations/sec, batch %d synthetic problem (n=16,m=8,N=%d, FULL_DDP=%d)" % (B, n_hor, fd)),
-            "value": K / dt,
+            # whole job: every rank advances its own 65 536-trajectory shard by K iterations (weak scaling), so the
+            # job does world x K batch-iterations in the slowest rank's time
+            "value": pkg.dist.whole_job_rate(K, dt, world),
             "unit": "iterations/s",
+            "value_definition": "iterations of a %d-trajectory batch per second, whole job: %d rank(s) x %d iterations / time of "
+                                "the slowest rank" % (B, world, K),
+            "per_gpu_iterations_per_s": K / dt,
             "n_gpus": world,
             "steps": K,
             "warmup": W,
@@ -432,17 +434,21 @@ def main():
             if bw:
                 out["roofline"] = {
                     "bound": "valu_fp64", "kernel": bw["kernel"],
-                    "achieved": bw["valu_fp64"]["TFLOPs"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": bw["valu_fp64"]["frac_of_peak"],
+                    "achieved": bw["hbm_equivalent"]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": bw["hbm_equivalent"]["frac_of_peak"],
                     "traffic": bw.get("pmc", {}).get("hbm_bytes_per_launch"),
                     "dominant_launch": bw, "second_launch": st1,
-                    "note": "The dominant launch evaluates the derivatives of a step in registers and is bound by fp64 vector "
-                            "issue and the divergence of the box QP, so `achieved` is priced in flop/s (the reference's "
-                            "back_pass arithmetic, %d flop per step and trajectory, backpass_flops(); the derivative "
-                            "callbacks it also evaluates are not counted).  Its HBM side, same launches, same window: "
-                            "hbm_equivalent = the SURVEY 8(d) bytes of the two stages it replaces over its time, pmc = "
-                            "what it really moves.  `alone` (below) = the same kernel with the batch as ONE group and "
-                            "nothing else on the GPU, over the same %d iterations." % (backpass_flops(nx, nu, fd), K)}
+                    "note": "achieved / frac follow the contract's recipe: SURVEY 8(d)'s ALGORITHMIC bytes of the launch "
+                            "(the 1 024 B per step and trajectory of the two stages this kernel replaces x steps x the "
+                            "trajectories of one launch) over its average duration in the timed window.  It is an "
+                            "HBM-EQUIVALENT rate, not a utilisation: the kernel evaluates the derivatives of a step in "
+                            "registers and moves 176 B per step (`traffic`, PMC: dominant_launch.pmc is its real HBM "
+                            "utilisation).  What bounds it is fp64 vector issue and the divergence of the box QP: "
+                            "dominant_launch.valu_fp64 prices the reference's back_pass arithmetic (%d flop per step and "
+                            "trajectory, backpass_flops(); the derivative callbacks it also evaluates are not counted) — "
+                            "one of %d launches that share the chip in the window; `alone` = the same kernel with the batch "
+                            "as ONE group and nothing else on the GPU, over the same %d iterations."
+                            % (backpass_flops(nx, nu, fd), stream_groups, K)}
         if secondary:
             # the dominant kernel ALONE: one group of trajectories, so a launch covers the whole batch and shares the
             # GPU with nothing; the SAME K iterations as the headline window (the kernel grows with the iterations)

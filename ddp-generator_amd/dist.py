@@ -26,6 +26,31 @@ def init(backend, rank, world, device=None):
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
 
+def barrier(world, device_sync=None):
+    """both sides of a timed region: every rank has arrived AND its device has drained (bench.py's contract)"""
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    if device_sync is not None:
+        device_sync()
+
+
+def max_over_ranks(seconds, world, device=None):
+    """the job's time for a region = the slowest rank's (a whole-job rate divides the work of ALL ranks by it)"""
+    if world == 1:
+        return float(seconds)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_rate(units_per_rank, seconds_max, world):
+    """`value` of the bench line: the units ALL ranks processed / the slowest rank's time (weak scaling)"""
+    return units_per_rank * world / seconds_max
+
+
 def gather_costs(cost, rank, world, dst=0):
     """the path's single collective: every rank's cost vector [per_rank] -> rank `dst` [world*per_rank]
     (None on the other ranks).  `cost` may be a zero-copy view of the solver's device memory."""

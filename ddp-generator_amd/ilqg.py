@@ -37,8 +37,9 @@ class IlqgError(RuntimeError):
 
 def library_path(problem="carparking", full_ddp=0, strict=False):
     """strict=True: the -ffp-contract=off build (bit-for-bit CPU parity of the backward pass; tests only);
-    strict="wave": the build of a small problem forced into the one-wavefront-per-trajectory mapping"""
-    suffix = "_wave" if strict == "wave" else ("_strict" if strict else "")
+    strict="wave": the build of a small problem forced into the one-wavefront-per-trajectory mapping;
+    strict="elem": the n = 16 problem built with the one-output-element-per-lane backward step (FMA-free)"""
+    suffix = "_wave" if strict == "wave" else ("_elem" if strict == "elem" else ("_strict" if strict else ""))
     return os.path.join(LIBDIR, "libilqg_%s_fd%d_hip%s.so" % (problem, int(full_ddp), suffix))
 
 

@@ -652,6 +652,44 @@ def test_wave_mapping_synthetic_golden(ilqg, fd, variant):
     s.close()
 
 
+def test_wave_mapping_element_step(ilqg):
+    """The backward step of the wave mapping for problems whose rows do not fit a 16-lane DPP row (N_X > 16 or N_U > 16:
+    one OUTPUT element per lane, both operands from LDS; ilqg_wave.hpp back_step_wave) — compiled for the n = 16 problem
+    with -DILQG_ROW_STEP=0 (libilqg_synth16x8_fd1_hip_elem.so, FMA-free) so that the path is exercised although no
+    shipped problem is that large: the reference's goldens at the single-pass tolerance, and bit for bit the results of
+    the row-mapped FMA-free build (both keep the reference's order of operations), stored tensors, over whole
+    iterations with lambda retries."""
+    g = golden("synth16x8_fd1.npz")
+    N = int(g["n_hor"])
+    s = ilqg.BatchSolver("synth16x8", 1, batch=1, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(ls_split=0), strict="elem")
+    s.init(g["x0"][:1], g["u0"][:1])
+    for tag in ("", "it3_"):
+        s.set_x(g[tag + "x_nom"][None]); s.set_u(g[tag + "u_nom"][None])
+        s.set_scalar("cost", float(g[tag + "cost"]))
+        s.calc_derivs()
+        s.set_scalar("lambda", float(g[tag + "lam"]))
+        s.back_pass(single_sweep=True)
+        assert s.ints("bp_rc")[0] == int(g[tag + "bp_rc"]) == 0
+        l, L = s.gains()
+        assert close(l[0], g[tag + "l"]), worst(l[0], g[tag + "l"])
+        assert close(L[0], g[tag + "L"]), worst(L[0], g[tag + "L"])
+        assert close(s.scalar("dV0")[0], g[tag + "dV"][0]) and close(s.scalar("dV1")[0], g[tag + "dV"][1])
+        assert close(s.scalar("g_norm")[0], g[tag + "g_norm"])
+    s.close()
+    B, iters = 9, 4
+    x0, u0 = syn_inputs(B, N, first=11)
+    out = []
+    for build in (True, "elem"):
+        s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters, fuse_derivs=0, lambdaInit=1e-3),
+                             strict=build)
+        s.init(x0, u0)
+        s.iterate(iters)
+        out.append((s.scalar("cost"), s.x(), s.ints("bp_calls"), s.ints("alpha_idx")))
+        s.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("strict", [False, True])
 def test_factored_tensors_equal_stored_tensors(ilqg, strict):
     """n=16 FULL_DDP: the backward pass that multiplies the tensors out of the generated coefficient tables (records

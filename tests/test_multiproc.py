@@ -35,6 +35,14 @@ def _worker(rank, world, port, out_path):
     else:
         d = Driver(lib_path("oracle"), 500, CAR_PARAMS, dict(max_iter=ITERS))
         cost, _, _ = d.solve_many(x0, u0, 1)
+    # the timed-region protocol of bench.py: barrier on both sides, the job's time is the slowest rank's, the value
+    # is the work of ALL ranks over it
+    pkg.dist.barrier(world)
+    mine = 0.25 * (rank + 1)  # (a made-up duration per rank: rank 1 is the slower one)
+    dt = pkg.dist.max_over_ranks(mine, world)
+    assert dt == 0.25 * world
+    assert pkg.dist.whole_job_rate(ITERS, dt, world) == ITERS * world / dt
+    pkg.dist.barrier(world)
     allc = pkg.dist.gather_costs(torch.from_numpy(cost), rank, world)
     if rank == 0:
         np.save(out_path, allc.numpy())
