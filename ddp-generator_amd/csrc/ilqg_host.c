@@ -274,7 +274,11 @@ ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int gro
     /* first line-search stage: 3 step sizes in the lane mapping (CarParking accepts 85 % of the steps there); 1 in
      * the wave mapping, whose roll-outs are latency bound whatever their number (n = 16 problem: 89 % accepted at
      * the first step size; measured 2.55 it/s with 1, 2.41 with 2, 2.48 with 3, 2.53 with 4) */
-    c->ls_split = dims[7] ? 1 : 3;
+    c->ls_split = dims[7] ? 1 : 4;
+    /* lane mapping: every roll-out of the search is kept and the accepted one becomes the current trajectory by a change
+     * of its location index (k_search / k_commit), with four step sizes in the first stage (one whole cache line per
+     * store of a step size's 16 lanes); wave mapping: second stage beside the winner pass (ROLL_SECOND) */
+    c->ls_keep = dims[7] ? 1 : 2;
     if(groups <= 0) {
         /* lane mapping: 3 (see above).  Wave mapping: 1 — two groups whose backward passes take turns (they share the
          * device's derivative work buffer) so that the roll-outs of one run beside the backward pass of the other were
@@ -382,7 +386,8 @@ int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value
     }
     if(strcmp(name, "ls_keep") == 0) {
         if(n != 1) return fail_msg(c, err_scalar);
-        c->ls_keep = value[0] != 0.0;
+        if(value[0] != 0.0 && value[0] != 1.0 && value[0] != 2.0) return fail_msg(c, "ls_keep must be 0, 1 or 2");
+        c->ls_keep = (int)value[0];
         return 0;
     }
     if(strcmp(name, "fuse_derivs") == 0) {

@@ -282,6 +282,8 @@ struct DevPtrs {
     int *pending;        // trajectories that go to the second line-search stage
     int *n_pending;      // their count (read by the second stage)
     int *n_pending_next; // counter the first-stage selection appends with (same word as n_pending)
+    double *xpl, *upl;   // lane mapping, ls_keep = 2: the kept roll-outs of the first line-search stage, 2 x PLANE_A planes
+    size_t xplane, uplane; //   of the layout and size of X resp. U (doubles per plane); see cur_x
     double *cand;        // second line-search stage: the trajectories its lanes roll out, [step size][step 0..N][x u]
                          //   [entry of pending] (entry fastest: a wavefront stores whole rows) — the accepted one is
                          //   copied, not rolled out again (k_adopt)
@@ -354,13 +356,31 @@ __device__ __forceinline__ size_t ix(const DevPtrs &P, int W, int steps, int k, 
 // (derivatives, backward pass, cost sweep, host copies); and the backward pass, whose steps are long enough to
 // absorb scattered stores, copies each (x_k, u_k) it reads into the record it completes with the gains of step k.
 // The records are therefore current whenever a line search starts.  (Wave mapping: records only.)
+//
+// With ls_keep = 2 the tiled representation exists in 1 + 2 PLANE_A copies of identical layout: the arrays X / U
+// ("home") and two sets of PLANE_A planes that the first stage of the line search rolls its candidates out into (set
+// by set in turn).  ILQG_I_LOC says where the CURRENT trajectory of b is: accepting the roll-out of step size a of a
+// search that wrote set s is `loc = 1 + s PLANE_A + a` — no second roll-out of the winner and no copy (both were
+// measured: the winner pass is a chain of N dependent steps and 376 vector instructions per step and trajectory; a
+// copy out of per-step-size planes reads four lines for every one it needs).  Everything that reads or writes "the
+// current (x, u)" goes through cur_x / cur_u and follows: a lane's base address is chosen once, the strides are
+// those of X / U.  A wavefront of 64 consecutive trajectories then reads pieces of up to PLANE_A + 1 rows per load
+// instead of one whole row — the backward pass moves 48 of these bytes per step and is nowhere near the memory system.
+constexpr int PLANE_A = 4;                // step sizes of a first stage that keeps its roll-outs (ls_split <= PLANE_A)
 constexpr int XSI = WAVE_MAP ? 1 : WAVE;  // distance between components of x / u in that representation
 __device__ __forceinline__ double *cur_x(const DevPtrs &P, int k, int b) {
-    return WAVE_MAP ? nomp(P, k, b) + NOM_X : P.f[ILQG_F_X] + ix(P, NX, P.N + 1, k, 0, b);
+    if(WAVE_MAP) return nomp(P, k, b) + NOM_X;
+    const int loc = P.i[ILQG_I_LOC][b];
+    return (loc ? P.xpl + (size_t)(loc - 1) * P.xplane : P.f[ILQG_F_X]) + ix(P, NX, P.N + 1, k, 0, b);
 }
 __device__ __forceinline__ double *cur_u(const DevPtrs &P, int k, int b) {
-    return WAVE_MAP ? nomp(P, k, b) + NOM_U : P.f[ILQG_F_U] + ix(P, NU, P.N, k, 0, b);
+    if(WAVE_MAP) return nomp(P, k, b) + NOM_U;
+    const int loc = P.i[ILQG_I_LOC][b];
+    return (loc ? P.upl + (size_t)(loc - 1) * P.uplane : P.f[ILQG_F_U]) + ix(P, NU, P.N, k, 0, b);
 }
+// the arrays X / U themselves (host copies, the initial roll-out, trajectories adopted from the second stage)
+__device__ __forceinline__ double *home_x(const DevPtrs &P, int k, int b) { return P.f[ILQG_F_X] + ix(P, NX, P.N + 1, k, 0, b); }
+__device__ __forceinline__ double *home_u(const DevPtrs &P, int k, int b) { return P.f[ILQG_F_U] + ix(P, NU, P.N, k, 0, b); }
 __device__ __forceinline__ size_t cur_xstride(const DevPtrs &P) { return WAVE_MAP ? (size_t)RN : (size_t)NX * P.Bp; }
 __device__ __forceinline__ size_t cur_ustride(const DevPtrs &P) { return WAVE_MAP ? (size_t)RN : (size_t)NU * P.Bp; }
 
@@ -1880,6 +1900,316 @@ __global__ __launch_bounds__(ROLL_BLOCK) ILQG_ROLLOUT_ATTR void k_rollout(DevPtr
     }
 }
 
+#if !ILQG_WAVE_MAP
+// ---------------------------------------------------------------------------
+// Line search that KEEPS what it rolls out (lane mapping, option ls_keep = 2)
+// ---------------------------------------------------------------------------
+// A wavefront takes T = 64 / n trajectories and all n step sizes of the stage, lane = a * T + t (step size a,
+// trajectory t of the wavefront).  What that buys:
+//  * everything the selection of line_search.c:37-75 needs is in the wavefront when the roll-outs end, so it happens
+//    right there, by wavefront shuffles (no k_select launch, no per-alpha round trip through HBM);
+//  * the nominal record of a step is ONE line request per trajectory, shared by its n lanes — which is what leaves
+//    the memory system room for the stores: every lane keeps its roll-out (measured: the first stage with one step
+//    size per ROW of the grid fetches the records once per row, 11 GB per iteration, and slows from 2.15 to 3.26 ms
+//    when it also stores; in this mapping 2.80 -> 2.87 ms);
+//  * with T = 16 (n = 4) the 16 lanes of a step size store 16 consecutive doubles: one whole line.
+// Stage 0 (all trajectories, step sizes [0, n)): the roll-outs go to the planes of set `set` (see cur_x), in the layout
+// of X / U, and the accepted one BECOMES the current trajectory when k_commit changes the trajectory's location index:
+// no second roll-out of the winner (a chain of N dependent steps, 376 vector instructions per step and trajectory) and
+// no copy.  Trajectories without an acceptable step size are appended to P.pending.
+// Stage 1 (the entries of P.pending, step sizes [a0, a0 + n)): kept in P.cand by entry; k_adopt_home copies the
+// accepted ones (few) into X / U.
+// The scan state (last cnew / dcost / expected) is carried from stage to stage exactly as k_select does, so the
+// accepted index and the values left behind are those of one sequential scan (line_search.c:37-75).
+__global__ __launch_bounds__(WAVE) void k_search(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int stage, int a0, int n, int set) {
+    const int lane = threadIdx.x;
+    const int T = WAVE / n;
+    int a = lane / T;
+    const int t = lane - a * T;
+    const bool used = a < n;  // (64 - n * T) lanes have nothing of their own to do: they repeat the last step size
+    if(!used) a = n - 1;
+    const int count = stage ? *P.n_pending : P.B;
+    if((int)blockIdx.x * T >= count) return;
+    const int e = blockIdx.x * T + t;                   // trajectory (stage 0) or entry of the pending list
+    const int ee = e < count ? e : count - 1;           // lanes beyond the end repeat the last one (results dropped)
+    const int b = stage ? P.pending[ee] : ee;
+    const bool live = used && e < count && P.i[ILQG_I_STATUS][b] == ILQG_ST_ACTIVE;
+    if(__builtin_amdgcn_ballot_w64(live) == 0ull) return;
+    const int N = P.N;
+    const int ai = a0 + a;
+    const double alpha = O.alpha[ai];
+    const bool feedback = (alpha != 0.0);  // alpha == 0.0: u = u_nom without feedback (iLQG_func.tem:156-158)
+
+    ILQG_CALLBACKS(C, H);
+    load_penalty_weights(C, P, b);
+    trajEl_t ct;
+    multipliersEl_t mk;
+    multipliersEl_t *const mp = HAS_MUL ? &mk : nullptr;
+    init_running(&ct, &C.o1);
+
+    NomPtrs q;
+    q.x = nomp(P, 0, b) + NOM_X;
+    q.u = nomp(P, 0, b) + NOM_U;
+    q.l = nomp(P, 0, b) + NOM_L;
+    q.K = nomp(P, 0, b) + NOM_K;
+    // where this lane keeps its roll-out: stage 0 in plane (set, a) in the layout of X / U, stage 1 in P.cand by entry
+    double *kx, *ku;
+    size_t kxs, kus, kcs;  // distance between steps (x, u) and between components
+    if(stage) {
+        kx = P.cand + (size_t)a * (N + 1) * CAND_W * P.Bp + ee;
+        ku = kx + (size_t)NX * P.Bp;
+        kxs = kus = (size_t)CAND_W * P.Bp;
+        kcs = P.Bp;
+    } else {
+        const int plane = set * PLANE_A + a;
+        kx = P.xpl + (size_t)plane * P.xplane + ix(P, NX, N + 1, 0, 0, b);
+        ku = P.upl + (size_t)plane * P.uplane + ix(P, NU, N, 0, 0, b);
+        kxs = cur_xstride(P);
+        kus = cur_ustride(P);
+        kcs = XSI;
+    }
+
+    double xc[NX];
+#pragma unroll
+    for(int i = 0; i < NX; i++) xc[i] = q.x[i];  // x0 (iLQG_func.tem:141-142)
+    double csum = 0.0;
+    int okc = 1;
+    NomStep cur;
+    load_nominal<true, 1>(cur, q);
+    drain_memory_ops();
+    for(int k = 0; k < N; k++) {
+        NomPtrs qn;
+        qn.x = q.x + RN;
+        qn.u = q.u + RN;
+        qn.l = q.l + RN;
+        qn.K = q.K + RN;
+        double xin[NX], uin[NU];
+#pragma unroll
+        for(int i = 0; i < NX; i++) xin[i] = xc[i];
+        {   // u = u_nom + alpha*l + L (x - x_nom), state by state (iLQG_func.tem:146-155)
+            double uf[NU];
+#pragma unroll
+            for(int j = 0; j < NU; j++) uf[j] = cur.u[j] + cur.l[j] * alpha;
+#pragma unroll
+            for(int i = 0; i < NX; i++) {
+                const double dx = xin[i] - cur.x[i];
+#pragma unroll
+                for(int j = 0; j < NU; j++) uf[j] += cur.K[j + i * NU] * dx;
+            }
+#pragma unroll
+            for(int j = 0; j < NU; j++) uin[j] = feedback ? uf[j] : cur.u[j];
+        }
+        load_nominal<true, 1>(cur, qn);  // the next step's record is in flight while this one computes
+        if(HAS_MUL) load_mul(P, k, b, mk);
+        double xnext[NX];
+        const double nf0 = H.nonfinite;
+        H.huge = 0.0;
+        auto step = [&]() {
+#pragma unroll
+            for(int i = 0; i < NX; i++) ct.x[i] = xin[i];
+#pragma unroll
+            for(int j = 0; j < NU; j++) ct.u[j] = uin[j];
+            int r = calcXVariableAux(&ct, mp, k, &C.o);
+            clampU(ct.u, &ct, k, C.o.p, N);
+            r &= calcXUVariableAux(&ct, mp, k, &C.o);
+            r &= ddpf(xnext, &ct, k, C.o.p, N);
+            r &= ddpL(&ct, k, &C.o);
+            return r;
+        };
+        int r = step();
+        if(H.huge != 0.0) {  // an argument beyond the fast sin/cos reduction: once more through the library
+            H.nonfinite = nf0;
+            H.slow = 1.0;
+            r = step();
+            H.slow = 0.0;
+        }
+        okc &= r;
+        csum += ct.c;
+        if(live) {  // behind the prefetch in issue order: the wait for the prefetched values leaves these in flight
+#pragma unroll
+            for(int i = 0; i < NX; i++) kx[i * kcs] = ct.x[i];
+#pragma unroll
+            for(int i = 0; i < NU; i++) ku[i * kcs] = ct.u[i];
+        }
+        kx += kxs;
+        ku += kus;
+#pragma unroll
+        for(int i = 0; i < NX; i++) xc[i] = xnext[i];
+        q = qn;
+    }
+    {   // final cost (iLQG_func.tem:179-182)
+        trajFin_t cf;
+        multipliersFin_t mf;
+        if(HAS_MUL) load_mul_fin(P, b, mf);
+        init_final(&cf, &C.o);
+        const double nf0 = H.nonfinite;
+        H.huge = 0.0;
+        auto fin = [&]() {
+#pragma unroll
+            for(int i = 0; i < NX; i++) cf.x[i] = xc[i];
+            int r = calcFVariableAux(&cf, HAS_MUL ? &mf : nullptr, &C.o);
+            r &= ddpF(&cf, &C.o);
+            return r;
+        };
+        int r = fin();
+        if(H.huge != 0.0) {
+            H.nonfinite = nf0;
+            H.slow = 1.0;
+            r = fin();
+            H.slow = 0.0;
+        }
+        okc &= r;
+        csum += cf.c;
+        if(live) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) kx[i * kcs] = cf.x[i];
+        }
+    }
+    const int ok = (okc && H.nonfinite == 0.0) ? 1 : 0;
+    if(live) {
+        P.f[ILQG_F_ALPHA_COST][tile_ix(ILQG_MAX_ALPHA, ai, b)] = csum;
+        P.i[ILQG_I_ALPHA_OK][(size_t)ai * P.Bp + b] = ok;
+    }
+
+    // Selection, as k_select does it (line_search.c:37-75), by the lane of the trajectory's first step size; the
+    // other lanes' values come by wavefront shuffles.  Every lane computes the test of its own step size.
+    const double cost = P.f[ILQG_F_COST][b], dV0 = P.f[ILQG_F_DV0][b], dV1 = P.f[ILQG_F_DV1][b];
+    const double my_dcost = cost - csum;
+    const double my_expected = -alpha * (dV0 + alpha * dV1);
+    const double my_z = (my_expected > 0) ? my_dcost / my_expected : 0.0;
+    const int my_pass = (ok && my_z > O.zMin) ? 1 : 0;
+    double cnew = (a0 > 0) ? P.f[ILQG_F_NEW_COST][b] : 0.0;
+    double dcost = P.f[ILQG_F_DCOST][b], expected = P.f[ILQG_F_EXPECTED][b];
+    int win = -1;
+    for(int i = 0; i < n; i++) {
+        const int src = i * T + t;
+        const int ok_i = __shfl(ok, src);
+        const int pass_i = __shfl(my_pass, src);
+        const double cnew_i = __shfl(csum, src);
+        const double dcost_i = __shfl(my_dcost, src);
+        const double expected_i = __shfl(my_expected, src);
+        if(win < 0) {
+            cnew = cnew_i;
+            if(ok_i) {
+                dcost = dcost_i;
+                expected = expected_i;
+                if(pass_i) win = i;
+            }
+        }
+    }
+    const bool leader = live && lane < T;  // a == 0
+    if(leader) {
+        P.i[ILQG_I_ALPHA_IDX][b] = (win >= 0 ? a0 + win : a0 + n) + 1;
+        P.i[ILQG_I_ACCEPTED][b] = win >= 0 ? 1 : 0;
+        P.f[ILQG_F_NEW_COST][b] = cnew;
+        P.f[ILQG_F_DCOST][b] = dcost;
+        P.f[ILQG_F_EXPECTED][b] = expected;
+    }
+    // to the second stage: one atomicAdd per wavefront
+    const bool more = leader && win < 0 && stage == 0 && a0 + n < O.n_alpha;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(more);
+    if(m != 0ull) {
+        int base = 0;
+        const int first = __builtin_ctzll(m);
+        if(lane == first) base = atomicAdd(P.n_pending_next, __builtin_popcountll(m));
+        base = __shfl(base, first);
+        if(more) P.pending[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = b;
+    }
+}
+
+// After k_search: what has to be COPIED into X / U, one thread per (step, trajectory or entry).
+//  * the trajectories the second stage settled, from P.cand (by entry);
+//  * the trajectories that found no acceptable step size at all while their current trajectory lives in a plane: the
+//    next search writes the set of planes it is in (the sets take turns), so it moves to X / U (rare: 0.5 % of the
+//    trajectories of the benchmark window).
+// The location indices change afterwards (k_commit), when nothing reads the old ones any more.  s1 = step sizes of
+// the first stage.
+__global__ void k_adopt_home(DevPtrs P, int s1) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int np = *P.n_pending, N1 = P.N + 1;
+    const size_t total2 = (size_t)N1 * np;
+    for(size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total2; w += stride) {
+        const int e = (int)(w % np), k = (int)(w / np);
+        const int b = P.pending[e];
+        if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) continue;
+        double *xo = home_x(P, k, b);
+        if(P.i[ILQG_I_ACCEPTED][b]) {
+            const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1 - s1;
+            const double *src = P.cand + ((size_t)a * N1 + k) * CAND_W * P.Bp + e;
+#pragma unroll
+            for(int i = 0; i < NX; i++) xo[i * XSI] = src[(size_t)i * P.Bp];
+            if(k < P.N) {
+                double *uo = home_u(P, k, b);
+#pragma unroll
+                for(int i = 0; i < NU; i++) uo[i * XSI] = src[(size_t)(NX + i) * P.Bp];
+            }
+        } else if(P.i[ILQG_I_LOC][b]) {
+            const double *xs = cur_x(P, k, b);
+#pragma unroll
+            for(int i = 0; i < NX; i++) xo[i * XSI] = xs[i * XSI];
+            if(k < P.N) {
+                const double *us = cur_u(P, k, b);
+                double *uo = home_u(P, k, b);
+#pragma unroll
+                for(int i = 0; i < NU; i++) uo[i * XSI] = us[i * XSI];
+            }
+        }
+    }
+}
+
+// ... and the same for a search without a second stage, where no list of the undecided exists: rejected trajectories
+// whose current trajectory lives in a plane move to X / U.  One thread per (step, trajectory).
+__global__ void k_rejected_home(DevPtrs P) {
+    const size_t total = (size_t)(P.N + 1) * P.Bp, stride = (size_t)gridDim.x * blockDim.x;
+    for(size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
+        const int b = (int)(w % P.Bp), k = (int)(w / P.Bp);
+        if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || P.i[ILQG_I_ACCEPTED][b] || !P.i[ILQG_I_LOC][b]) continue;
+        const double *xs = cur_x(P, k, b);
+        double *xo = home_x(P, k, b);
+#pragma unroll
+        for(int i = 0; i < NX; i++) xo[i * XSI] = xs[i * XSI];
+        if(k < P.N) {
+            const double *us = cur_u(P, k, b);
+            double *uo = home_u(P, k, b);
+#pragma unroll
+            for(int i = 0; i < NU; i++) uo[i * XSI] = us[i * XSI];
+        }
+    }
+}
+
+// The new location of every trajectory that took part in the search: the plane of the accepted step size of the first
+// stage, else X / U (adopted from the second stage, or moved there by the kernels above, or there already).
+__global__ void k_commit(DevPtrs P, int s1, int set) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
+    const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1;
+    if(P.i[ILQG_I_ACCEPTED][b])
+        P.i[ILQG_I_LOC][b] = (a < s1) ? 1 + set * PLANE_A + a : 0;
+    else
+        P.i[ILQG_I_LOC][b] = 0;
+}
+
+// every current trajectory into X / U (before the host reads or writes them, before an initial roll-out): copy, then
+// the caller clears the location indices
+__global__ void k_all_home(DevPtrs P) {
+    const size_t total = (size_t)(P.N + 1) * P.Bp, stride = (size_t)gridDim.x * blockDim.x;
+    for(size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
+        const int b = (int)(w % P.Bp), k = (int)(w / P.Bp);
+        if(b >= P.B || !P.i[ILQG_I_LOC][b]) continue;
+        const double *xs = cur_x(P, k, b);
+        double *xo = home_x(P, k, b);
+#pragma unroll
+        for(int i = 0; i < NX; i++) xo[i * XSI] = xs[i * XSI];
+        if(k < P.N) {
+            const double *us = cur_u(P, k, b);
+            double *uo = home_u(P, k, b);
+#pragma unroll
+            for(int i = 0; i < NU; i++) uo[i * XSI] = us[i * XSI];
+        }
+    }
+}
+#endif  // !ILQG_WAVE_MAP
+
 // line_search.c:37-75: the FIRST step size (lowest index) whose forward pass was finite and
 // whose z = dcost/expected exceeds zMin wins.  The scan over the step sizes can be cut in two
 // stages [0,a1) and [a1,n_alpha): a trajectory that finds no acceptable step size in the first
@@ -2284,6 +2614,8 @@ struct ilqg_dev {
     std::vector<PendingRead> pending;
     int *counter;
     size_t cand_bytes;    // size of P.cand
+    size_t xpl_bytes, upl_bytes;  // sizes of P.xpl / P.upl (ls_keep = 2)
+    int loc_set;          // the set of planes current trajectories may live in (-1: none, all in X / U)
     bool winner_done;     // the last search ended with the accepted trajectories in place (two-stage search)
     int *queues;          // wave mapping: the backward kernel's trajectory counters (DevPtrs::queue), QUEUE_CELL ints apart
     int cus;              // compute units of the device
@@ -2548,6 +2880,7 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
     d->pinned = nullptr;
     d->pinned_bytes = 0;
     d->timing = false;
+    d->loc_set = -1;
     memset(d->t_ms, 0, sizeof(d->t_ms));
     memset(d->t_n, 0, sizeof(d->t_n));
     memset(&d->P, 0, sizeof(d->P));
@@ -2700,6 +3033,8 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     if(d->counter) hipFree(d->counter);
     if(d->queues) hipFree(d->queues);
     if(d->P.cand) hipFree(d->P.cand);
+    if(d->P.xpl) hipFree(d->P.xpl);
+    if(d->P.upl) hipFree(d->P.upl);
     if(d->P.pending) hipFree(d->P.pending);
     if(d->P.n_pending) hipFree(d->P.n_pending);
     for(double *p : d->param_bufs) hipFree(p);
@@ -2859,8 +3194,11 @@ static int der_io(ilqg_dev *d, double *host_rw, const double *host_ro) {
 }
 #endif
 
+static int all_home(ilqg_dev_t *d);
+
 int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps) {
     HIP_TRY(hipSetDevice(d->device));
+    if(has_tiled_copy(field) && all_home(d)) return 1;
     const FieldInfo fi = field_info(field);
     if(steps < 1 || steps > field_steps(d, field)) {
         g_err = "ilqg_dev_write_steps: bad step count";
@@ -2905,6 +3243,7 @@ int ilqg_dev_write_steps(ilqg_dev_t *d, int field, const double *host, int steps
 
 int ilqg_dev_read(ilqg_dev_t *d, int field, double *host) {
     HIP_TRY(hipSetDevice(d->device));
+    if(has_tiled_copy(field) && all_home(d)) return 1;
     const FieldInfo fi = field_info(field);
     const int steps = field_steps(d, field);
     const size_t n = (size_t)d->B * steps * fi.wh;
@@ -2990,6 +3329,31 @@ int ilqg_dev_io_end(ilqg_dev_t *d) {
         return 1;                                                        \
     }
 
+// (re)allocates a device buffer that must hold `need` bytes; what is queued on `rs` may still use the old one
+static int ensure_buffer(ilqg_dev_t *d, double **buf, size_t *have, size_t need, hipStream_t rs) {
+    if(*have >= need) return 0;
+    HIP_TRY(hipStreamSynchronize(rs));
+    if(*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc((void **)buf, need));
+    *have = need;
+    return 0;
+}
+
+// ls_keep = 2: every current trajectory back into the arrays X / U (the host is about to read or write them, an
+// initial roll-out is about to store there, or a search that does not keep its roll-outs follows)
+static int all_home(ilqg_dev_t *d) {
+#if !ILQG_WAVE_MAP
+    if(d->loc_set < 0) return 0;
+    hipLaunchKernelGGL(k_all_home, dim3(8 * d->cus), dim3(256), 0, d->stream, d->P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(d->P.i[ILQG_I_LOC], 0, d->Bp * sizeof(int), d->stream));
+    d->loc_set = -1;
+#endif
+    return 0;
+}
+
 int ilqg_dev_reset(ilqg_dev_t *d) {
     HIP_TRY(hipSetDevice(d->device));
     hipLaunchKernelGGL(k_reset, grid1(d->Bp, 256), dim3(256), 0, d->stream, d->P, d->O);
@@ -3033,6 +3397,7 @@ static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_
 int ilqg_dev_rollout_init(ilqg_dev_t *d) {
     NEED_PARAMS(d);
     HIP_TRY(hipSetDevice(d->device));
+    if(all_home(d)) return 1;  // (the controls the roll-out starts from are read where they currently are)
     if(roll_enter(d)) return 1;
     HIP_TRY(hipMemsetAsync(d->P.i[ILQG_I_STATUS], 0, d->Bp * sizeof(int), roll_stream(d)));
     launch_rollout(d, ROLL_INIT, ILQG_K_ROLLOUT_INIT, 0, 1, roll_stream(d));
@@ -3213,6 +3578,47 @@ int ilqg_dev_search(ilqg_dev_t *d) {
     const int A = d->O.n_alpha;
     const int s1 = (d->O.ls_split > 0 && d->O.ls_split < A) ? d->O.ls_split : A;
     hipStream_t rs = roll_stream(d);
+#if !ILQG_WAVE_MAP
+    if(d->O.ls_keep >= 2 && s1 <= PLANE_A && WAVE / s1 >= 1 && (A == s1 || WAVE / (A - s1) >= 1)) {
+        // Every roll-out of the search is kept and the accepted one becomes the current trajectory by a change of its
+        // location index (k_search, k_adopt_home, k_commit; see cur_x).
+        const int n2 = A - s1, set = (d->loc_set == 0) ? 1 : 0;
+        const size_t xplane = (size_t)(d->N + 1) * NX * d->Bp, uplane = (size_t)d->N * NU * d->Bp;
+        if(ensure_buffer(d, &d->P.xpl, &d->xpl_bytes, 2 * PLANE_A * xplane * sizeof(double), rs)) return 1;
+        if(ensure_buffer(d, &d->P.upl, &d->upl_bytes, 2 * PLANE_A * uplane * sizeof(double), rs)) return 1;
+        d->P.xplane = xplane;
+        d->P.uplane = uplane;
+        if(n2 > 0 && ensure_buffer(d, &d->P.cand, &d->cand_bytes, (size_t)d->Bp * n2 * (d->N + 1) * CAND_W * sizeof(double), rs))
+            return 1;
+        HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), rs));
+        {
+            Timed t(d, ILQG_K_ROLLOUT_SEARCH, rs);
+            const int T = WAVE / s1;
+            hipLaunchKernelGGL(k_search, dim3((d->B + T - 1) / T), dim3(WAVE), 0, rs, d->P, d->O, d->pv, 0, 0, s1, set);
+        }
+        if(n2 > 0) {  // the grid covers the worst case; wavefronts beyond the pending count return at once
+            {
+                Timed t(d, ILQG_K_ROLLOUT_SEARCH2, rs);
+                const int T = WAVE / n2;
+                hipLaunchKernelGGL(k_search, dim3((d->B + T - 1) / T), dim3(WAVE), 0, rs, d->P, d->O, d->pv, 1, s1, n2, set);
+            }
+            Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
+            hipLaunchKernelGGL(k_adopt_home, dim3(8 * d->cus), dim3(256), 0, rs, d->P, s1);
+        } else {
+            Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
+            hipLaunchKernelGGL(k_rejected_home, dim3(8 * d->cus), dim3(256), 0, rs, d->P);
+        }
+        {
+            Timed t(d, ILQG_K_SELECT, rs);
+            hipLaunchKernelGGL(k_commit, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, s1, set);
+        }
+        d->loc_set = set;
+        d->winner_done = true;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if(all_home(d)) return 1;  // the searches below store accepted trajectories in place: in X / U
+#endif
     if(roll_enter(d)) return 1;
     HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), rs));
     launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, 0, s1, rs);

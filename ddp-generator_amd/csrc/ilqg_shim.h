@@ -32,7 +32,10 @@ typedef struct {
     int resweep; /* 1: repeat the reference's cost-only sweep after an accepted step (iLQG.c:338) */
     int ls_split; /* step sizes rolled out for every trajectory in the first line-search stage; the rest only
                    * for trajectories still without an acceptable one (0 or >= n_alpha: single stage) */
-    int ls_keep; /* 1: the second stage keeps the trajectories it rolls out and runs side by side with the winner pass
+    int ls_keep; /* 2 (lane mapping; the default there): every roll-out of the line search is KEPT where it is rolled out
+                  * and an accepted trajectory becomes the current one by a change of its location index (k_search,
+                  * k_commit): no second roll-out of the winner, no copy;
+                  * 1: the second stage keeps the trajectories it rolls out and runs side by side with the winner pass
                   * of the first stage's trajectories; 0: second stage, then one winner pass for all */
     int bw_split; /* 1: the fused backward pass runs on two wavefronts per 64 trajectories (derivatives of step k-1 on
                    * one, Riccati update of step k on the other) where the problem allows it; 0: on one */
@@ -89,6 +92,8 @@ enum {
     ILQG_I_BP_RC,       /* result of the last backward sweep: 0 ok, 1 failed */
     ILQG_I_RESWEEP,     /* set by the update: 2 = update multipliers + cost sweep (iLQG.c:337-338), 1 = cost
                          * sweep after a rejected step raised the penalty weights (iLQG.c:345-349), 0 = none */
+    ILQG_I_LOC,         /* lane mapping, ls_keep = 2: where the CURRENT (x, u) of the trajectory lives: 0 = the arrays
+                         * X / U, p > 0 = plane p - 1 of the kept roll-outs of the line search (see cur_x) */
     ILQG_I_ALPHA_OK,    /* [n_alpha] forward pass finite?                */
     ILQG_I_COUNT
 };

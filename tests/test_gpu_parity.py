@@ -316,35 +316,48 @@ def test_fused_and_unfused_iterations_agree(ilqg, synth, fuse):
     assert np.abs(out[0][2] - out[1][2]).max() < 1e-7
 
 
-def test_line_search_staging_and_resweep_do_not_change_results(ilqg, synth):
+@pytest.mark.parametrize("strict", [False, True])
+def test_line_search_staging_and_resweep_do_not_change_results(ilqg, synth, strict):
     """two-stage line search (any split) == all step sizes for every trajectory, bit for bit;
-    the reference's cost-only re-sweep after an accepted step returns the same cost bit for bit"""
+    the reference's cost-only re-sweep after an accepted step returns the same cost bit for bit.
+    Three implementations of the stages (option ls_keep): 2 = every roll-out is kept where it is rolled out and the
+    accepted one becomes the current trajectory by a change of its location index (k_search / k_commit; the lane
+    mapping's default, first stages of up to 4 step sizes); 1 = second stage beside the re-rolled winners of the
+    first, its own winners copied; 0 = everything accepted is rolled out again.  Within one implementation every split
+    gives identical bits; ACROSS implementations (different kernels around the same generated callbacks) identical
+    bits are required of the -ffp-contract=off build, the product build may contract multiply-adds differently and is
+    held to the single-pass tolerance."""
     B, iters = 200, 6
     x0, u0 = synth.car_batch(B, first=900)
-    ref = None
-    # (two stages: the second one keeps what it rolls out and the accepted trajectories are copied, ls_keep = 1, or
-    # everything accepted is rolled out again, ls_keep = 0; one stage: rolled out again)
-    for opts in (dict(ls_split=0, resweep=1), dict(ls_split=3, resweep=0), dict(ls_split=4, resweep=0), dict(ls_split=1, resweep=0),
-                 dict(ls_split=5, resweep=1), dict(ls_split=8, resweep=0), dict(ls_split=3, ls_keep=0), dict(ls_split=2, ls_keep=0)):
+    ref = {}
+    for opts in (dict(ls_split=4, resweep=1), dict(ls_split=3, resweep=0), dict(ls_split=1, resweep=0), dict(ls_split=2, resweep=1),
+                 dict(ls_split=0, ls_keep=1), dict(ls_split=3, ls_keep=1), dict(ls_split=1, ls_keep=1), dict(ls_split=5, ls_keep=1, resweep=1),
+                 dict(ls_split=8, ls_keep=1), dict(ls_split=3, ls_keep=0), dict(ls_split=2, ls_keep=0)):
         s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS,
-                             opts=dict(max_iter=iters, fuse_derivs=0, **opts))
+                             opts=dict(max_iter=iters, fuse_derivs=0, **opts), strict=strict)
         s.init(x0, u0)
         hist = []
-        for _ in range(iters):
+        for it in range(iters):
             s.iterate(1)
             hist.append((s.ints("alpha_idx").copy(), s.ints("accepted").copy(), s.scalar("cost").copy(),
                          s.scalar("new_cost").copy(), s.scalar("lambda").copy()))
+            if it == 2:
+                s.x()  # a host read in the middle: the current trajectories go back to X / U and the solve goes on
         out = (hist, s.x(), s.u())
         s.close()
-        if ref is None:
-            ref = out
+        family = 2 if opts.get("ls_keep", 2) == 2 else 1
+        if family not in ref:
+            ref[family] = out
             idx = np.concatenate([h[0] for h in hist])
-            assert idx.max() >= 4  # the second stage is exercised
-            continue
-        for h, hr in zip(out[0], ref[0]):
-            for a, r in zip(h, hr):
-                assert np.array_equal(a, r), opts
-        assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2]), opts
+            assert idx.max() >= 4  # with splits below 4 the second stage is exercised
+        for fam, r in ref.items():
+            exact = strict or fam == family
+            same = np.array_equal if exact else close
+            for h, hr in zip(out[0], r[0]):
+                assert np.array_equal(h[0], hr[0]) and np.array_equal(h[1], hr[1]), opts  # step index, accepted: always
+                for a, q in zip(h[2:], hr[2:]):
+                    assert same(a, q), (opts, fam)
+            assert same(out[1], r[1]) and same(out[2], r[2]), (opts, fam)
 
 
 @pytest.mark.parametrize("fd", [0, 1])
