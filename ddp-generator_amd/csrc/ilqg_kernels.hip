@@ -1921,7 +1921,22 @@ __global__ __launch_bounds__(ROLL_BLOCK) ILQG_ROLLOUT_ATTR void k_rollout(DevPtr
 // accepted ones (few) into X / U.
 // The scan state (last cnew / dcost / expected) is carried from stage to stage exactly as k_select does, so the
 // accepted index and the values left behind are those of one sequential scan (line_search.c:37-75).
-__global__ __launch_bounds__(WAVE) void k_search(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int stage, int a0, int n, int set) {
+#ifndef ILQG_SEARCH_OCC  // wavefronts of k_search per SIMD the register allocation must allow
+#define ILQG_SEARCH_OCC 1
+#endif
+// DMA: the nominal records of the wavefront's T trajectories reach the lanes through LDS.  Every lane needs the whole
+// record of its trajectory (x, u, l, L: 128 bytes for CarParking) in every step, and with per-lane loads the n lanes of
+// a trajectory each pull it through the CU's vector-memory path: 8 KB per wavefront and step for 2 KB of data, on the
+// path that also carries the stores of the kept roll-outs — measured, the stores alone cost 0.65 of the kernel's 3.07
+// ms, so that path and not the arithmetic bounds the kernel.  Instead the records are fetched ONCE, by
+// global_load_lds_dwordx4 straight into LDS (no staging registers): lane i of load m moves the 16-byte piece
+// q = 64 m + i, and the pieces lie piece-major, q = j T + r (piece j of record r), so that the T lanes of a step size
+// read T consecutive 16-byte pieces (no bank conflicts).  Two buffers: the records of step k+2 are on their way while
+// step k+1's are read.  Used when a step's pieces fit DMA_LOADS loads (T * RN / 2 <= 64 DMA_LOADS).
+constexpr int DMA_LOADS = 3;
+template <int stage, bool DMA>
+__global__ __launch_bounds__(WAVE, ILQG_SEARCH_OCC) void k_search(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int a0, int n, int set) {
+    extern __shared__ __attribute__((aligned(16))) double s_rec[];  // DMA: [2][T * RN] doubles
     const int lane = threadIdx.x;
     const int T = WAVE / n;
     int a = lane / T;
@@ -1952,21 +1967,58 @@ __global__ __launch_bounds__(WAVE) void k_search(DevPtrs P, ilqg_dev_opts_t O, P
     q.u = nomp(P, 0, b) + NOM_U;
     q.l = nomp(P, 0, b) + NOM_L;
     q.K = nomp(P, 0, b) + NOM_K;
+    // DMA: this lane's pieces (see above) — source of load m at step 0, and whether the lane takes part in it
+    constexpr int PIECES = RN / 2;
+    const double *dsrc[DMA_LOADS];
+    bool dact[DMA_LOADS];
+    if(DMA) {
+#pragma unroll
+        for(int m = 0; m < DMA_LOADS; m++) {
+            const int qq = m * WAVE + lane;
+            const int j = qq / T, r = qq - j * T;
+            dact[m] = qq < T * PIECES;
+            const int br = __shfl(b, r < T ? r : 0);  // trajectory of record r: held by lane r (step size 0)
+            dsrc[m] = nomp(P, 0, br) + 2 * (j < PIECES ? j : 0);
+        }
+    }
+    auto dma_issue = [&](int buf) {  // the records of the step dsrc points at -> LDS buffer buf; dsrc moves on one step
+#pragma unroll
+        for(int m = 0; m < DMA_LOADS; m++) {
+            if(dact[m])
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)dsrc[m],
+                                                 (__attribute__((address_space(3))) void *)(s_rec + (size_t)buf * T * RN + m * WAVE * 2),
+                                                 16, 0, 0);
+            dsrc[m] += RN;
+        }
+    };
+    auto dma_read = [&](NomStep &c, int buf) {  // this lane's record out of LDS buffer buf
+        double rec[RN];
+        const double *base = s_rec + (size_t)buf * T * RN + 2 * t;
+#pragma unroll
+        for(int j = 0; j < PIECES; j++) {
+            rec[2 * j] = base[(size_t)j * T * 2];
+            rec[2 * j + 1] = base[(size_t)j * T * 2 + 1];
+        }
+#pragma unroll
+        for(int i = 0; i < NX; i++) c.x[i] = rec[NOM_X + i];
+#pragma unroll
+        for(int i = 0; i < NU; i++) c.u[i] = rec[NOM_U + i];
+#pragma unroll
+        for(int i = 0; i < NU; i++) c.l[i] = rec[NOM_L + i];
+#pragma unroll
+        for(int i = 0; i < NXU; i++) c.K[i] = rec[NOM_K + i];
+    };
     // where this lane keeps its roll-out: stage 0 in plane (set, a) in the layout of X / U, stage 1 in P.cand by entry
     double *kx, *ku;
-    size_t kxs, kus, kcs;  // distance between steps (x, u) and between components
+    const size_t kxs = stage ? (size_t)CAND_W * P.Bp : cur_xstride(P), kus = stage ? kxs : cur_ustride(P);  // between steps
+    const size_t kcs = stage ? (size_t)P.Bp : (size_t)XSI;                                                 // between components
     if(stage) {
         kx = P.cand + (size_t)a * (N + 1) * CAND_W * P.Bp + ee;
         ku = kx + (size_t)NX * P.Bp;
-        kxs = kus = (size_t)CAND_W * P.Bp;
-        kcs = P.Bp;
     } else {
         const int plane = set * PLANE_A + a;
         kx = P.xpl + (size_t)plane * P.xplane + ix(P, NX, N + 1, 0, 0, b);
         ku = P.upl + (size_t)plane * P.uplane + ix(P, NU, N, 0, 0, b);
-        kxs = cur_xstride(P);
-        kus = cur_ustride(P);
-        kcs = XSI;
     }
 
     double xc[NX];
@@ -1975,7 +2027,14 @@ __global__ __launch_bounds__(WAVE) void k_search(DevPtrs P, ilqg_dev_opts_t O, P
     double csum = 0.0;
     int okc = 1;
     NomStep cur;
-    load_nominal<true, 1>(cur, q);
+    if(DMA) {
+        dma_issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dma_read(cur, 0);
+        dma_issue(1);  // step 1 (N >= 2)
+    } else {
+        load_nominal<true, 1>(cur, q);
+    }
     drain_memory_ops();
     for(int k = 0; k < N; k++) {
         NomPtrs qn;
@@ -1999,7 +2058,7 @@ __global__ __launch_bounds__(WAVE) void k_search(DevPtrs P, ilqg_dev_opts_t O, P
 #pragma unroll
             for(int j = 0; j < NU; j++) uin[j] = feedback ? uf[j] : cur.u[j];
         }
-        load_nominal<true, 1>(cur, qn);  // the next step's record is in flight while this one computes
+        if(!DMA) load_nominal<true, 1>(cur, qn);  // the next step's record is in flight while this one computes
         if(HAS_MUL) load_mul(P, k, b, mk);
         double xnext[NX];
         const double nf0 = H.nonfinite;
@@ -2025,12 +2084,19 @@ __global__ __launch_bounds__(WAVE) void k_search(DevPtrs P, ilqg_dev_opts_t O, P
         }
         okc &= r;
         csum += ct.c;
-        if(live) {  // behind the prefetch in issue order: the wait for the prefetched values leaves these in flight
+        if(DMA) {
+            // Outstanding here: the kept roll-out of step k-1 and the records of step k+1, both issued a whole step
+            // ago.  The wait stands BEFORE this step's stores so that it never waits for a store just issued.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dma_read(cur, (k + 1) & 1);
+        }
+        if(live) {  // (!DMA: behind the prefetch in issue order: the wait for the prefetched values leaves these in flight)
 #pragma unroll
             for(int i = 0; i < NX; i++) kx[i * kcs] = ct.x[i];
 #pragma unroll
             for(int i = 0; i < NU; i++) ku[i * kcs] = ct.u[i];
         }
+        if(DMA && k + 2 <= N) dma_issue(k & 1);  // (that buffer held step k: read at the end of step k-1)
         kx += kxs;
         ku += kus;
 #pragma unroll
@@ -3594,13 +3660,21 @@ int ilqg_dev_search(ilqg_dev_t *d) {
         {
             Timed t(d, ILQG_K_ROLLOUT_SEARCH, rs);
             const int T = WAVE / s1;
-            hipLaunchKernelGGL(k_search, dim3((d->B + T - 1) / T), dim3(WAVE), 0, rs, d->P, d->O, d->pv, 0, 0, s1, set);
+            const bool dma = T * (RN / 2) <= WAVE * DMA_LOADS && !getenv("ILQG_NO_DMA");
+            if(dma)
+                hipLaunchKernelGGL((k_search<0, true>), dim3((d->B + T - 1) / T), dim3(WAVE), 2 * T * RN * sizeof(double), rs, d->P, d->O, d->pv, 0, s1, set);
+            else
+                hipLaunchKernelGGL((k_search<0, false>), dim3((d->B + T - 1) / T), dim3(WAVE), 0, rs, d->P, d->O, d->pv, 0, s1, set);
         }
         if(n2 > 0) {  // the grid covers the worst case; wavefronts beyond the pending count return at once
             {
                 Timed t(d, ILQG_K_ROLLOUT_SEARCH2, rs);
                 const int T = WAVE / n2;
-                hipLaunchKernelGGL(k_search, dim3((d->B + T - 1) / T), dim3(WAVE), 0, rs, d->P, d->O, d->pv, 1, s1, n2, set);
+                const bool dma = T * (RN / 2) <= WAVE * DMA_LOADS && !getenv("ILQG_NO_DMA");
+                if(dma)
+                    hipLaunchKernelGGL((k_search<1, true>), dim3((d->B + T - 1) / T), dim3(WAVE), 2 * T * RN * sizeof(double), rs, d->P, d->O, d->pv, s1, n2, set);
+                else
+                    hipLaunchKernelGGL((k_search<1, false>), dim3((d->B + T - 1) / T), dim3(WAVE), 0, rs, d->P, d->O, d->pv, s1, n2, set);
             }
             Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
             hipLaunchKernelGGL(k_adopt_home, dim3(8 * d->cus), dim3(256), 0, rs, d->P, s1);
