@@ -41,9 +41,10 @@
  * each with its own HIP stream, advanced alternately.  Every kernel of an iteration is either a chain of n_hor
  * dependent time steps with one wavefront per 64 trajectories — too few wavefronts to keep a SIMD busy — or wide
  * and throughput bound; with two groups in flight the chain of one overlaps with the wide kernel of the other
- * (measured at 65 536 CarParking trajectories, 20 iterations: 9.0 ms per iteration with one group, 8.8 with two,
- * 8.0-8.2 with three, 9.2 with four).  Trajectories are independent, so results do not depend
- * on the grouping. */
+ * (measured at 65 536 CarParking trajectories, 20 iterations, round 3 with the line search that keeps its roll-outs:
+ * 167-170 it/s with one group, 171-174 with two, 162-167 with three, 178-183 with four; five and more share the
+ * process's four hardware queues and collapse to 118, with GPU_MAX_HW_QUEUES=8 they reach 159-171).  Trajectories are
+ * independent, so results do not depend on the grouping. */
 #define ILQG_MAX_GROUPS 4
 struct ilqg_batch {
     ilqg_dev_t *dev[ILQG_MAX_GROUPS];
@@ -247,9 +248,7 @@ const char *ilqg_batch_error(const ilqg_batch_t *c) { return c ? c->err : g_crea
 
 static int param_len(const ilqg_batch_t *c, int i) { return paramdesc[i]->size == -1 ? c->N + 1 : paramdesc[i]->size; }
 
-/* groups = 0: automatic (ILQG_GROUPS in the environment, else 3 for large batches in the lane mapping: measured
- * 128-131 it/s with 1 group, 136.6 with 3, 136-140 with 4 depending on the box; beyond the 4 hardware queues of a
- * process the streams share queues and it collapses to 94) */
+/* groups = 0: automatic (ILQG_GROUPS in the environment, else 4 for large batches in the lane mapping, see above) */
 ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int groups) {
     int i, g, per, dims[8];
     ilqg_batch_t *c = (ilqg_batch_t *)calloc(1, sizeof(*c));
@@ -280,13 +279,13 @@ ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int gro
      * store of a step size's 16 lanes); wave mapping: second stage beside the winner pass (ROLL_SECOND) */
     c->ls_keep = dims[7] ? 1 : 2;
     if(groups <= 0) {
-        /* lane mapping: 3 (see above).  Wave mapping: 1 — two groups whose backward passes take turns (they share the
+        /* lane mapping: 4 (see above).  Wave mapping: 1 — two groups whose backward passes take turns (they share the
          * device's derivative work buffer) so that the roll-outs of one run beside the backward pass of the other were
          * measured SLOWER on the n = 16 problem (1.98 -> 1.53 it/s): a workgroup of the backward kernel takes all the
          * registers of its CU (8 wavefronts x 250) and the whole LDS, so roll-out wavefronts (256 registers) find no
          * room beside it, while each group's roll-outs keep the full chain latency of n_hor steps. */
         const char *e = getenv("ILQG_GROUPS");
-        groups = e ? atoi(e) : ((batch >= 8192 && !dims[7]) ? 3 : 1);
+        groups = e ? atoi(e) : ((batch >= 8192 && !dims[7]) ? 4 : 1);
     }
 
     if(groups < 1) groups = 1;

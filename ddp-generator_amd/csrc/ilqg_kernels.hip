@@ -2348,9 +2348,16 @@ __global__ void k_adopt(DevPtrs P, int a0, int n2) {
 }
 
 // iLQG.c:311-361 and the loop bookkeeping of iLQG.c:239,365-378
-__global__ void k_update(DevPtrs P, ilqg_dev_opts_t O) {
+// commit_s1 >= 0: also what k_commit does (the search of this iteration left the change of location to this kernel);
+// reset_pending: the counter of the pending list is cleared for the next search (nothing reads it any more)
+__global__ void k_update(DevPtrs P, ilqg_dev_opts_t O, int commit_s1, int commit_set, int reset_pending) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if(b == 0 && reset_pending) *P.n_pending = 0;
     if(b >= P.B) return;
+    if(!WAVE_MAP && commit_s1 >= 0 && P.i[ILQG_I_STATUS][b] == ILQG_ST_ACTIVE) {
+        const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1;
+        P.i[ILQG_I_LOC][b] = (P.i[ILQG_I_ACCEPTED][b] && a < commit_s1) ? 1 + commit_set * PLANE_A + a : 0;
+    }
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) {  // finished, possibly in this iteration's backward pass
         P.i[ILQG_I_RESWEEP][b] = 0;
         return;
@@ -2682,6 +2689,8 @@ struct ilqg_dev {
     size_t cand_bytes;    // size of P.cand
     size_t xpl_bytes, upl_bytes;  // sizes of P.xpl / P.upl (ls_keep = 2)
     int loc_set;          // the set of planes current trajectories may live in (-1: none, all in X / U)
+    bool defer_commit, commit_pending, pending_zero;  // ls_keep = 2: k_update commits / clears the pending counter
+    int commit_s1, commit_set;
     bool winner_done;     // the last search ended with the accepted trajectories in place (two-stage search)
     int *queues;          // wave mapping: the backward kernel's trajectory counters (DevPtrs::queue), QUEUE_CELL ints apart
     int cus;              // compute units of the device
@@ -3656,7 +3665,8 @@ int ilqg_dev_search(ilqg_dev_t *d) {
         d->P.uplane = uplane;
         if(n2 > 0 && ensure_buffer(d, &d->P.cand, &d->cand_bytes, (size_t)d->Bp * n2 * (d->N + 1) * CAND_W * sizeof(double), rs))
             return 1;
-        HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), rs));
+        if(!d->pending_zero) HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), rs));
+        d->pending_zero = false;
         {
             Timed t(d, ILQG_K_ROLLOUT_SEARCH, rs);
             const int T = WAVE / s1;
@@ -3682,7 +3692,11 @@ int ilqg_dev_search(ilqg_dev_t *d) {
             Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
             hipLaunchKernelGGL(k_rejected_home, dim3(8 * d->cus), dim3(256), 0, rs, d->P);
         }
-        {
+        if(d->defer_commit) {  // inside ilqg_dev_iterate: the update kernel of this iteration commits
+            d->commit_pending = true;
+            d->commit_s1 = s1;
+            d->commit_set = set;
+        } else {
             Timed t(d, ILQG_K_SELECT, rs);
             hipLaunchKernelGGL(k_commit, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, s1, set);
         }
@@ -3695,6 +3709,7 @@ int ilqg_dev_search(ilqg_dev_t *d) {
 #endif
     if(roll_enter(d)) return 1;
     HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), rs));
+    d->pending_zero = false;
     launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, 0, s1, rs);
     {
         Timed t(d, ILQG_K_SELECT, rs);
@@ -3754,7 +3769,10 @@ int ilqg_dev_update(ilqg_dev_t *d) {
     if(roll_enter(d)) return 1;
     {
         Timed t(d, ILQG_K_UPDATE, rs);
-        hipLaunchKernelGGL(k_update, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O);
+        const int reset = (!WAVE_MAP && d->defer_commit) ? 1 : 0;
+        hipLaunchKernelGGL(k_update, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O, d->commit_pending ? d->commit_s1 : -1, d->commit_set, reset);
+        d->commit_pending = false;
+        d->pending_zero = reset != 0;
     }
     if(HAS_MUL) {
         Timed t(d, ILQG_K_MULTIPLIERS, rs);
@@ -3766,6 +3784,11 @@ int ilqg_dev_update(ilqg_dev_t *d) {
 }
 
 int ilqg_dev_iterate(ilqg_dev_t *d, int n) {
+    struct Defer {  // search and update of one iteration are launched together: the update commits for the search
+        ilqg_dev_t *d;
+        explicit Defer(ilqg_dev_t *d_) : d(d_) { d->defer_commit = true; }
+        ~Defer() { d->defer_commit = false; }
+    } defer(d);
     for(int it = 0; it < n; it++) {
         if(d->O.fuse_derivs || WAVE_MAP) {  // wave mapping: derivatives + sweep chunk by chunk
             if(ilqg_dev_backward(d, 2)) return 1;

@@ -46,7 +46,7 @@ int ilqg_device_count(void);
 ilqg_batch_t *ilqg_batch_create(int device, int batch, int n_hor); /* NULL on failure (ilqg_batch_error(NULL)) */
 /* The batch is advanced as `groups` independent sets of consecutive trajectories, each on its own HIP stream,
  * so that the latency-bound kernels of one set overlap with the throughput-bound ones of another.  Results do
- * not depend on it.  groups = 0 (what ilqg_batch_create passes): ILQG_GROUPS from the environment, else 3 for
+ * not depend on it.  groups = 0 (what ilqg_batch_create passes): ILQG_GROUPS from the environment, else 4 for
  * batches >= 8192 in the one-lane-per-trajectory mapping (measured best at 65 536 trajectories), else 1.  At most 4. */
 ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int groups);
 /* Builds with one wavefront per trajectory (N_X > 8) keep the derivative records of the trajectories in flight in ONE
@@ -65,15 +65,18 @@ const char *ilqg_batch_error(const ilqg_batch_t *c);
  *   "fuse_derivs" 0/1: ilqg_batch_iterate/solve evaluate the derivatives inside the backward
  *                 kernel instead of materialising the records in HBM.  Default 1, 0 for problems
  *                 with multipliers (measured faster there); same results either way.
- *   "ls_split"    default 3 (1 for builds with one wavefront per trajectory): step sizes
+ *   "ls_split"    default 4 (1 for builds with one wavefront per trajectory): step sizes
  *                 alpha[0..ls_split) are rolled out for every trajectory,
  *                 the remaining ones only for trajectories that found none acceptable among
  *                 them; 0 = all step sizes for every trajectory.  The accepted step size is the
  *                 same either way (first acceptable, line_search.c:37-60).
- *   "ls_keep"     default 1: the second stage runs side by side with the roll-out that stores the
- *                 accepted trajectories of the first stage, and keeps what it rolls out, so that
- *                 its own accepted trajectories are copied instead of rolled out once more;
- *                 0: second stage, then one storing roll-out for all.  Same results either way.
+ *   "ls_keep"     default 2 in the one-lane-per-trajectory mapping (first stages of up to 4 step sizes): every
+ *                 roll-out of the line search is kept where it is rolled out and the accepted one becomes the
+ *                 current trajectory by a change of its location index — no second roll-out, no copy;
+ *                 1 (default with one wavefront per trajectory): the second stage runs side by side with the
+ *                 roll-out that stores the accepted trajectories of the first stage, and keeps what it rolls
+ *                 out, so that its own accepted trajectories are copied instead of rolled out once more;
+ *                 0: second stage, then one storing roll-out for all.  Same results in all three.
  *   "bw_split"    default 0.  1: the fused backward pass runs on two wavefronts per 64 trajectories
  *                 (derivatives of step k-1 on one, Riccati update of step k on the other, hand-over in
  *                 LDS) where the problem allows it (no multipliers, constant limits).  Same results;

@@ -840,13 +840,13 @@ def test_properties_at_benchmark_size(ilqg, synth, mapping):
 
 
 def test_properties_at_full_benchmark_batch(ilqg, synth, oracle_built):
-    """B = 65 536 (BASELINE config 3, the batch the metric is quoted on; three stream groups by default): accepted
+    """B = 65 536 (BASELINE config 3, the batch the metric is quoted on; four stream groups by default): accepted
     steps reduce the cost, every trajectory is still active inside the window, trajectories picked from different
     groups and tiles equal the same trajectories solved alone, and one of them equals the CPU oracle."""
     B, iters = 65536, 3
     x0, u0 = synth.car_batch(B)
     s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=50))
-    assert s.groups() == 3
+    assert s.groups() == 4
     s.init(x0, u0)
     prev = s.scalar("cost")
     for _ in range(iters):
@@ -856,7 +856,7 @@ def test_properties_at_full_benchmark_batch(ilqg, synth, oracle_built):
         assert np.all(c[acc] < prev[acc]) and np.array_equal(c[~acc], prev[~acc])
         prev = c
     assert s.active() == B and np.all(s.ints("iterations") == iters)
-    pick = [0, 63, 64, 21887, 21888, 40000, 43775, 43776, 65535]   # group and tile boundaries (groups of 21 888)
+    pick = [0, 15, 16, 63, 64, 16383, 16384, 40000, 49151, 49152, 65535]   # group (16 384), tile and search-wavefront (16) boundaries
     x_big, u_big = s.x()[pick], s.u()[pick]
     small = ilqg.BatchSolver("carparking", 0, batch=len(pick), n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(max_iter=50))
     small.init(x0[pick], u0[pick])
