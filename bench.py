@@ -274,9 +274,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resweep", type=int, default=-1, help="-1: library default (off without multipliers)")
     ap.add_argument("--fuse-derivs", type=int, default=1)
-    ap.add_argument("--ls-split", type=int, default=None, help="default: the library's (3; 1 in the wave mapping)")
+    ap.add_argument("--ls-split", type=int, default=None, help="default: the library's (4; 1 in the wave mapping)")
     ap.add_argument("--bw-split", type=int, default=0, help="1: fused backward pass on two wavefronts per 64 trajectories (measured: no gain)")
-    ap.add_argument("--ls-keep", type=int, default=None, help="default: the library's (1); 0: second line-search stage and winner pass one after the other")
+    ap.add_argument("--ls-keep", type=int, default=None,
+                    help="default: the library's (2 in the lane mapping: every roll-out kept, the accepted one relocated; 1 in the wave "
+                         "mapping: second stage beside the re-rolled winners); 0: second stage, then winner pass")
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary runs (kernels alone, config 5, drop-in)")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--single-process", action="store_true",
@@ -373,7 +375,7 @@ def main():
                        "batch_per_gpu": B, "n_hor": n_hor, "n_x": nx, "n_u": nu, "full_ddp": fd,
                        "mapping": ("one wavefront per trajectory" if wave_mapping else
                                    "one lane per trajectory (64 trajectories per wavefront)"),
-                       "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split if args.ls_split is not None else "library default (3; 1 in the wave mapping)", "ls_keep": args.ls_keep if args.ls_keep is not None else "library default (1)", "bw_split": args.bw_split, "resweep": args.resweep,
+                       "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split if args.ls_split is not None else "library default (4; 1 in the wave mapping)", "ls_keep": args.ls_keep if args.ls_keep is not None else "library default (2: roll-outs kept, accepted one relocated; 1 in the wave mapping)", "bw_split": args.bw_split, "resweep": args.resweep,
                        "stream_groups": stream_groups,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             # PRIMARY: the whole iteration against the HBM roofline, algorithmic bytes of SURVEY 8(d)
@@ -430,7 +432,10 @@ def main():
 
             bw = launch_object("k_backward[fused derivs]", alg["k_derivs"] + alg["k_backward"], backpass_flops(nx, nu, fd),
                                (nx + nu) * 8 + (nx + 2 * nu + nx * nu) * 8)
-            st1 = launch_object("k_rollout[search]", alg["k_rollout[search]"], 0, (nx + 2 * nu + nx * nu) * 8)
+            # first stage of the line search: k_search (ls_keep = 2: every roll-out kept: + 4 x 48 B written per step) or
+            # the legacy rows of k_rollout
+            st1 = (launch_object("k_search[stage 1]", alg["k_rollout[search]"], 0, (nx + 2 * nu + nx * nu) * 8 + 4 * (nx + nu) * 8)
+                   or launch_object("k_rollout[search]", alg["k_rollout[search]"], 0, (nx + 2 * nu + nx * nu) * 8))
             if bw:
                 out["roofline"] = {
                     "bound": "valu_fp64", "kernel": bw["kernel"],

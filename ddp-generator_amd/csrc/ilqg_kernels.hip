@@ -2914,7 +2914,7 @@ const char *ilqg_dev_kernel_name(int k) {
     static const char *names[ILQG_K_COUNT] = {"k_derivs", "k_backward", "k_rollout[search]", "k_select",
                                               "k_rollout[winner]", "k_update", "k_rollout[cost]", "k_rollout[init]",
                                               "layout kernels", "k_backward[fused derivs]", "k_rollout[stage 2 | winner]",
-                                              "k_multipliers"};
+                                              "k_multipliers", "k_search[stage 1]", "k_search[stage 2]", "k_adopt_home + k_commit"};
     return (k >= 0 && k < ILQG_K_COUNT) ? names[k] : "?";
 }
 
@@ -3668,7 +3668,7 @@ int ilqg_dev_search(ilqg_dev_t *d) {
         if(!d->pending_zero) HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), rs));
         d->pending_zero = false;
         {
-            Timed t(d, ILQG_K_ROLLOUT_SEARCH, rs);
+            Timed t(d, ILQG_K_SEARCH, rs);
             const int T = WAVE / s1;
             const bool dma = T * (RN / 2) <= WAVE * DMA_LOADS && !getenv("ILQG_NO_DMA");
             if(dma)
@@ -3678,7 +3678,7 @@ int ilqg_dev_search(ilqg_dev_t *d) {
         }
         if(n2 > 0) {  // the grid covers the worst case; wavefronts beyond the pending count return at once
             {
-                Timed t(d, ILQG_K_ROLLOUT_SEARCH2, rs);
+                Timed t(d, ILQG_K_SEARCH2, rs);
                 const int T = WAVE / n2;
                 const bool dma = T * (RN / 2) <= WAVE * DMA_LOADS && !getenv("ILQG_NO_DMA");
                 if(dma)
@@ -3686,10 +3686,10 @@ int ilqg_dev_search(ilqg_dev_t *d) {
                 else
                     hipLaunchKernelGGL((k_search<1, false>), dim3((d->B + T - 1) / T), dim3(WAVE), 0, rs, d->P, d->O, d->pv, s1, n2, set);
             }
-            Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
+            Timed t(d, ILQG_K_ADOPT, rs);
             hipLaunchKernelGGL(k_adopt_home, dim3(8 * d->cus), dim3(256), 0, rs, d->P, s1);
         } else {
-            Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
+            Timed t(d, ILQG_K_ADOPT, rs);
             hipLaunchKernelGGL(k_rejected_home, dim3(8 * d->cus), dim3(256), 0, rs, d->P);
         }
         if(d->defer_commit) {  // inside ilqg_dev_iterate: the update kernel of this iteration commits
@@ -3697,7 +3697,7 @@ int ilqg_dev_search(ilqg_dev_t *d) {
             d->commit_s1 = s1;
             d->commit_set = set;
         } else {
-            Timed t(d, ILQG_K_SELECT, rs);
+            Timed t(d, ILQG_K_ADOPT, rs);
             hipLaunchKernelGGL(k_commit, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, s1, set);
         }
         d->loc_set = set;

@@ -112,6 +112,9 @@ enum {
     ILQG_K_BACKWARD_FUSED,
     ILQG_K_ROLLOUT_SEARCH2,
     ILQG_K_MULTIPLIERS,
+    ILQG_K_SEARCH,   /* ls_keep = 2: k_search on all trajectories (first stage) */
+    ILQG_K_SEARCH2,  /*             k_search on the pending list (second stage) */
+    ILQG_K_ADOPT,    /*             k_adopt_home / k_rejected_home, k_commit */
     ILQG_K_COUNT
 };
 

@@ -18,6 +18,10 @@ KERNEL_LABELS = {  # (kernel, grid) -> bench.py's kernel label; rollout modes di
     "k_derivs": "k_derivs",
     "void k_backward<0>": "k_backward",
     "void k_backward<2>": "k_backward[fused derivs]",
+    "void k_search<0, true>": "k_search[stage 1]",
+    "void k_search<0, false>": "k_search[stage 1]",
+    "void k_search<1, true>": "k_search[stage 2]",
+    "void k_search<1, false>": "k_search[stage 2]",
 }
 
 
