@@ -422,7 +422,7 @@ def main():
                     o["pmc"] = {"hbm_bytes_per_launch": pmc, "GBs": pmc / (avg_ms * 1e-3) / 1e9,
                                 "frac_of_peak": pmc / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                          "command, tools/collect_traffic.sh; per launch of a third of the batch; not "
+                                          "command, tools/collect_traffic.sh; per launch of one of the stream groups; not "
                                           "collected in this run)"}
                 if flops_per_step:
                     o["valu_fp64"] = {"algorithmic_flops_per_launch": flops_per_step * n_hor * per_launch,
