@@ -2276,6 +2276,248 @@ __global__ void k_all_home(DevPtrs P) {
 }
 #endif  // !ILQG_WAVE_MAP
 
+#if ILQG_WAVE_MAP && defined(ILQG_ROLLOUT_PARTS)
+// ---------------------------------------------------------------------------
+// Roll-outs of the wave mapping on ILQG_ROLLOUT_PARTS wavefronts per 64 trajectories (round 3)
+// ---------------------------------------------------------------------------
+// k_rollout gives a trajectory one lane, and a lane walks the generated scalar code of a step alone: for the n = 16
+// problem 32 sin / cos evaluations and ~800 multiply-adds, 35 us per step, on a `trajEl_t` in scratch memory — with
+// 16 384 trajectories that is 256 wavefronts on 1 024 SIMDs, each a chain of 1 000 such steps (35 + 56 ms of a 370 ms
+// iteration, the chip three quarters idle).  The generated file now offers the step in N_X independent PARTS
+// (ilqg_step_part, tools/gen_problem.py: part r = component r of the dynamics with the auxiliaries it needs and every
+// N_X-th summand of the running cost; the assignments are the ones of calcX*VariableAux / ddpf / ddpL, unchanged).
+// Here a workgroup of RW wavefronts (N_X, or N_X / 2 above 8) takes 64 trajectories, wavefront = part(s), lane = trajectory:
+//   phase 1  wavefront j < N_U: input j, u_j = u_nom_j + alpha l_j + sum_i L(j,i) (x_i - x_nom_i) (the order of
+//            iLQG_func.tem:146-155), its operands prefetched one step ahead;            -> LDS, barrier
+//   phase 2  every wavefront: all inputs out of LDS, clampU, its part of the step;      -> LDS, barrier
+//   then     every wavefront reads the new state; the first one adds the cost summands in the order of ddpL's sum.
+// The scalar code path per wavefront shrinks to 2/16 of the step and no `trajEl_t` lives in scratch.  Same expressions,
+// same order: the -ffp-contract=off build gives the bits of k_rollout (the product build differs from it by contractions
+// across the cost summands, which are added one by one here).  Measured (config 5): first stage 34.9 -> 13.8 ms, second
+// launch 56 -> 50 ms, 2.69 -> 2.89 it/s.  A wavefront still issues ~1 400 instructions per step (625 per component: 66
+// 64-bit literals = 132 scalar moves, two sin / cos calls that each evaluate both functions): instruction bound, not
+// memory bound (prefetch placement, an LDS-only barrier instead of __syncthreads: no change).  Tried: one part per
+// wavefront (16 wavefronts, 128 registers: 164 spilled); sin / cos inlined instead of called, with the huge-argument
+// case repeated by the scalar kernel (no calls, 22 spills, but 10 000 instructions of straight-line code for the 16
+// cases — more than the instruction cache: 34 / 91 ms, slower than the calls).
+// Modes as k_rollout's general instantiation: ROLL_SEARCH (row = step size), ROLL_WINNER, ROLL_SEARCH_LIST,
+// ROLL_SECOND (row 0 = winners, rows 1.. = second stage, kept in P.cand).
+constexpr int RP = ILQG_ROLLOUT_PARTS, RT = ILQG_ROLLOUT_TERMS;
+constexpr int RPX = (NX + 2 + 1) / 2 * 2, RPU = (NU + 2 + 1) / 2 * 2, RPT = (RT + 2 + 1) / 2 * 2;  // LDS rows per lane, padded
+// wavefronts per workgroup: one per part up to 8 (512 threads leave a wavefront 256 registers: the phase 1 operands
+// of the next step and the state are ~100 of them; with 16 wavefronts, 128 registers each, 164 were spilled), else two
+// parts per wavefront
+constexpr int RW = RP > 8 ? (RP + 1) / 2 : RP;
+constexpr int PPW = (RP + RW - 1) / RW;  // parts per wavefront
+constexpr int JPW = (NU + RW - 1) / RW;  // inputs per wavefront in phase 1
+// Workgroup barrier for data handed over in LDS only: __syncthreads() also waits for every global load and store in
+// flight (vmcnt(0)), i.e. for the operands prefetched for the next step and for the roll-out's stores — twice per step
+// (measured: 14 us per step with it).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ __launch_bounds__(WAVE *RW) void k_rollout_parts(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int mode, int a0) {
+    __shared__ __attribute__((aligned(16))) double s_x[WAVE][RPX];
+    __shared__ __attribute__((aligned(16))) double s_u[WAVE][RPU];
+    __shared__ __attribute__((aligned(16))) double s_t[WAVE][RPT];
+    __shared__ int s_bad[RW][WAVE];
+    const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    int b = blockIdx.x * WAVE + lane;
+    int ai = a0 + blockIdx.y;
+    double *keep = nullptr;
+    int second_row = -1;
+    bool live = true;
+    if(mode == ROLL_SECOND) {
+        if(blockIdx.y == 0) {
+            mode = ROLL_WINNER;
+        } else {
+            mode = ROLL_SEARCH_LIST;
+            ai = a0 + blockIdx.y - 1;
+            second_row = blockIdx.y - 1;
+        }
+    }
+    if(mode == ROLL_SEARCH_LIST) {
+        // (the rows start their walk over the list at different workgroups, see k_rollout)
+        const int nb = gridDim.x, rows = (int)gridDim.y - (second_row >= 0 ? 1 : 0);
+        const int row = second_row >= 0 ? second_row : (int)blockIdx.y;
+        const int first = (int)(((long long)row * nb) / rows);
+        const int e0 = ((int)blockIdx.x + first) % nb * WAVE, np = *P.n_pending;
+        if(e0 >= np) return;  // the whole workgroup
+        const int e = e0 + lane;
+        live = e < np;
+        if(second_row >= 0) keep = P.cand + (size_t)second_row * (P.N + 1) * CAND_W * P.Bp + e;
+        b = P.pending[live ? e : e0];
+    }
+    if(b >= P.B) {
+        live = false;
+        b = P.B - 1;
+    }
+    const int N = P.N;
+    double alpha = 0.0;
+    if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) live = false;
+    if(mode == ROLL_WINNER) {
+        if(!P.i[ILQG_I_ACCEPTED][b]) live = false;
+        const int idx = P.i[ILQG_I_ALPHA_IDX][b] - 1;
+        alpha = O.alpha[(live && idx >= 0 && idx < ILQG_MAX_ALPHA) ? idx : 0];
+    } else {
+        alpha = O.alpha[ai];
+    }
+    if(__builtin_amdgcn_ballot_w64(live) == 0ull) return;  // (the same lanes in every wavefront: the whole workgroup)
+    const bool store = (mode == ROLL_WINNER) && live;
+    const bool feedback = (alpha != 0.0);
+
+    ILQG_CALLBACKS(C, H);
+    const double *rec = nomp(P, 0, b);  // this trajectory's record of the current step
+    double x[NX];
+#pragma unroll
+    for(int i = 0; i < NX; i++) x[i] = rec[NOM_X + i];
+    // phase 1 operands of this wavefront's input(s) part, part + RW, ..., one step ahead
+    double nx[NX], nk[JPW][NX], nu_nom[JPW], nl[JPW];
+    auto fetch = [&](const double *r) {
+        if(part < NU) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) nx[i] = r[NOM_X + i];
+#pragma unroll
+            for(int q = 0; q < JPW; q++) {
+                const int ju = (part + q * RW < NU) ? part + q * RW : part;
+#pragma unroll
+                for(int i = 0; i < NX; i++) nk[q][i] = r[NOM_K + ju + i * NU];
+                nu_nom[q] = r[NOM_U + ju];
+                nl[q] = r[NOM_L + ju];
+            }
+        }
+    };
+    fetch(rec);
+    double csum = 0.0;
+    int bad = 0;
+    double *xo = cur_x(P, 0, b), *uo = cur_u(P, 0, b);
+    drain_memory_ops();
+    for(int k = 0; k < N; k++) {
+        // ---- phase 1: this wavefront's input
+        if(part < NU) {
+#pragma unroll
+            for(int q = 0; q < JPW; q++) {
+                if(part + q * RW < NU) {
+                    double uf = nu_nom[q] + nl[q] * alpha;
+#pragma unroll
+                    for(int i = 0; i < NX; i++) uf += nk[q][i] * (x[i] - nx[i]);
+                    s_u[lane][part + q * RW] = feedback ? uf : nu_nom[q];
+                }
+            }
+        }
+        rec += RN;
+        fetch(rec);  // step k+1 (the records have a step N: its gains are not used)
+        lds_barrier();
+        // ---- phase 2: all inputs, the box, this wavefront's part of the step
+        double u[NU];
+#pragma unroll
+        for(int j = 0; j < NU; j++) u[j] = s_u[lane][j];
+        {
+            double xb[NX];  // clampU reads t->x, the first member of the element (iLQG_problem.tem:24)
+#pragma unroll
+            for(int i = 0; i < NX; i++) xb[i] = x[i];
+            clampU(u, reinterpret_cast<trajEl_t *>(xb), k, C.o.p, N);
+        }
+        int bad_step = 0;
+        // this wavefront's part(s) of the step.  (sin / cos stay calls in the large generated files, which handle their
+        // huge arguments themselves; small files go through the hooks as everywhere else)
+        auto parts = [&]() {
+#pragma unroll
+            for(int q = 0; q < PPW; q++)
+                if(part + q * RW < RP) ilqg_step_part(part + q * RW, &s_x[lane][0], &s_t[lane][0], &bad_step, x, u, k, C.o.p, N);
+        };
+#if ILQG_UNIFORM_GUARDS
+        parts();
+#else
+        H.huge = 0.0;
+        parts();
+        if(H.huge != 0.0) {  // an argument beyond the fast sin/cos reduction: once more through the library
+            H.slow = 1.0;
+            bad_step = 0;
+            parts();
+            H.slow = 0.0;
+        }
+#endif
+        bad |= bad_step;
+        // what the roll-out stores of step k: by the last wavefront (it holds x_k and the clamped u_k like all others)
+        if(part == RW - 1) {
+            if(store) {
+#pragma unroll
+                for(int i = 0; i < NX; i++) xo[i] = x[i];
+#pragma unroll
+                for(int i = 0; i < NU; i++) uo[i] = u[i];
+            } else if(keep && live) {
+#pragma unroll
+                for(int i = 0; i < NX; i++) keep[(size_t)i * P.Bp] = x[i];
+#pragma unroll
+                for(int i = 0; i < NU; i++) keep[(size_t)(NX + i) * P.Bp] = u[i];
+            }
+        }
+        xo += RN;
+        uo += RN;
+        if(keep) keep += (size_t)CAND_W * P.Bp;
+        lds_barrier();
+        // ---- the new state; the cost of the step in the order of ddpL's sum
+#pragma unroll
+        for(int i = 0; i < NX; i++) x[i] = s_x[lane][i];
+        if(part == 0) {
+            double c = s_t[lane][0];
+#pragma unroll
+            for(int m = 1; m < RT; m++) c = c + s_t[lane][m];
+            csum += c;
+        }
+        // (the next step's phase 1 writes s_u, read before this barrier pair's second barrier by everybody; its
+        // phase 2 writes s_x / s_t only behind the next first barrier, which every wavefront reaches after these reads)
+    }
+    s_bad[part][lane] = bad;
+    __syncthreads();
+    if(part != 0) return;
+    int okc = 1;
+#pragma unroll
+    for(int q = 0; q < RW; q++) okc &= (s_bad[q][lane] == 0);
+    {   // final cost (iLQG_func.tem:179-182)
+        trajFin_t cf;
+        init_final(&cf, &C.o);
+        auto fin = [&]() {
+#pragma unroll
+            for(int i = 0; i < NX; i++) cf.x[i] = x[i];
+            int r = calcFVariableAux(&cf, nullptr, &C.o);
+            r &= ddpF(&cf, &C.o);
+            return r;
+        };
+        int r = 1;
+#if ILQG_UNIFORM_GUARDS
+        if(okc) r = run_guarded(fin);
+#else
+        const double nf0 = H.nonfinite;
+        H.huge = 0.0;
+        r = fin();
+        if(H.huge != 0.0) {
+            H.nonfinite = nf0;
+            H.slow = 1.0;
+            r = fin();
+            H.slow = 0.0;
+        }
+#endif
+        okc &= r;
+        csum += cf.c;
+        if(store) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) xo[i] = cf.x[i];
+        } else if(keep && live) {
+#pragma unroll
+            for(int i = 0; i < NX; i++) keep[(size_t)i * P.Bp] = cf.x[i];
+        }
+    }
+    const int ok = (okc && H.nonfinite == 0.0) ? 1 : 0;
+    if(!live) return;
+    if(mode == ROLL_WINNER) {
+        P.f[ILQG_F_NEW_COST][b] = csum;
+    } else {
+        P.f[ILQG_F_ALPHA_COST][tile_ix(ILQG_MAX_ALPHA, ai, b)] = csum;
+        P.i[ILQG_I_ALPHA_OK][(size_t)ai * P.Bp + b] = ok;
+    }
+}
+#endif  // ILQG_WAVE_MAP && ILQG_ROLLOUT_PARTS
+
 // line_search.c:37-75: the FIRST step size (lowest index) whose forward pass was finite and
 // whose z = dcost/expected exceeds zMin wins.  The scan over the step sizes can be cut in two
 // stages [0,a1) and [a1,n_alpha): a trajectory that finds no acceptable step size in the first
@@ -3464,6 +3706,10 @@ static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_
         hipLaunchKernelGGL(k_rollout<RK_INIT>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
     else if(mode == ROLL_COST)
         hipLaunchKernelGGL(k_rollout<RK_COST>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
+#if ILQG_WAVE_MAP && defined(ILQG_ROLLOUT_PARTS)
+    else if(!HAS_MUL && !getenv("ILQG_NO_ROLLOUT_PARTS"))  // the generated file offers the step in parts: several wavefronts per 64 trajectories
+        hipLaunchKernelGGL(k_rollout_parts, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE * RW), 0, stream, d->P, d->O, d->pv, mode, a0);
+#endif
     else
         hipLaunchKernelGGL(k_rollout<RK_GENERAL>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
     return 0;

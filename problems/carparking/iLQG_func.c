@@ -585,3 +585,51 @@ int update_multipliers(tOptSet *o, int init) {
 int get_g_size() { return 0; }
 
 int calcG(double g[], trajEl_t *t, int k, double **p) { return 1; }
+
+/* ---- additive: one step of forward_pass in ILQG_ROLLOUT_PARTS independent parts (batched back-ends that put
+ * several wavefronts on a trajectory's step; the reference's solver never calls this).  Part r: component r of the
+ * dynamics and the summands r, r + N_X, ... of the running cost, term[] indexed by their place in ddpL's sum:
+ * t->c == ((term[0] + term[1]) + term[2]) + ...  A NaN or Inf in a guarded value sets bad[0]. */
+#define ILQG_ROLLOUT_PARTS 4
+#define ILQG_ROLLOUT_TERMS 4
+#ifndef ILQG_PART_SIN  /* a back-end may define these two before including this file */
+#define ILQG_PART_SIN(v) sin(v)
+#define ILQG_PART_COS(v) cos(v)
+#endif
+#ifndef ILQG_PART_FN  /* ... and the function's storage class / attributes */
+#define ILQG_PART_FN static
+#endif
+typedef struct {
+    double s;
+} ilqg_step_aux_t;
+ILQG_PART_FN void ilqg_step_part(int part, double x_next[], double term[], int bad[], const double *x, const double *u, int k, double **p, int N) {
+    ilqg_step_aux_t aux_, *const t= &aux_;
+
+    switch(part) {
+    case 0:
+        aux_s= p[3][0] + p[4][0]*x[3]*ILQG_PART_COS(u[0]) - sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(ILQG_PART_SIN(u[0])*ILQG_PART_SIN(u[0])));
+        if(!((aux_s) - (aux_s) == 0.0)) bad[0]= 1;
+        x_next[0]= aux_s*ILQG_PART_COS(x[2]) + x[0];
+        if(!((x_next[0]) - (x_next[0]) == 0.0)) bad[0]= 1;
+        term[0]= p[1][0]*(u[0]*u[0]);
+        break;
+    case 1:
+        aux_s= p[3][0] + p[4][0]*x[3]*ILQG_PART_COS(u[0]) - sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(ILQG_PART_SIN(u[0])*ILQG_PART_SIN(u[0])));
+        if(!((aux_s) - (aux_s) == 0.0)) bad[0]= 1;
+        x_next[1]= aux_s*ILQG_PART_SIN(x[2]) + x[1];
+        if(!((x_next[1]) - (x_next[1]) == 0.0)) bad[0]= 1;
+        term[1]= p[1][1]*(u[1]*u[1]);
+        break;
+    case 2:
+        x_next[2]= x[2] + asin(p[4][0]*x[3]*ILQG_PART_SIN(u[0])/p[3][0]);
+        if(!((x_next[2]) - (x_next[2]) == 0.0)) bad[0]= 1;
+        term[2]= p[2][0]*(-p[8][0] + sqrt((p[8][0]*p[8][0]) + (x[0]*x[0])));
+        break;
+    case 3:
+        x_next[3]= p[4][0]*u[1] + x[3];
+        if(!((x_next[3]) - (x_next[3]) == 0.0)) bad[0]= 1;
+        term[3]= p[2][1]*(-p[8][1] + sqrt((p[8][1]*p[8][1]) + (x[1]*x[1])));
+        break;
+    default: break;
+    }
+}

@@ -477,3 +477,49 @@ int update_multipliers(tOptSet *o, int init) {
 int get_g_size() { return 0; }
 
 int calcG(double g[], trajEl_t *t, int k, double **p) { return 1; }
+
+/* ---- additive: one step of forward_pass in ILQG_ROLLOUT_PARTS independent parts (batched back-ends that put
+ * several wavefronts on a trajectory's step; the reference's solver never calls this).  Part r: component r of the
+ * dynamics and the summands r, r + N_X, ... of the running cost, term[] indexed by their place in ddpL's sum:
+ * t->c == ((term[0] + term[1]) + term[2]) + ...  A NaN or Inf in a guarded value sets bad[0]. */
+#define ILQG_ROLLOUT_PARTS 3
+#define ILQG_ROLLOUT_TERMS 6
+#ifndef ILQG_PART_SIN  /* a back-end may define these two before including this file */
+#define ILQG_PART_SIN(v) sin(v)
+#define ILQG_PART_COS(v) cos(v)
+#endif
+#ifndef ILQG_PART_FN  /* ... and the function's storage class / attributes */
+#define ILQG_PART_FN static
+#endif
+typedef struct {
+    double e;
+} ilqg_step_aux_t;
+ILQG_PART_FN void ilqg_step_part(int part, double x_next[], double term[], int bad[], const double *x, const double *u, int k, double **p, int N) {
+    ilqg_step_aux_t aux_, *const t= &aux_;
+
+    switch(part) {
+    case 0:
+        aux_e= exp(-1.0/4.0*(x[2]*x[2]))*ILQG_PART_SIN(x[0]);
+        if(!((aux_e) - (aux_e) == 0.0)) bad[0]= 1;
+        x_next[0]= p[3][0]*x[1] + x[0];
+        if(!((x_next[0]) - (x_next[0]) == 0.0)) bad[0]= 1;
+        term[0]= (1.0/10.0)*(aux_e*aux_e);
+        term[3]= p[2][0]*(sqrt((x[0]*x[0]) + 1.0) - 1.0);
+        break;
+    case 1:
+        aux_e= exp(-1.0/4.0*(x[2]*x[2]))*ILQG_PART_SIN(x[0]);
+        if(!((aux_e) - (aux_e) == 0.0)) bad[0]= 1;
+        x_next[1]= p[3][0]*(-aux_e*p[4][3] + u[0]) + x[1];
+        if(!((x_next[1]) - (x_next[1]) == 0.0)) bad[0]= 1;
+        term[1]= p[1][0]*(u[0]*u[0]);
+        term[4]= p[2][1]*(x[1]*x[1]);
+        break;
+    case 2:
+        x_next[2]= p[3][0]*(u[1] + (1.0/4.0)*x[0]*x[1] - 1.0/2.0*x[2]) + x[2];
+        if(!((x_next[2]) - (x_next[2]) == 0.0)) bad[0]= 1;
+        term[2]= p[1][1]*(u[1]*u[1]);
+        term[5]= p[2][2]*(x[2]*x[2]);
+        break;
+    default: break;
+    }
+}

@@ -683,6 +683,7 @@ typedef struct {{
           "int get_g_size() { return 0; }\n\n"
           "int calcG(double g[], trajEl_t *t, int k, double **p) { return 1; }\n")
         w(self.emit_factored_tensors())
+        w(self.emit_step_parts())
         return "".join(o)
 
     def emit_cost_and_dynamics(self):
@@ -1097,6 +1098,89 @@ def _emit_factored_tensors(self):
 
 
 Emitter.emit_factored_tensors = _emit_factored_tensors
+
+
+def _emit_step_parts(self):
+    """Additive (no counterpart in the reference): one step of forward_pass cut into N_X independent parts, for
+    back-ends that evaluate a trajectory's step on several wavefronts at once.  Part r owns component r of the dynamics
+    and every N_X-th summand of the running cost, with the auxiliaries they need as locals (no trajEl_t: nothing but x
+    and u goes in).  The assignments are the ones of calcXVariableAux / calcXUVariableAux / ddpf, unchanged; the cost is
+    emitted summand by summand in the order ddpL's expression adds them, so that
+        c = term[0]; c = c + term[1]; ...   reproduces ddpL's t->c to the last bit
+    (a sum a + b + c is evaluated left to right; a printed "- q" is the addition of the negated summand).  NaN / Inf in a
+    guarded value sets bad[0] instead of returning (the caller decides per trajectory).  Only for problems without
+    multipliers (their auxiliaries take the multipliers and penalty weights as inputs)."""
+    if self.plain or self.mu_c or not self.p.f:
+        return ""
+    n = self.n
+    L = self.csub(self.p.L, None)
+    terms = _printer._as_ordered_terms(L, order=None) if L.is_Add else [L]
+    # the pieces must print exactly as the whole does: check the reconstruction against the printer's own output
+    whole = cexpr(L)
+    rebuilt = ""
+    for i, t in enumerate(terms):
+        ts = cexpr(t)
+        if i == 0:
+            rebuilt = ts
+        elif ts.startswith("-"):
+            rebuilt += " - " + ts[1:]
+        else:
+            rebuilt += " + " + ts
+    if rebuilt != whole:
+        return ""  # (an expression shape the printer arranges differently: no parts for this problem)
+    need_all = set()
+    parts = []
+    for r in range(n):
+        mine_terms = [m for m in range(len(terms)) if m % n == r]
+        exprs = [self.p.f[r]]
+        # the summands are in C spelling already: find the auxiliaries they use through the macro names
+        aux_by_macro = {self.macro_name(q): q for q in self.D.defs}
+        used = set()
+        for m in mine_terms:
+            for sym in terms[m].free_symbols:
+                if sym.name in aux_by_macro:
+                    used.add(aux_by_macro[sym.name])
+        need = self.D.closure(exprs) | used | self.D.closure([self.D.defs[q] for q in used])
+        need = {q for q in need if self.D.kind[q] == "aux"}
+        need_all |= need
+        parts.append((r, mine_terms, need))
+    members = [q for q in self.D.order if q in need_all]
+
+    import re as _re
+
+    def part_math(text):  # sin / cos of the parts go through macros a back-end may point at an inlined implementation
+        text = _re.sub(r"(?<![A-Za-z0-9_])sin\(", "ILQG_PART_SIN(", text)
+        return _re.sub(r"(?<![A-Za-z0-9_])cos\(", "ILQG_PART_COS(", text)
+
+    def guarded(lhs, rhs):
+        return "        %s= %s;\n        if(!((%s) - (%s) == 0.0)) bad[0]= 1;\n" % (lhs, part_math(rhs), lhs, lhs)
+
+    out = ("\n/* ---- additive: one step of forward_pass in ILQG_ROLLOUT_PARTS independent parts (batched back-ends that put\n"
+           " * several wavefronts on a trajectory's step; the reference's solver never calls this).  Part r: component r of the\n"
+           " * dynamics and the summands r, r + N_X, ... of the running cost, term[] indexed by their place in ddpL's sum:\n"
+           " * t->c == ((term[0] + term[1]) + term[2]) + ...  A NaN or Inf in a guarded value sets bad[0]. */\n"
+           "#define ILQG_ROLLOUT_PARTS %d\n#define ILQG_ROLLOUT_TERMS %d\n"
+           "#ifndef ILQG_PART_SIN  /* a back-end may define these two before including this file */\n"
+           "#define ILQG_PART_SIN(v) sin(v)\n#define ILQG_PART_COS(v) cos(v)\n#endif\n"
+           "#ifndef ILQG_PART_FN  /* ... and the function's storage class / attributes */\n#define ILQG_PART_FN static\n#endif\n" % (n, len(terms)))
+    out += "typedef struct {\n" + "".join("    double %s;\n" % q.name for q in members) + ("    double unused_;\n" if not members else "") + "} ilqg_step_aux_t;\n"
+    out += ("ILQG_PART_FN void ilqg_step_part(int part, double x_next[], double term[], int bad[], const double *x, const double *u, int k, double **p, int N) {\n"
+            "    ilqg_step_aux_t aux_, *const t= &aux_;\n\n    switch(part) {\n")
+    for r, mine_terms, need in parts:
+        out += "    case %d:\n" % r
+        for q in self.D.order:
+            if q in need:
+                out += guarded(self.macro_name(q), cexpr(self.csub(self.D.defs[q], None)))
+        out += guarded("x_next[%d]" % r, cexpr(self.csub(self.p.f[r], None)))
+        for m in mine_terms:
+            ts = cexpr(terms[m])
+            out += "        term[%d]= %s;\n" % (m, part_math(ts))
+        out += "        break;\n"
+    out += "    default: break;\n    }\n}\n"
+    return out
+
+
+Emitter.emit_step_parts = _emit_step_parts
 
 
 def load_problem(path):
