@@ -277,7 +277,8 @@ ilqg_batch_t *ilqg_batch_create_groups(int device, int batch, int n_hor, int gro
     /* lane mapping: every roll-out of the search is kept and the accepted one becomes the current trajectory by a change
      * of its location index (k_search / k_commit), with four step sizes in the first stage (one whole cache line per
      * store of a step size's 16 lanes); wave mapping: second stage beside the winner pass (ROLL_SECOND) */
-    c->ls_keep = dims[7] ? 1 : 2;
+    c->ls_keep = 2; /* (wave mapping: where the generated file offers the step in parts, both stages keep their roll-outs
+                     * and the accepted ones are copied into the records; else as ls_keep = 1) */
     if(groups <= 0) {
         /* lane mapping: 4 (see above).  Wave mapping: 1 — two groups whose backward passes take turns (they share the
          * device's derivative work buffer) so that the roll-outs of one run beside the backward pass of the other were

@@ -284,6 +284,7 @@ struct DevPtrs {
     int *n_pending_next; // counter the first-stage selection appends with (same word as n_pending)
     double *xpl, *upl;   // lane mapping, ls_keep = 2: the kept roll-outs of the first line-search stage, 2 x PLANE_A planes
     size_t xplane, uplane; //   of the layout and size of X resp. U (doubles per plane); see cur_x
+    double *cand1;       // wave mapping, ls_keep = 2: what the FIRST stage's lanes roll out, [step size][step 0..N][x u][trajectory]
     double *cand;        // second line-search stage: the trajectories its lanes roll out, [step size][step 0..N][x u]
                          //   [entry of pending] (entry fastest: a wavefront stores whole rows) — the accepted one is
                          //   copied, not rolled out again (k_adopt)
@@ -1565,7 +1566,8 @@ void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_f
 // ---------------------------------------------------------------------------
 // forward_pass: one lane per (trajectory, step size)
 // ---------------------------------------------------------------------------
-enum { ROLL_INIT = 0, ROLL_SEARCH = 1, ROLL_WINNER = 2, ROLL_COST = 3, ROLL_SEARCH_LIST = 4, ROLL_SECOND = 5 };
+enum { ROLL_INIT = 0, ROLL_SEARCH = 1, ROLL_WINNER = 2, ROLL_COST = 3, ROLL_SEARCH_LIST = 4, ROLL_SECOND = 5,
+       ROLL_LIST_KEEP = 6 };  // (k_rollout_parts only: the second stage alone, rows = step sizes, kept in P.cand)
 constexpr int CAND_W = NX + NU;  // doubles per step of a kept second-stage roll-out
 
 // nominal data of one step (what forward_pass reads of the nominal trajectory, iLQG_func.tem:145-155)
@@ -2333,10 +2335,15 @@ __global__ __launch_bounds__(WAVE *RW) void k_rollout_parts(DevPtrs P, ilqg_dev_
             ai = a0 + blockIdx.y - 1;
             second_row = blockIdx.y - 1;
         }
+    } else if(mode == ROLL_LIST_KEEP) {
+        mode = ROLL_SEARCH_LIST;
+        second_row = blockIdx.y;
+    } else if(mode == ROLL_SEARCH && P.cand1) {  // the first stage keeps what it rolls out, by trajectory
+        keep = P.cand1 + (size_t)blockIdx.y * (P.N + 1) * CAND_W * P.Bp + b;
     }
     if(mode == ROLL_SEARCH_LIST) {
         // (the rows start their walk over the list at different workgroups, see k_rollout)
-        const int nb = gridDim.x, rows = (int)gridDim.y - (second_row >= 0 ? 1 : 0);
+        const int nb = gridDim.x, rows = (int)gridDim.y - ((second_row >= 0 && second_row != (int)blockIdx.y) ? 1 : 0);
         const int row = second_row >= 0 ? second_row : (int)blockIdx.y;
         const int first = (int)(((long long)row * nb) / rows);
         const int e0 = ((int)blockIdx.x + first) % nb * WAVE, np = *P.n_pending;
@@ -2578,6 +2585,29 @@ __global__ void k_adopt(DevPtrs P, int a0, int n2) {
         if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) continue;
         const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1 - a0;
         const double *src = P.cand + ((size_t)a * (P.N + 1) + k) * CAND_W * P.Bp + e;
+        double *xo = cur_x(P, k, b);
+#pragma unroll
+        for(int i = 0; i < NX; i++) xo[i * XSI] = src[(size_t)i * P.Bp];
+        if(k < P.N) {
+            double *uo = cur_u(P, k, b);
+#pragma unroll
+            for(int i = 0; i < NU; i++) uo[i * XSI] = src[(size_t)(NX + i) * P.Bp];
+        }
+    }
+}
+
+// Wave mapping, ls_keep = 2: the roll-outs the first stage accepted, kept by trajectory in P.cand1, become the current
+// trajectory (the records' x and u): one thread per (step, trajectory), consecutive threads = consecutive trajectories
+// on the reading side, 192 contiguous bytes per thread on the writing side.  Replaces the winner pass: a copy at the
+// speed of the memory system instead of 16 384 chains of N steps beside the second stage's.
+__global__ void k_adopt_first(DevPtrs P, int s1) {
+    const size_t total = (size_t)(P.N + 1) * P.Bp, stride = (size_t)gridDim.x * blockDim.x;
+    for(size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
+        const int b = (int)(w % P.Bp), k = (int)(w / P.Bp);
+        if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) continue;
+        const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1;
+        if(a >= s1) continue;
+        const double *src = P.cand1 + ((size_t)a * (P.N + 1) + k) * CAND_W * P.Bp + b;
         double *xo = cur_x(P, k, b);
 #pragma unroll
         for(int i = 0; i < NX; i++) xo[i * XSI] = src[(size_t)i * P.Bp];
@@ -2929,6 +2959,8 @@ struct ilqg_dev {
     std::vector<PendingRead> pending;
     int *counter;
     size_t cand_bytes;    // size of P.cand
+    size_t cand1_bytes;   // size of P.cand1
+    bool keep_first;      // the roll-out launch in progress keeps the first stage's roll-outs in P.cand1
     size_t xpl_bytes, upl_bytes;  // sizes of P.xpl / P.upl (ls_keep = 2)
     int loc_set;          // the set of planes current trajectories may live in (-1: none, all in X / U)
     bool defer_commit, commit_pending, pending_zero;  // ls_keep = 2: k_update commits / clears the pending counter
@@ -3350,6 +3382,7 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     if(d->counter) hipFree(d->counter);
     if(d->queues) hipFree(d->queues);
     if(d->P.cand) hipFree(d->P.cand);
+    if(d->P.cand1) hipFree(d->P.cand1);
     if(d->P.xpl) hipFree(d->P.xpl);
     if(d->P.upl) hipFree(d->P.upl);
     if(d->P.pending) hipFree(d->P.pending);
@@ -3707,8 +3740,11 @@ static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_
     else if(mode == ROLL_COST)
         hipLaunchKernelGGL(k_rollout<RK_COST>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
 #if ILQG_WAVE_MAP && defined(ILQG_ROLLOUT_PARTS)
-    else if(!HAS_MUL && !getenv("ILQG_NO_ROLLOUT_PARTS"))  // the generated file offers the step in parts: several wavefronts per 64 trajectories
-        hipLaunchKernelGGL(k_rollout_parts, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE * RW), 0, stream, d->P, d->O, d->pv, mode, a0);
+    else if(!HAS_MUL && !getenv("ILQG_NO_ROLLOUT_PARTS")) {  // the generated file offers the step in parts: several wavefronts per 64 trajectories
+        DevPtrs Q = d->P;
+        if(!d->keep_first) Q.cand1 = nullptr;
+        hipLaunchKernelGGL(k_rollout_parts, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE * RW), 0, stream, Q, d->O, d->pv, mode, a0);
+    }
 #endif
     else
         hipLaunchKernelGGL(k_rollout<RK_GENERAL>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
@@ -3956,6 +3992,40 @@ int ilqg_dev_search(ilqg_dev_t *d) {
     if(roll_enter(d)) return 1;
     HIP_TRY(hipMemsetAsync(d->P.n_pending, 0, sizeof(int), rs));
     d->pending_zero = false;
+#if ILQG_WAVE_MAP && defined(ILQG_ROLLOUT_PARTS)
+    if(d->O.ls_keep >= 2 && !HAS_MUL && !getenv("ILQG_NO_ROLLOUT_PARTS")) {
+        // Wave mapping with the roll-outs in parts: BOTH stages keep what they roll out and the accepted roll-outs are
+        // copied into the records — no winner pass (16 384 chains of N steps beside the second stage's: the second
+        // launch needed two rounds of workgroups, 50 ms; the second stage alone fits one).
+        const int n2 = A - s1;
+        const size_t row = (size_t)d->Bp * (d->N + 1) * CAND_W * sizeof(double);
+        if(ensure_buffer(d, &d->P.cand1, &d->cand1_bytes, row * s1, rs)) return 1;
+        if(n2 > 0 && ensure_buffer(d, &d->P.cand, &d->cand_bytes, row * n2, rs)) return 1;
+        d->keep_first = true;
+        launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, 0, s1, rs);
+        d->keep_first = false;
+        {
+            Timed t(d, ILQG_K_SELECT, rs);
+            hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O, 0, s1, 0);
+        }
+        if(n2 > 0) {
+            launch_rollout(d, ROLL_LIST_KEEP, ILQG_K_ROLLOUT_SEARCH2, s1, n2, rs);
+            {
+                Timed t(d, ILQG_K_SELECT, rs);
+                hipLaunchKernelGGL(k_select, grid1(d->Bp, 256), dim3(256), 0, rs, d->P, d->O, s1, A, 1);
+            }
+            Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
+            hipLaunchKernelGGL(k_adopt, dim3(8 * d->cus), dim3(256), 0, rs, d->P, s1, n2);
+        }
+        {
+            Timed t(d, ILQG_K_ROLLOUT_WINNER, rs);
+            hipLaunchKernelGGL(k_adopt_first, dim3(16 * d->cus), dim3(256), 0, rs, d->P, s1);
+        }
+        d->winner_done = true;
+        HIP_TRY(hipGetLastError());
+        return roll_leave(d);
+    }
+#endif
     launch_rollout(d, ROLL_SEARCH, ILQG_K_ROLLOUT_SEARCH, 0, s1, rs);
     {
         Timed t(d, ILQG_K_SELECT, rs);
