@@ -70,10 +70,12 @@ const char *ilqg_batch_error(const ilqg_batch_t *c);
  *                 the remaining ones only for trajectories that found none acceptable among
  *                 them; 0 = all step sizes for every trajectory.  The accepted step size is the
  *                 same either way (first acceptable, line_search.c:37-60).
- *   "ls_keep"     default 2 in the one-lane-per-trajectory mapping (first stages of up to 4 step sizes): every
+ *   "ls_keep"     default 2.  One lane per trajectory (first stages of up to 4 step sizes): every
  *                 roll-out of the line search is kept where it is rolled out and the accepted one becomes the
- *                 current trajectory by a change of its location index — no second roll-out, no copy;
- *                 1 (default with one wavefront per trajectory): the second stage runs side by side with the
+ *                 current trajectory by a change of its location index — no second roll-out, no copy.  One
+ *                 wavefront per trajectory, generated file with the step in parts: both stages keep their
+ *                 roll-outs and the accepted ones are copied (no second roll-out); else as 1.
+ *                 1: the second stage runs side by side with the
  *                 roll-out that stores the accepted trajectories of the first stage, and keeps what it rolls
  *                 out, so that its own accepted trajectories are copied instead of rolled out once more;
  *                 0: second stage, then one storing roll-out for all.  Same results in all three.
