@@ -2032,7 +2032,6 @@ __global__ __launch_bounds__(WAVE, ILQG_SEARCH_OCC) void k_search(DevPtrs P, ilq
     if(DMA) {
         dma_issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        dma_read(cur, 0);
         dma_issue(1);  // step 1 (N >= 2)
     } else {
         load_nominal<true, 1>(cur, q);
@@ -2044,6 +2043,9 @@ __global__ __launch_bounds__(WAVE, ILQG_SEARCH_OCC) void k_search(DevPtrs P, ilq
         qn.u = q.u + RN;
         qn.l = q.l + RN;
         qn.K = q.K + RN;
+        // DMA: the record is read out of LDS HERE, where it is consumed, not a step ahead: its 32 registers are live for
+        // the first few instructions of the step only, not across the sin / cos evaluations (145 -> fewer registers)
+        if(DMA) dma_read(cur, k & 1);
         double xin[NX], uin[NU];
 #pragma unroll
         for(int i = 0; i < NX; i++) xin[i] = xc[i];
@@ -2090,7 +2092,6 @@ __global__ __launch_bounds__(WAVE, ILQG_SEARCH_OCC) void k_search(DevPtrs P, ilq
             // Outstanding here: the kept roll-out of step k-1 and the records of step k+1, both issued a whole step
             // ago.  The wait stands BEFORE this step's stores so that it never waits for a store just issued.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dma_read(cur, (k + 1) & 1);
         }
         if(live) {  // (!DMA: behind the prefetch in issue order: the wait for the prefetched values leaves these in flight)
 #pragma unroll
