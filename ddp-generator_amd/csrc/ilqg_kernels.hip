@@ -3732,7 +3732,8 @@ static int roll_leave(ilqg_dev_t *d) {  // ... and the roll-outs before whatever
     return 0;
 }
 
-static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_alpha, hipStream_t stream = nullptr) {
+// (launch errors are picked up by the caller's hipGetLastError())
+static void launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_alpha, hipStream_t stream = nullptr) {
     if(!stream) stream = d->stream;
     Timed t(d, kernel_id, stream);
     const dim3 grid((d->Bp + ROLL_BLOCK - 1) / ROLL_BLOCK, n_alpha), block(ROLL_BLOCK);
@@ -3749,7 +3750,6 @@ static int launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n_
 #endif
     else
         hipLaunchKernelGGL(k_rollout<RK_GENERAL>, grid, block, 0, stream, d->P, d->O, d->pv, mode, a0);
-    return 0;
 }
 
 int ilqg_dev_rollout_init(ilqg_dev_t *d) {
