@@ -1351,31 +1351,70 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
 
 using StepLds = std::conditional_t<ROW_STEP, RowLds<(ROW_STEP ? NX : 1), (ROW_STEP ? NU : 1)>, WaveLds<NX, NU>>;
 
-#if ILQG_FACTORED
-// the step's record with the tensors multiplied out on the fly: coefficient tables (LDS copies of the generated
-// ilqg_tensor_coef_*) times the products bp_tensor_basis left in the record (LDS copy of this step's)
-struct FactoredSource : RecordSource<NX, NU, true> {
-    const double *txx, *tuu, *txu;  // LDS copies of ilqg_tensor_coef_xx / _uu / _xu
-    double product;                 // lane i: product i of this step (bp_tensor_basis)
-    struct Slice {
-        int i;
-        double gxx, guu, gxu;       // the products the entries of slice i are multiples of (wave-uniform)
-    };
-    ILQG_DEV Slice slice(int i) const {
-        return {i, lane_bcast(product, ilqg_tensor_slice_xx[i]), lane_bcast(product, ilqg_tensor_slice_uu[i]),
-                lane_bcast(product, ilqg_tensor_slice_xu[i])};
-    }
-    ILQG_DEV double fxx(const Slice &s, int e) const { return txx[e + s.i * SXX] * s.gxx; }
-    ILQG_DEV double fuu(const Slice &s, int e) const { return tuu[e + s.i * SUU] * s.guu; }
-    ILQG_DEV double fxu(const Slice &s, int e) const { return txu[e + s.i * NXU] * s.gxu; }
-};
+// byte offsets of the members of a step's record (trajEl_t) the row-mapped backward step reads
+struct RecOffsets {
+    static constexpr unsigned cx = offsetof(trajEl_t, cx), cxx = offsetof(trajEl_t, cxx), cu = offsetof(trajEl_t, cu),
+                              cuu = offsetof(trajEl_t, cuu), cxu = offsetof(trajEl_t, cxu), fx = offsetof(trajEl_t, fx),
+                              fu = offsetof(trajEl_t, fu), lower = offsetof(trajEl_t, lower), upper = offsetof(trajEl_t, upper),
+                              lower_sign = offsetof(trajEl_t, lower_sign), upper_sign = offsetof(trajEl_t, upper_sign),
+                              lower_hx = offsetof(trajEl_t, lower_hx), upper_hx = offsetof(trajEl_t, upper_hx);
+#if FULL_DDP
+    static constexpr unsigned fxx = offsetof(trajEl_t, fxx), fuu = offsetof(trajEl_t, fuu), fxu = offsetof(trajEl_t, fxu);
 #endif
-constexpr int TABLE_DOUBLES = FACTORED ? NX * (SXX + SUU + NXU) : 0;
+};
+
+#if ILQG_FACTORED
+// The step's record with the tensors multiplied out on the fly: coefficient tables (an LDS copy of the generated
+// ilqg_tensor_coef_*, shared by the workgroup) times the products bp_tensor_basis left in the record.  The LDS copy
+// is slice-major, [slice][xx | uu | xu], so that what a lane reads of a slice sits within a few hundred bytes: ONE
+// address register (table + 8 * lane) serves the whole contraction, the rest is immediate offsets.  A lane beyond
+// the end of an array reads its neighbour's (or the next slice's) numbers; those sums are never used.
+constexpr int FACT_SLICE = SXX + SUU + NXU;  // doubles per slice
+struct FactoredSource : RecordSource<NX, NU, true, RecOffsets> {
+    unsigned table;  // LDS address of the coefficient tables
+    double product;  // lane i: product i of this step (bp_tensor_basis)
+    ILQG_DEV void contract(const double vxl, double (&dxx)[NTX], double (&duu)[NTU], double (&dxu)[NTC], const int lane) const {
+        constexpr int PER = NTX + NTU + NTC;
+        const LdsBase p = lds_base(table + lane * 8);
+        // the entries of slice i this lane multiplies: xx, uu, xu
+        auto fetch = [&](int i, double (&t)[PER]) {
+#pragma unroll
+            for(int q = 0; q < NTX; q++) t[q] = p.fetch(i * FACT_SLICE + 64 * q);
+#pragma unroll
+            for(int q = 0; q < NTU; q++) t[NTX + q] = p.fetch(i * FACT_SLICE + SXX + 64 * q);
+#pragma unroll
+            for(int q = 0; q < NTC; q++) t[NTX + NTU + q] = p.fetch(i * FACT_SLICE + SXX + SUU + 64 * q);
+        };
+        double cur[PER], nxt[PER];
+        fetch(0, cur);
+        static_for<0, NX>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if(i + 1 < NX) fetch(i + 1, nxt);  // (in flight during this slice's arithmetic)
+            // the products the entries of slice i are multiples of (wave-uniform)
+            const double gxx = lane_bcast(product, ilqg_tensor_slice_xx[i]), guu = lane_bcast(product, ilqg_tensor_slice_uu[i]),
+                         gxu = lane_bcast(product, ilqg_tensor_slice_xu[i]);
+            // d += Vx[i] * (coefficient * product), Vx[i] broadcast from lane i of the row
+#pragma unroll
+            for(int q = 0; q < NTC; q++) row_fma<i>(dxu[q], vxl, cur[NTX + NTU + q] * gxu);
+#pragma unroll
+            for(int q = 0; q < NTU; q++) row_fma<i>(duu[q], vxl, cur[NTX + q] * guu);
+#pragma unroll
+            for(int q = 0; q < NTX; q++) row_fma<i>(dxx[q], vxl, cur[q] * gxx);
+#pragma unroll
+            for(int q = 0; q < PER; q++) cur[q] = nxt[q];
+        });
+    }
+};
+constexpr int TABLE_DOUBLES = NX * FACT_SLICE;
+#else
+constexpr int TABLE_DOUBLES = 0;
+#endif
 constexpr int WAVE_LDS_DOUBLES = (int)((sizeof(StepLds) + 7) / 8);  // LDS of one wavefront
 
 // one backward step in the form that goes with the LDS block (a template, so that only that form is instantiated)
 template <bool FACT, class Lds>
-__device__ __forceinline__ int step_of_wave(Lds &S, const double *tables, double product, const StepFields<NX, NU> &F, double *lout,
+__device__ __forceinline__ int step_of_wave(Lds &S, const double *tables, double product, const trajEl_t *t, const double *u_nom,
+                                            const StepFields<NX, NU> &F, double *lout,
                                             double *Kout, double lambda, int regType, double &dV0, double &dV1, double &gsum,
                                             Prof *pf) {
     if constexpr(std::is_same<Lds, WaveLds<NX, NU>>::value) {
@@ -1383,19 +1422,26 @@ __device__ __forceinline__ int step_of_wave(Lds &S, const double *tables, double
     } else if constexpr(FACT) {
 #if ILQG_FACTORED
         FactoredSource D;
-        D.F = F;
-        D.txx = tables;
-        D.tuu = tables + NX * SXX;
-        D.txu = tables + NX * (SXX + SUU);
+        D.rec = reinterpret_cast<const char *>(t);
+        D.table = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(tables));
         D.product = product;
-        return back_step_row<NX, NU, FULL, HX>(S, D, F, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
+        return back_step_row<NX, NU, FULL, HX>(S, D, u_nom, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
 #else
         return 0;
 #endif
     } else {
-        const RecordSource<NX, NU, FULL> D{F};
-        return back_step_row<NX, NU, FULL, HX>(S, D, F, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
+        const RecordSource<NX, NU, FULL, RecOffsets> D{reinterpret_cast<const char *>(t)};
+        return back_step_row<NX, NU, FULL, HX>(S, D, u_nom, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
     }
+}
+
+// the value function behind the last step (Vx, packed Vxx of the final cost) into the LDS block, in the block's form
+template <int A, int B>
+__device__ __forceinline__ void set_final_value(RowLds<A, B> &S, const double *vx, const double *vxx, int lane) { S.set_value(vx, vxx, lane); }
+template <int A, int B>
+__device__ __forceinline__ void set_final_value(WaveLds<A, B> &S, const double *vx, const double *vxx, int lane) {
+    for(int i = lane; i < A; i += 64) S.Vx[i] = vx[i];
+    for(int i = lane; i < tri(A); i += 64) S.Vxx[i] = vxx[i];
 }
 
 // one sweep of one trajectory on one wave; returns 0 ok, 1 box-QP failed (wave-uniform)
@@ -1405,8 +1451,7 @@ __device__ __forceinline__ int backward_sweep_wave(StepLds &S, const double *tab
     const int lane = threadIdx.x & 63;
     const int N = P.N;
     const double *fin = P.f[ILQG_F_FIN] + (size_t)b * FIN;
-    for(int i = lane; i < NX; i += 64) S.Vx[i] = fin[i];
-    for(int i = lane; i < SXX; i += 64) S.Vxx[i] = fin[NX + i];
+    set_final_value(S, fin, fin + NX, lane);
     for(int i = lane; i < NU; i += 64) S.l[i] = 0.0;
     wave_sync();
     dV0 = 0.0;
@@ -1444,8 +1489,8 @@ __device__ __forceinline__ int backward_sweep_wave(StepLds &S, const double *tab
         const StepFields<NX, NU> F = fields(k);
         double next_product = 0.0;
         if(FACT && k > 0) next_product = fields(k - 1).fxx[bl];
-        const int rc = step_of_wave<FACT>(S, tables, product, F, nomp(P, k, b) + NOM_L, nomp(P, k, b) + NOM_K, lambda, regType,
-                                         dV0, dV1, gsum, pf);
+        const int rc = step_of_wave<FACT>(S, tables, product, work_rec(P, bw, k), nomp(P, k, b) + NOM_U, F, nomp(P, k, b) + NOM_L,
+                                         nomp(P, k, b) + NOM_K, lambda, regType, dV0, dV1, gsum, pf);
 #ifdef ILQG_PROFILE_SECTIONS
         prof.acc[7]++;  // steps executed (sweeps that are abandoned half way count with the steps they ran)
 #endif
@@ -1537,9 +1582,9 @@ void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_f
     constexpr int WAVES = FACT ? ILQG_FACT_WAVES : 1;
 #if ILQG_FACTORED
     if(FACT) {
-        for(int i = threadIdx.x; i < NX * SXX; i += 64 * WAVES) wave_lds[i] = ilqg_tensor_coef_xx[i];
-        for(int i = threadIdx.x; i < NX * SUU; i += 64 * WAVES) wave_lds[NX * SXX + i] = ilqg_tensor_coef_uu[i];
-        for(int i = threadIdx.x; i < NX * NXU; i += 64 * WAVES) wave_lds[NX * (SXX + SUU) + i] = ilqg_tensor_coef_xu[i];
+        for(int i = threadIdx.x; i < NX * SXX; i += 64 * WAVES) wave_lds[i / SXX * FACT_SLICE + i % SXX] = ilqg_tensor_coef_xx[i];
+        for(int i = threadIdx.x; i < NX * SUU; i += 64 * WAVES) wave_lds[i / SUU * FACT_SLICE + SXX + i % SUU] = ilqg_tensor_coef_uu[i];
+        for(int i = threadIdx.x; i < NX * NXU; i += 64 * WAVES) wave_lds[i / NXU * FACT_SLICE + SXX + SUU + i % NXU] = ilqg_tensor_coef_xu[i];
         __syncthreads();  // the only meeting of the workgroup's wavefronts
     }
 #endif

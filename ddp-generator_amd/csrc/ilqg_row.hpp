@@ -17,8 +17,22 @@
 // and the CPU's up to FMA contraction; the -ffp-contract=off build (ILQG_STRICT_FP) multiplies and adds separately.
 // Symmetric results (Quu, Qxx, Vxx) are produced by the lanes with 4g+j <= c in the reference's order of the two
 // half sums; the other lanes run the same instructions and their results are discarded.
+//
+// The kernel is bound by the NUMBER of vector instructions it issues (two wavefronts per SIMD keep it ~80 % busy), and
+// an integer instruction costs what a 64-bit multiply-add costs.  So the step spends as few as it can on addresses:
+//   * symmetric matrices live in LDS as full squares (both triangles stored): every access is base + constant, where a
+//     packed triangle needs a multiply, a compare and a select per index;
+//   * every group of LDS accesses goes through ONE address register made of a wave-uniform part (block + member) and
+//     a lane part, given to the optimiser as opaque (lds_base): the accesses then carry their distance as immediate
+//     offsets — left to itself the optimiser re-derives a base per pair of accesses;
+//   * the record of the step is read as (uniform base) + (32-bit lane offset), the form global loads take without
+//     64-bit address arithmetic;
+//   * values every lane needs from one lane of its row (Vx[i], l[i], ...) are broadcast inside the consuming
+//     multiply-add (row_newbcast) instead of through two v_readlane.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
 #include <type_traits>
 #include "ilqg_device.hpp"
 #include "ilqg_wave.hpp"
@@ -96,26 +110,67 @@ ILQG_DEV double row_get(const double a) {
 }
 
 // ---------------------------------------------------------------------------
+// LDS addresses.  An LDS pointer is a 32-bit number; LdsBase is one the optimiser has to take as it is (the `asm`),
+// so that p[i] with a constant i becomes the instruction's immediate offset and a group of accesses shares ONE
+// address register.
+// ---------------------------------------------------------------------------
+using lds_double = __attribute__((address_space(3))) double;
+ILQG_DEV unsigned lds_addr(const void *p) {  // p: a generic pointer INTO LDS
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+struct LdsBase {
+    unsigned a;
+    ILQG_DEV lds_double &operator[](int i) const { return ((lds_double *)a)[i]; }
+    // a read the optimiser neither merges with a neighbour (a merged pair takes small offsets only and gets a new
+    // base register computed for it) nor moves: offset i (doubles) is the instruction's immediate
+    ILQG_DEV double fetch(int i) const { return ((volatile lds_double *)a)[i]; }
+};
+ILQG_DEV LdsBase lds_base(unsigned a) {
+    asm("" : "+v"(a));
+    return {a};
+}
+constexpr int pad64(int n) { return (n + 63) / 64 * 64; }
+
+// ---------------------------------------------------------------------------
 // boxQP.c:39-238 for the wave mapping, cooperative as box_qp_rows (ilqg_wave.hpp: lane i owns variable i — its x, g,
 // limits, clamp flag, row i of H and of the inverse, column i of the Cholesky factor), with every exchange between the
 // lanes a row broadcast inside the consuming multiply-add instead of two v_readlane and a scalar operand: lane j of
 // EVERY 16-lane row holds variable j (the other lanes mirror lane mod M), so row_newbcast:j reaches it from anywhere.
 // Expression trees, operand order and exits are those of box_qp_rows, i.e. of the reference, bit for bit.
+//
+// LD = 0: H and the inverse are packed upper triangles (the reference's storage; the inverse zeroed on entry).
+// LD > 0: full squares of leading dimension LD with both triangles stored (the backward step's; the inverse is written
+// by the first factorisation, and without one — every variable clamped at once — nothing reads it).  Also handed
+// back: this lane's clamp flag (of variable (lane mod 16) mod M) and the flags of all variables as two wave-uniform
+// masks (at the lower / at the upper limit).
 // ---------------------------------------------------------------------------
-template <int M>
-ILQG_DEV int box_qp_row(const double *Hpacked /* LDS */, const double g, const double lower, const double upper,
-                        double *S_l, int *S_clamp, double *S_invH, int &n_free_out) {
+template <int M, int LD = 0>
+ILQG_DEV int box_qp_row(const double *H /* LDS */, const double g, const double lower, const double upper, double *S_l,
+                        int *S_clamp, double *S_invH, int &n_free_out, int *clamp_out = nullptr, unsigned *lo_mask = nullptr,
+                        unsigned *hi_mask = nullptr) {
     static_assert(M <= 16, "one 16-lane row holds all variables");
     constexpr int T = tri(M);
-    const int lane = threadIdx.x & 63, me = (lane & 15) % M;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));  // (as in back_step_row: what depends on the lane alone is not kept across steps)
+    lane &= 63;
+    const int me = (lane & 15) % M;
     const unsigned all = (1u << M) - 1u;
     const int max_iter = 100;
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+    unsigned inv_at = 0;  // LDS address of the inverse (full-square form)
+    if constexpr(LD > 0) inv_at = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(S_invH));
 
     double Hrow[M], invrow[M], Ucol[M];
+    if constexpr(LD > 0) {
+        const LdsBase ph = lds_base((unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(H)) + me * (LD * 8));
+#pragma unroll
+        for(int j = 0; j < M; j++) Hrow[j] = ph[j];
+    } else {
+#pragma unroll
+        for(int j = 0; j < M; j++) Hrow[j] = H[sy(me, j)];
+    }
 #pragma unroll
     for(int j = 0; j < M; j++) {
-        Hrow[j] = Hpacked[sy(me, j)];
         invrow[j] = 0.0;
         Ucol[j] = 0.0;
     }
@@ -123,7 +178,8 @@ ILQG_DEV int box_qp_row(const double *Hpacked /* LDS */, const double g, const d
     if(x > upper) x = upper;
     if(x < lower) x = lower;
     int clamp = 0;
-    for(int e = lane; e < T; e += 64) S_invH[e] = 0.0;
+    if constexpr(LD == 0)
+        for(int e = lane; e < T; e += 64) S_invH[e] = 0.0;
     n_free_out = 0;
 
     // value(y) = sum_i y_i (g_i + 0.5 (H y)_i), boxQP.c:17-37
@@ -213,14 +269,31 @@ ILQG_DEV int box_qp_row(const double *Hpacked /* LDS */, const double g, const d
                 ny[k] = -y[k];
             });
             wave_sync();
-            if(lane < M) {
+            if constexpr(LD > 0) {
+                // lane l < M writes its entries (l, k), k >= l, into both triangles
+                if(lane < M) {
+                    const LdsBase pr = lds_base(inv_at + me * (LD * 8)), pc = lds_base(inv_at + me * 8);
 #pragma unroll
-                for(int k = 0; k < M; k++)
-                    if(k >= me) S_invH[ut(me, k)] = y[k];
+                    for(int k = 0; k < M; k++)
+                        if(k >= me) {
+                            pr[k] = y[k];
+                            pc[k * LD] = y[k];
+                        }
+                }
+                wave_sync();
+                const LdsBase pi = lds_base(inv_at + me * (LD * 8));
+#pragma unroll
+                for(int j = 0; j < M; j++) invrow[j] = pi[j];
+            } else {
+                if(lane < M) {
+#pragma unroll
+                    for(int k = 0; k < M; k++)
+                        if(k >= me) S_invH[ut(me, k)] = y[k];
+                }
+                wave_sync();
+#pragma unroll
+                for(int j = 0; j < M; j++) invrow[j] = S_invH[sy(me, j)];
             }
-            wave_sync();
-#pragma unroll
-            for(int j = 0; j < M; j++) invrow[j] = S_invH[sy(me, j)];
         }
 
         if(gnorm < min_grad * min_grad) { rc = 5; break; }
@@ -266,6 +339,9 @@ ILQG_DEV int box_qp_row(const double *Hpacked /* LDS */, const double g, const d
         S_l[me] = x;
         S_clamp[me] = clamp;
     }
+    if(clamp_out) *clamp_out = clamp;
+    if(lo_mask) *lo_mask = (unsigned)__ballot(clamp == 1) & all;
+    if(hi_mask) *hi_mask = (unsigned)__ballot(clamp == 2) & all;
     wave_sync();
     return rc;
 }
@@ -274,75 +350,105 @@ template <int NX, int NU>
 struct RowLds {
     static constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
     static constexpr int LDX = NX + 1, LDU = NU + 1;  // padded leading dimensions: column reads hit distinct banks
-    double Vx[NX], Vxx[SXX];
-    double fx[LDX * NX], fu[LDX * NU];   // NX x NX, NX x NU
-    double T1[LDX * NX], T2[LDX * NU];   // Vxx fx, Vxx fu
+    double Vx[NX], Vxx[LDX * NX];        // Vxx: full square
     double Qxu[LDX * NU];                // NX x NU
-    double Qu[NU], Quu[SUU], QuuF[SUU];
+    double Qu[NU], Quu[LDU * NU], QuuF[LDU * NU];  // full squares
     double l[NU];
     union {
-        struct {                         // from the box QP to the end of the step
-            double K[LDU * NX], BA[LDU * NX];  // gains (NU x NX), Quu K
-            double invH[SUU];
-        };
         struct {                         // from the start of the step to the assembly of the Q blocks
-            double dxx[SXX], duu[SUU], dxu[NXU];  // sum_i Vx[i] * (fxx_i, fuu_i, fxu_i), in the arrays' own order
+            double fx[LDX * NX], fu[LDX * NU];   // NX x NX, NX x NU
+            double T1[LDX * NX], T2[LDX * NU];   // Vxx fx, Vxx fu
+            // sum_i Vx[i] * (fxx_i, fuu_i, fxu_i), packed as the tensors' slices are; padded: every lane stores its sums
+            double dxx[pad64(SXX)], duu[pad64(SUU)], dxu[pad64(NXU)];
+        };
+        struct {                         // from the box QP to the end of the step
+            double K[LDU * NX], BA[LDU * NX];    // gains (NU x NX), Quu K
+            double invH[LDU * NU];               // full square
         };
     };
-    int clamp[NU];
+    int clamp[NU + NU % 2];
+    double spare[4];                     // (rows 4g..4g+3 are read as a group also where NX is not a multiple of 4)
+    // the value function behind the last step (the final cost's: packed triangle in global memory)
+    ILQG_DEV void set_value(const double *vx, const double *vxx_packed, int lane) {
+        for(int i = lane; i < NX; i += 64) Vx[i] = vx[i];
+        for(int e = lane; e < NX * NX; e += 64) Vxx[(e % NX) + (e / NX) * LDX] = vxx_packed[sy(e % NX, e / NX)];
+    }
 };
 
 // Where a step's derivative entries come from.  RecordSource: the trajEl_t the generated calc_derivs code has
-// written to HBM (k_derivs_wave).  Every accessor returns the entry THIS lane needs; out-of-range lanes get an
-// in-range address (their results are never used).
-template <int NX, int NU, bool FULL>
+// written to HBM (k_derivs_wave), addressed as uniform base + 32-bit lane offset.  R: byte offsets of the members
+// (a struct of constexpr unsigned: cx, cxx, cu, cuu, cxu, fx, fu, lower, upper, lower_sign, upper_sign, lower_hx,
+// upper_hx and — FULL — fxx, fuu, fxu).
+template <int NX, int NU, bool FULL, class R_>
 struct RecordSource {
+    using R = R_;
     static constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
-    StepFields<NX, NU> F;
-    ILQG_DEV double fx(int i) const { return F.fx[i]; }
-    ILQG_DEV double fu(int i) const { return F.fu[i]; }
-    ILQG_DEV double cx(int i) const { return F.cx[i]; }
-    ILQG_DEV double cu(int i) const { return F.cu[i]; }
-    ILQG_DEV double cxu(int i) const { return F.cxu[i]; }
-    ILQG_DEV double cxx(int e) const { return F.cxx[e]; }
-    ILQG_DEV double cuu(int e) const { return F.cuu[e]; }
-    // the tensors slice by slice: slice(i) is whatever identifies slice i, f??(slice, e) entry e of it
-    ILQG_DEV int slice(int i) const { return i; }
-    ILQG_DEV double fxu(int i, int e) const { return F.fxu[e + i * NXU]; }
-    ILQG_DEV double fuu(int i, int e) const { return F.fuu[e + i * SUU]; }
-    ILQG_DEV double fxx(int i, int e) const { return F.fxx[e + i * SXX]; }
+    static constexpr int NTX = (SXX + 63) / 64, NTU = (SUU + 63) / 64, NTC = (NXU + 63) / 64;
+    const char *rec;  // wave-uniform
+    template <unsigned OFF>
+    ILQG_DEV double ld(unsigned byte_off) const {
+        return *reinterpret_cast<const double *>(rec + OFF + byte_off);
+    }
+    // d??[q] += sum_i Vx[i] * f??_i[lane + 64 q], i ascending (vxl: Vx[c] in lane c of every row)
+    ILQG_DEV void contract(const double vxl, double (&dxx)[NTX], double (&duu)[NTU], double (&dxu)[NTC], const int lane) const {
+        if constexpr(FULL) {
+#pragma unroll 8
+            for(int i = 0; i < NX; i++) {
+                const double vxi = lane_bcast(vxl, i);  // Vx[i] (lane i holds it)
+#pragma unroll
+                for(int q = 0; q < NTC; q++)
+                    dxu[q] += vxi * ld<R::fxu>((unsigned)(((lane + 64 * q < NXU) ? lane + 64 * q : 0) + i * NXU) * 8u);
+#pragma unroll
+                for(int q = 0; q < NTU; q++)
+                    duu[q] += vxi * ld<R::fuu>((unsigned)(((lane + 64 * q < SUU) ? lane + 64 * q : 0) + i * SUU) * 8u);
+#pragma unroll
+                for(int q = 0; q < NTX; q++)
+                    dxx[q] += vxi * ld<R::fxx>((unsigned)(((lane + 64 * q < SXX) ? lane + 64 * q : 0) + i * SXX) * 8u);
+            }
+        }
+    }
 };
 
-// One backward step.  S: LDS block of the wavefront (Vx, Vxx, l carry over between steps); lout / Kout: the step's
-// gains in global memory.  Returns the box-QP code (wave-uniform); < 1 abandons the sweep (back_pass.c:168-171).
+// One backward step.  S: LDS block of the wavefront (Vx, Vxx, l carry over between steps); nom_u / lout / Kout: the
+// step's nominal inputs and gains in global memory.  Returns the box-QP code (wave-uniform); < 1 abandons the sweep
+// (back_pass.c:168-171).
 template <int NX, int NU, bool FULL, bool HX, class Source>
-__device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D, const StepFields<NX, NU> &F, double *lout,
-                                             double *Kout, const double lambda, const int regType, double &dV0,
-                                             double &dV1, double &gsum, Prof *pf = nullptr) {
+__device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D, const double *nom_u, double *lout, double *Kout,
+                                             const double lambda, const int regType, double &dV0, double &dV1, double &gsum,
+                                             Prof *pf = nullptr) {
     static_assert(NX <= 16 && NU <= 16, "one 16-lane row per matrix row block");
+    using L = RowLds<NX, NU>;
+    using R = typename Source::R;
     constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
     constexpr int LDX = NX + 1, LDU = NU + 1;
+#define ROW_OFF(m) ((unsigned)offsetof(L, m))
     // Everything below that depends on the lane alone (rows, columns, the LDS and record addresses made of them) is
     // loop invariant in the sweep, and the optimiser would move all of it — some hundred values — in front of the
     // loop and keep it in registers, i.e. spill it.  The lane number is made opaque here, once per step: the
     // addresses are recomputed by a few integer instructions where they are used.
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
+    lane &= 63;  // (the range, for the optimiser: clamps that can never act fold away)
     const int g = lane >> 4, c = lane & 15;
-    const int cx_ = (c < NX) ? c : 0, cu_ = (c < NU) ? c : 0;  // this lane's column, clamped into range
-    int a[4], ax[4], au[4];                                    // this lane's rows 4g+j, clamped into range
+    // this lane's column and block of four rows, moved into range where the matrix is smaller than 16: such lanes
+    // compute along on entries that exist, their results are never stored
+    constexpr bool P2U = (NU & (NU - 1)) == 0, P2GU = NU % 4 == 0 && ((NU / 4) & (NU / 4 - 1)) == 0;
+    const int cx_ = (c < NX) ? c : 0, cu_ = P2U ? (c & (NU - 1)) : ((c < NU) ? c : 0);
+    const int gx = (4 * g < NX) ? g : 0, gu = P2GU ? (g & (NU / 4 - 1)) : ((4 * g < NU) ? g : 0);
+    const int me = (lane & 15) % NU;  // the input whose limits and clamp flag this lane holds in the box QP
+    int a[4];                         // this lane's rows 4g+j
 #pragma unroll
-    for(int j = 0; j < 4; j++) {
-        a[j] = 4 * g + j;
-        ax[j] = (a[j] < NX) ? a[j] : 0;
-        au[j] = (a[j] < NU) ? a[j] : 0;
-    }
+    for(int j = 0; j < 4; j++) a[j] = 4 * g + j;
+    const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(&S));  // the block's LDS address
 
     // ---- value function of step k+1
-    double vxl = S.Vx[cx_];  // Vx[c]
-    double vxx_r[4];         // Vxx[4g+j, c]
+    double vxl = lds_base(sb + ROW_OFF(Vx) + cx_ * 8)[0];  // Vx[c]
+    double vxx_r[4];                                       // Vxx[4g+j, c]
+    {
+        const LdsBase p = lds_base(sb + ROW_OFF(Vxx) + (cx_ * LDX + 4 * gx) * 8);
 #pragma unroll
-    for(int j = 0; j < 4; j++) vxx_r[j] = S.Vxx[sy(ax[j], cx_)];
+        for(int j = 0; j < 4; j++) vxx_r[j] = p[j];
+    }
     dpp_source(vxl);
     dpp_source(vxx_r);
 
@@ -351,34 +457,32 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     constexpr int NFX = (NX * NX + 63) / 64, NFU = (NXU + 63) / 64;
     double fx_in[NFX], fu_in[NFU];
 #pragma unroll
-    for(int q = 0; q < NFX; q++) fx_in[q] = D.fx((lane + 64 * q < NX * NX) ? lane + 64 * q : 0);
+    for(int q = 0; q < NFX; q++) fx_in[q] = D.template ld<R::fx>((unsigned)((lane + 64 * q < NX * NX) ? lane + 64 * q : 0) * 8u);
 #pragma unroll
-    for(int q = 0; q < NFU; q++) fu_in[q] = D.fu((lane + 64 * q < NXU) ? lane + 64 * q : 0);
-    const double cxl = D.cx(cx_), cul = D.cu(cu_);
+    for(int q = 0; q < NFU; q++) fu_in[q] = D.template ld<R::fu>((unsigned)((lane + 64 * q < NXU) ? lane + 64 * q : 0) * 8u);
+    const double cxl = D.template ld<R::cx>((unsigned)cx_ * 8u), cul = D.template ld<R::cu>((unsigned)cu_ * 8u);
     // this lane's 4 entries of a packed triangle are consecutive: rows 4g..4g+3 of column c where 4g <= c (rows
     // beyond the diagonal, and all four where 4g > c, are never used: any address inside the array will do)
     const int rxx = (4 * g <= cx_) ? 4 * g : 0, ruu = (4 * g <= cu_) ? 4 * g : 0;
-    int exu[4], euu[4], exx[4];
-#pragma unroll
-    for(int j = 0; j < 4; j++) {
-        exu[j] = ax[j] + cu_ * NX;
-        euu[j] = (ut(ruu, cu_) + j < SUU) ? ut(ruu, cu_) + j : SUU - 1;
-        exx[j] = (ut(rxx, cx_) + j < SXX) ? ut(rxx, cx_) + j : SXX - 1;
-    }
+    const int txx0 = ut(rxx, cx_), tuu0 = ut(ruu, cu_);  // the first of the four
+    const int xu0 = 4 * gx + cu_ * NX;                    // entry (4g, c) of cxu / dxu; the other three follow
     double cxu_e[4], cuu_e[4], cxx_e[4];
 #pragma unroll
     for(int j = 0; j < 4; j++) {
-        cxu_e[j] = D.cxu(exu[j]);
-        cuu_e[j] = D.cuu(euu[j]);
-        cxx_e[j] = D.cxx(exx[j]);
+        // (clamped to the array's last entry unless the largest index a lane can form is inside anyway)
+        constexpr bool in_xu = NX % 4 == 0, in_uu = NU >= 4 && ut(NU - 1 - (NU - 1) % 4, NU - 1) + 3 < SUU,
+                       in_xx = NX >= 4 && ut(NX - 1 - (NX - 1) % 4, NX - 1) + 3 < SXX;
+        cxu_e[j] = D.template ld<R::cxu>((unsigned)(in_xu ? xu0 + j : ((xu0 + j < NXU) ? xu0 + j : NXU - 1)) * 8u);
+        cuu_e[j] = D.template ld<R::cuu>((unsigned)(in_uu ? tuu0 + j : ((tuu0 + j < SUU) ? tuu0 + j : SUU - 1)) * 8u);
+        cxx_e[j] = D.template ld<R::cxx>((unsigned)(in_xx ? txx0 + j : ((txx0 + j < SXX) ? txx0 + j : SXX - 1)) * 8u);
     }
-    const double lo_k = F.lower[(lane & 15) % NU], up_k = F.upper[(lane & 15) % NU];
-    const double u_l = F.u[cu_];
+    const double lo_k = D.template ld<R::lower>((unsigned)me * 8u), up_k = D.template ld<R::upper>((unsigned)me * 8u);
+    const double u_l = nom_u[(unsigned)cu_];
 
     // ---- second-order terms of the dynamics (back_pass.c:95-131): d[e] = sum_i Vx[i] * tensor_i[e], i ascending.
     // Here the lanes take the entries e of a tensor slice in the array's own order (e = lane, lane + 64, ...: consecutive
     // lanes on consecutive doubles, every lane busy) and hand the sums to the lanes that own them through LDS.
-    if(FULL) {
+    if constexpr(FULL) {
         constexpr int NTX = (SXX + 63) / 64, NTU = (SUU + 63) / 64, NTC = (NXU + 63) / 64;
         double dxx[NTX], duu[NTU], dxu[NTC];
 #pragma unroll
@@ -387,40 +491,35 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         for(int q = 0; q < NTU; q++) duu[q] = 0.0;
 #pragma unroll
         for(int q = 0; q < NTC; q++) dxu[q] = 0.0;
-#ifndef ILQG_ROW_UNROLL
-#define ILQG_ROW_UNROLL 8
-#endif
-#pragma unroll ILQG_ROW_UNROLL
-        for(int i = 0; i < NX; i++) {
-            const double vxi = lane_bcast(vxl, i);  // Vx[i] (lane i holds it)
-            const auto slice = D.slice(i);
+        D.contract(vxl, dxx, duu, dxu, lane);
+        const LdsBase pd = lds_base(sb + lane * 8);  // (the arrays are padded to whole wavefronts: no lane is left out)
 #pragma unroll
-            for(int q = 0; q < NTC; q++) dxu[q] += vxi * D.fxu(slice, (lane + 64 * q < NXU) ? lane + 64 * q : 0);
+        for(int q = 0; q < NTC; q++) pd[ROW_OFF(dxu) / 8 + 64 * q] = dxu[q];
 #pragma unroll
-            for(int q = 0; q < NTU; q++) duu[q] += vxi * D.fuu(slice, (lane + 64 * q < SUU) ? lane + 64 * q : 0);
+        for(int q = 0; q < NTU; q++) pd[ROW_OFF(duu) / 8 + 64 * q] = duu[q];
 #pragma unroll
-            for(int q = 0; q < NTX; q++) dxx[q] += vxi * D.fxx(slice, (lane + 64 * q < SXX) ? lane + 64 * q : 0);
-        }
-#pragma unroll
-        for(int q = 0; q < NTC; q++)
-            if(lane + 64 * q < NXU) S.dxu[lane + 64 * q] = dxu[q];
-#pragma unroll
-        for(int q = 0; q < NTU; q++)
-            if(lane + 64 * q < SUU) S.duu[lane + 64 * q] = duu[q];
-#pragma unroll
-        for(int q = 0; q < NTX; q++)
-            if(lane + 64 * q < SXX) S.dxx[lane + 64 * q] = dxx[q];
+        for(int q = 0; q < NTX; q++) pd[ROW_OFF(dxx) / 8 + 64 * q] = dxx[q];
     }
     // fx, fu into LDS
+    if constexpr(NX == 16) {
+        // entry lane + 64 q is (row c, column g + 4 q)
+        const LdsBase pf_ = lds_base(sb + ROW_OFF(fx) + (c + g * LDX) * 8), pu_ = lds_base(sb + ROW_OFF(fu) + (c + g * LDX) * 8);
 #pragma unroll
-    for(int q = 0; q < NFX; q++) {
-        const int i = lane + 64 * q;
-        if(i < NX * NX) S.fx[(i % NX) + (i / NX) * LDX] = fx_in[q];
-    }
+        for(int q = 0; q < NFX; q++) pf_[4 * q * LDX] = fx_in[q];
 #pragma unroll
-    for(int q = 0; q < NFU; q++) {
-        const int i = lane + 64 * q;
-        if(i < NXU) S.fu[(i % NX) + (i / NX) * LDX] = fu_in[q];
+        for(int q = 0; q < NFU; q++)
+            if(64 * (q + 1) <= NXU || lane + 64 * q < NXU) pu_[4 * q * LDX] = fu_in[q];
+    } else {
+#pragma unroll
+        for(int q = 0; q < NFX; q++) {
+            const int i = lane + 64 * q;
+            if(i < NX * NX) S.fx[(i % NX) + (i / NX) * LDX] = fx_in[q];
+        }
+#pragma unroll
+        for(int q = 0; q < NFU; q++) {
+            const int i = lane + 64 * q;
+            if(i < NXU) S.fu[(i % NX) + (i / NX) * LDX] = fu_in[q];
+        }
     }
     wave_sync();
 
@@ -428,28 +527,32 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     double qxl = cxl, qul = cul;  // Qx[c], Qu[c]
     {
         double fxc[NX];  // column c of fx
+        const LdsBase p = lds_base(sb + ROW_OFF(fx) + cx_ * (LDX * 8));
 #pragma unroll
-        for(int s = 0; s < NX; s++) fxc[s] = S.fx[s + cx_ * LDX];
+        for(int s = 0; s < NX; s++) fxc[s] = p[s];
         row_dot<NX>(qxl, vxl, fxc);
         double t1[4] = {0.0, 0.0, 0.0, 0.0};
         row_product<NX>(t1, vxx_r, fxc);
+        const LdsBase w = lds_base(sb + ROW_OFF(T1) + (cx_ * LDX + 4 * gx) * 8);
 #pragma unroll
         for(int j = 0; j < 4; j++)
-            if(a[j] < NX && c < NX) S.T1[a[j] + c * LDX] = t1[j];
+            if(a[j] < NX && c < NX) w[j] = t1[j];
     }
     __builtin_amdgcn_sched_barrier(0);
     {
         double fuc[NX];  // column c of fu
+        const LdsBase p = lds_base(sb + ROW_OFF(fu) + cu_ * (LDX * 8));
 #pragma unroll
-        for(int s = 0; s < NX; s++) fuc[s] = S.fu[s + cu_ * LDX];
+        for(int s = 0; s < NX; s++) fuc[s] = p[s];
         row_dot<NX>(qul, vxl, fuc);
         double t2[4] = {0.0, 0.0, 0.0, 0.0};
         row_product<NX>(t2, vxx_r, fuc);
+        const LdsBase w = lds_base(sb + ROW_OFF(T2) + (cu_ * LDX + 4 * gx) * 8);
 #pragma unroll
         for(int j = 0; j < 4; j++)
-            if(a[j] < NX && c < NU) S.T2[a[j] + c * LDX] = t2[j];
+            if(a[j] < NX && c < NU) w[j] = t2[j];
     }
-    if(g == 0 && c < NU) S.Qu[c] = qul;
+    if(lane < NU) S.Qu[lane] = qul;
     wave_sync();
     if(pf) pf->probe(0);
 
@@ -459,32 +562,42 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     double qxu_r[4], qxx_r[4];  // Qxu[4g+j, c], Qxx[4g+j, c]
     {
         double t2c[NX];  // column c of T2
+        {
+            const LdsBase p = lds_base(sb + ROW_OFF(T2) + cu_ * (LDX * 8));
 #pragma unroll
-        for(int s = 0; s < NX; s++) t2c[s] = S.T2[s + cu_ * LDX];
+            for(int s = 0; s < NX; s++) t2c[s] = p[s];
+        }
         {
             double fxt[4];  // fx[c, 4g+j]: what the row mates read
+            const LdsBase p = lds_base(sb + ROW_OFF(fx) + (cx_ + 4 * gx * LDX) * 8);
 #pragma unroll
-            for(int j = 0; j < 4; j++) fxt[j] = S.fx[cx_ + ax[j] * LDX];
+            for(int j = 0; j < 4; j++) fxt[j] = p[j * LDX];
             dpp_source(fxt);
             double dxu[4] = {0.0, 0.0, 0.0, 0.0};
             row_product<NX>(dxu, fxt, t2c);  // sum_si fx[si, r] * T2[si, c]
+            const LdsBase pd = lds_base(sb + ROW_OFF(dxu) + xu0 * 8), w = lds_base(sb + ROW_OFF(Qxu) + (cu_ * LDX + 4 * gx) * 8);
 #pragma unroll
             for(int j = 0; j < 4; j++) {
                 double v = cxu_e[j] + dxu[j];
-                if(FULL) v += S.dxu[exu[j]];
+                if(FULL) v += pd[j];
                 qxu_r[j] = v;
-                if(a[j] < NX && c < NU) S.Qxu[a[j] + c * LDX] = v;
+                if(a[j] < NX && c < NU) w[j] = v;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             double fuc2[NX], fut[4], t2t[4];  // column c of fu; fu[c, 4g+j], T2[c, 4g+j]
+            {
+                const LdsBase p = lds_base(sb + ROW_OFF(fu) + cu_ * (LDX * 8));
 #pragma unroll
-            for(int s = 0; s < NX; s++) fuc2[s] = S.fu[s + cu_ * LDX];
+                for(int s = 0; s < NX; s++) fuc2[s] = p[s];
+                const unsigned lt = (cx_ + 4 * gu * LDX) * 8;
+                const LdsBase pa = lds_base(sb + ROW_OFF(fu) + lt), pb = lds_base(sb + ROW_OFF(T2) + lt);
 #pragma unroll
-            for(int j = 0; j < 4; j++) {
-                fut[j] = S.fu[cx_ + au[j] * LDX];
-                t2t[j] = S.T2[cx_ + au[j] * LDX];
+                for(int j = 0; j < 4; j++) {
+                    fut[j] = pa[j * LDX];
+                    t2t[j] = pb[j * LDX];
+                }
             }
             dpp_source(fut);
             dpp_source(t2t);
@@ -493,13 +606,20 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
 #pragma unroll
             for(int j = 0; j < 4; j++) suu_d[j] = suu[j];  // a diagonal entry stops here
             row_product_t<NX>(suu, fuc2, t2t);  // ... + sum_si fu[si, c] * T2[si, r]      (r < c)
+            const LdsBase pd = lds_base(sb + ROW_OFF(duu) + tuu0 * 8);
+            const unsigned la = (cu_ * LDU + 4 * gu) * 8, lb = (cu_ + 4 * gu * LDU) * 8;  // (4g+j, c) and its mirror image
+            const LdsBase wa = lds_base(sb + ROW_OFF(Quu) + la), wb = lds_base(sb + ROW_OFF(Quu) + lb);
+            const LdsBase fa = lds_base(sb + ROW_OFF(QuuF) + la), fb = lds_base(sb + ROW_OFF(QuuF) + lb);
 #pragma unroll
             for(int j = 0; j < 4; j++) {
                 double v = cuu_e[j] + ((a[j] == c) ? suu_d[j] : suu[j] * 0.5);
-                if(FULL) v += S.duu[euu[j]];
+                if(FULL) v += pd[j];
                 if(a[j] <= c && c < NU) {
-                    S.Quu[ut(au[j], cu_)] = v;
-                    S.QuuF[ut(au[j], cu_)] = (regType == 1 && a[j] == c) ? v + lambda : v;
+                    const double vf = (regType == 1 && a[j] == c) ? v + lambda : v;
+                    wa[j] = v;
+                    wb[j * LDU] = v;
+                    fa[j] = vf;
+                    fb[j * LDU] = vf;
                 }
             }
         }
@@ -507,15 +627,20 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     __builtin_amdgcn_sched_barrier(0);
     {
         double t1c[NX], fxc2[NX], fxt[4], t1t[4];  // columns c of T1 and fx; fx[c, 4g+j], T1[c, 4g+j]
+        {
+            const LdsBase p1 = lds_base(sb + ROW_OFF(T1) + cx_ * (LDX * 8)), p2 = lds_base(sb + ROW_OFF(fx) + cx_ * (LDX * 8));
 #pragma unroll
-        for(int s = 0; s < NX; s++) {
-            t1c[s] = S.T1[s + cx_ * LDX];
-            fxc2[s] = S.fx[s + cx_ * LDX];
-        }
+            for(int s = 0; s < NX; s++) {
+                t1c[s] = p1[s];
+                fxc2[s] = p2[s];
+            }
+            const unsigned lt = (cx_ + 4 * gx * LDX) * 8;
+            const LdsBase pa = lds_base(sb + ROW_OFF(fx) + lt), pb = lds_base(sb + ROW_OFF(T1) + lt);
 #pragma unroll
-        for(int j = 0; j < 4; j++) {
-            fxt[j] = S.fx[cx_ + ax[j] * LDX];
-            t1t[j] = S.T1[cx_ + ax[j] * LDX];
+            for(int j = 0; j < 4; j++) {
+                fxt[j] = pa[j * LDX];
+                t1t[j] = pb[j * LDX];
+            }
         }
         dpp_source(fxt);
         dpp_source(t1t);
@@ -524,10 +649,11 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
 #pragma unroll
         for(int j = 0; j < 4; j++) sxx_d[j] = sxx[j];
         row_product_t<NX>(sxx, fxc2, t1t);
+        const LdsBase pd = lds_base(sb + ROW_OFF(dxx) + txx0 * 8);
 #pragma unroll
         for(int j = 0; j < 4; j++) {
             double v = cxx_e[j] + ((a[j] == c) ? sxx_d[j] : sxx[j] * 0.5);
-            if(FULL) v += S.dxx[exx[j]];
+            if(FULL) v += pd[j];
             qxx_r[j] = v;
         }
     }
@@ -547,11 +673,13 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
 #pragma unroll
             for(int q = 0; q < NU; q++)
                 acc += S.fu[(sy(q, r) % NX) + (sy(q, r) / NX) * LDX] * S.fu[(sy(q, cc) % NX) + (sy(q, cc) / NX) * LDX];
-            S.QuuF[e] = S.Quu[e] + acc * lambda;
+            const double v = S.Quu[r + cc * LDU] + acc * lambda;
+            S.QuuF[r + cc * LDU] = v;
+            S.QuuF[cc + r * LDU] = v;
         }
 #pragma unroll
         for(int j = 0; j < 4; j++) {
-            const int i = ax[j], q = cu_;
+            const int i = (a[j] < NX) ? a[j] : 0, q = cu_;
             double acc = 0.0;
 #pragma unroll
             for(int s = 0; s < NX; s++) acc += S.fx[s + i * LDX] * S.fu[((s + q * NU) % NX) + ((s + q * NU) / NX) * LDX];
@@ -562,60 +690,66 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     if(pf) pf->probe(2);
 
     // ---- box QP, one lane per input (box_qp_rows); warm start: the later step's solution in S.l (back_pass.c:163-166)
-    int nf;
-    const int rc = box_qp_row<NU>(S.QuuF, S.Qu[(lane & 15) % NU], lo_k, up_k, S.l, S.clamp, S.invH, nf);
+    // (from here on fx .. dxu are dead: K, Quu K and the inverse take their place)
+    int nf, mine;
+    unsigned cm_lo, cm_hi;
+    const int rc = box_qp_row<NU, LDU>(S.QuuF, S.Qu[me], lo_k, up_k, S.l, S.clamp, S.invH, nf, &mine, &cm_lo, &cm_hi);
     if(pf) pf->probe(3);
     if(rc < 1) return rc;
 
     // ---- feedback gains (back_pass.c:175-201): lane (g, i) computes K[i, 4g+j], input i = c, state 4g+j
     double kt[4] = {0.0, 0.0, 0.0, 0.0};
     {
-        int cl[NU];
         double nih[NU];  // -invH[i, jj]
+        {
+            const LdsBase p = lds_base(sb + ROW_OFF(invH) + cu_ * (LDU * 8));
 #pragma unroll
-        for(int jj = 0; jj < NU; jj++) {
-            cl[jj] = __builtin_amdgcn_readfirstlane(S.clamp[jj]);  // wave-uniform: a scalar branch below
-            nih[jj] = -S.invH[sy(cu_, jj)];
+            for(int jj = 0; jj < NU; jj++) nih[jj] = -p[jj];
         }
         dpp_source(qxur_r);
         static_for<0, NU>([&](auto jc) {
             constexpr int jj = decltype(jc)::value;
-            if(!cl[jj]) {  // wave-uniform
+            const int cl = ((cm_lo >> jj) & 1u) ? 1 : (((cm_hi >> jj) & 1u) ? 2 : 0);  // wave-uniform: scalar branches
+            if(!cl) {
 #pragma unroll
                 for(int j = 0; j < 4; j++) row_fma<jj>(kt[j], qxur_r[j], nih[jj]);
             } else if(HX) {
                 double w = 0.0;
 #pragma unroll
                 for(int s = 0; s < NU; s++)
-                    if(!cl[s]) w -= S.invH[sy(cu_, s)] * S.QuuF[sy(s, jj)];
-                const double sg = (cl[jj] == 1) ? F.lower_sign[jj] : F.upper_sign[jj];
+                    if(!(((cm_lo | cm_hi) >> s) & 1u)) w -= S.invH[cu_ * LDU + s] * S.QuuF[s + jj * LDU];
+                const double sg = (cl == 1) ? D.template ld<R::lower_sign>(jj * 8u) : D.template ld<R::upper_sign>(jj * 8u);
 #pragma unroll
                 for(int j = 0; j < 4; j++) {
-                    const double hx = (cl[jj] == 1) ? F.lower_hx[ax[j] + jj * NX] : F.upper_hx[ax[j] + jj * NX];
+                    const unsigned o = (unsigned)(((a[j] < NX) ? a[j] : 0) + jj * NX) * 8u;
+                    const double hx = (cl == 1) ? D.template ld<R::lower_hx>(o) : D.template ld<R::upper_hx>(o);
                     kt[j] -= w * (sg * hx);
                 }
             }
         });
-        const int mine = S.clamp[cu_];
         if(mine) {  // a clamped input follows its limit (back_pass.c:186-190)
 #pragma unroll
             for(int j = 0; j < 4; j++) {
                 double v = 0.0;
                 if(HX) {
-                    const double sg = (mine == 1) ? F.lower_sign[cu_] : F.upper_sign[cu_];
-                    const double hx = (mine == 1) ? F.lower_hx[ax[j] + cu_ * NX] : F.upper_hx[ax[j] + cu_ * NX];
+                    const unsigned o = (unsigned)(((a[j] < NX) ? a[j] : 0) + me * NX) * 8u;
+                    const double sg = (mine == 1) ? D.template ld<R::lower_sign>((unsigned)me * 8u)
+                                                  : D.template ld<R::upper_sign>((unsigned)me * 8u);
+                    const double hx = (mine == 1) ? D.template ld<R::lower_hx>(o) : D.template ld<R::upper_hx>(o);
                     v -= sg * hx;
                 }
                 kt[j] = v;
             }
         }
+        const LdsBase w = lds_base(sb + ROW_OFF(K) + (cu_ + 4 * gx * LDU) * 8);
+        double *const ko = Kout + (unsigned)(cu_ + 4 * gx * NU);
 #pragma unroll
         for(int j = 0; j < 4; j++)
             if(a[j] < NX && c < NU) {
-                S.K[c + a[j] * LDU] = kt[j];
-                Kout[c + a[j] * NU] = kt[j];
+                w[j * LDU] = kt[j];
+                ko[j * NU] = kt[j];
             }
-        if(g == 0 && c < NU) lout[c] = S.l[c];
+        if(lane < NU) lout[lane] = S.l[lane];
     }
     wave_sync();
     if(pf) pf->probe(4);
@@ -624,14 +758,18 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     double kc[NU];           // column c of K: K[s, c], state c
     double ql[NU];           // Quu[c, s]: row c of Quu
     double quu_r[4];         // Quu[4g+j, c]
-    double ll = S.l[cu_];    // l[c]
+    double ll = lds_base(sb + ROW_OFF(l) + cu_ * 8)[0];    // l[c]
+    {
+        const LdsBase pk = lds_base(sb + ROW_OFF(K) + cx_ * (LDU * 8)), pq = lds_base(sb + ROW_OFF(Quu) + cu_ * (LDU * 8));
 #pragma unroll
-    for(int s = 0; s < NU; s++) {
-        kc[s] = S.K[s + cx_ * LDU];
-        ql[s] = S.Quu[sy(cu_, s)];
+        for(int s = 0; s < NU; s++) {
+            kc[s] = pk[s];
+            ql[s] = pq[s];
+        }
+        const LdsBase pr = lds_base(sb + ROW_OFF(Quu) + (cu_ * LDU + 4 * gu) * 8);
+#pragma unroll
+        for(int j = 0; j < 4; j++) quu_r[j] = pr[j];
     }
-#pragma unroll
-    for(int j = 0; j < 4; j++) quu_r[j] = S.Quu[sy(au[j], cu_)];
     dpp_source(quu_r);
     dpp_source(ll);
     double bcl = 0.0;        // (Quu l)[c]
@@ -639,16 +777,22 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     {
         double ba[4] = {0.0, 0.0, 0.0, 0.0};
         row_product<NU>(ba, quu_r, kc);  // (Quu K)[4g+j, c]
+        const LdsBase w = lds_base(sb + ROW_OFF(BA) + (cx_ * LDU + 4 * gu) * 8);
 #pragma unroll
         for(int j = 0; j < 4; j++)
-            if(a[j] < NU && c < NX) S.BA[a[j] + c * LDU] = ba[j];
+            if(a[j] < NU && c < NX) w[j] = ba[j];
     }
-    // dV += [l'Qu, 0.5 l'Quu l], term by term over the inputs
-#pragma unroll
-    for(int i = 0; i < NU; i++) {
-        const double qi = lane_bcast(qul, i), li = lane_bcast(ll, i), bi = lane_bcast(bcl, i);
-        dV0 += qi * li;
-        dV1 += 0.5 * li * bi;
+    // dV += [l'Qu, 0.5 l'Quu l], term by term over the inputs (the same sums in every lane)
+    {
+        double hl = 0.5 * ll;
+        dpp_source(hl);
+        dpp_source(bcl);
+        dpp_source(qul);
+        static_for<0, NU>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            row_fma2<i>(dV0, qul, ll);
+            row_fma2<i>(dV1, hl, bcl);
+        });
     }
     wave_sync();
     if(pf) pf->probe(5);
@@ -657,18 +801,20 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     {
         double bac[NU], qxc[NU];  // column c of Quu K; row c of Qxu
         double bat[4];            // (Quu K)[c, 4g+j]
+        {
+            const LdsBase pb = lds_base(sb + ROW_OFF(BA) + cx_ * (LDU * 8)), pq = lds_base(sb + ROW_OFF(Qxu) + cx_ * 8);
 #pragma unroll
-        for(int s = 0; s < NU; s++) {
-            bac[s] = S.BA[s + cx_ * LDU];
-            qxc[s] = S.Qxu[cx_ + s * LDX];
+            for(int s = 0; s < NU; s++) {
+                bac[s] = pb[s];
+                qxc[s] = pq[s * LDX];
+            }
+            const LdsBase pt = lds_base(sb + ROW_OFF(BA) + (cu_ + 4 * gx * LDU) * 8);
+#pragma unroll
+            for(int j = 0; j < 4; j++) bat[j] = pt[j * LDU];
         }
-#pragma unroll
-        for(int j = 0; j < 4; j++) bat[j] = S.BA[cu_ + ax[j] * LDU];
         dpp_source(bat);
         dpp_source(kt);
         dpp_source(qxu_r);
-        dpp_source(bcl);
-        dpp_source(qul);
 
         // Vx[c] = Qx[c] + K[:, c]'(Quu l) + K[:, c]'Qu + Qxu[c, :] l
         double d = 0.0;
@@ -696,25 +842,31 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         row_product<NU>(vd, kt, qx2);
         row_product<NU>(vv, kt, qxc);
         row_product_t<NU>(vv, kc, qxu_r);
+        const LdsBase wa = lds_base(sb + ROW_OFF(Vxx) + (cx_ * LDX + 4 * gx) * 8), wb = lds_base(sb + ROW_OFF(Vxx) + (cx_ + 4 * gx * LDX) * 8);
 #pragma unroll
         for(int j = 0; j < 4; j++)
-            if(a[j] <= c && c < NX) S.Vxx[ut(ax[j], cx_)] = (a[j] == c) ? vd[j] : vv[j];
-        if(g == 0 && c < NX) S.Vx[c] = vx;
+            if(a[j] <= c && c < NX) {
+                const double v = (a[j] == c) ? vd[j] : vv[j];
+                wa[j] = v;
+                wb[j * LDX] = v;
+            }
+        if(lane < NX) S.Vx[lane] = vx;
     }
 
     // gradient-norm summand (back_pass.c:246-251)
     {
-        const double gl = fabs(ll) / (fabs(u_l) + 1.0);
+        double gl = fabs(ll) / (fabs(u_l) + 1.0);
+        dpp_source(gl);
         double gmax = 0.0;
-#pragma unroll
-        for(int i = 0; i < NU; i++) {
-            const double gi = lane_bcast(gl, i);
+        static_for<0, NU>([&](auto ic) {
+            const double gi = row_get<decltype(ic)::value>(gl);
             if(gi > gmax) gmax = gi;
-        }
+        });
         gsum += gmax;
     }
     wave_sync();
     if(pf) pf->probe(6);
+#undef ROW_OFF
     return rc;
 }
 
