@@ -62,6 +62,17 @@ ILQG_DEV void row_fma(double &acc, const double a, const double b) {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(S));
 #endif
 }
+// acc -= (a of lane S of the row) * b          (the sign rides on the operand: no instruction for the negation)
+template <int S>
+ILQG_DEV void row_fnma(double &acc, const double a, const double b) {
+#ifdef ILQG_STRICT_FP
+    double t;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(a), "n"(S));
+    acc = acc + t * -b;
+#else
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(S));
+#endif
+}
 // A value written by a VALU instruction must not be read through DPP in the next two issue slots (the hazard
 // recogniser does not look into inline assembly): every array that is about to be broadcast passes through here.
 ILQG_DEV void dpp_source(double &a) { asm volatile("s_nop 1" : "+v"(a)); }
@@ -131,6 +142,64 @@ ILQG_DEV LdsBase lds_base(unsigned a) {
 }
 constexpr int pad64(int n) { return (n + 63) / 64 * 64; }
 
+// Selections that depend on the lane NUMBER alone: the set of lanes is a 64-bit constant, handed to v_cndmask as a
+// literal — no compare, and no scalar register pair that has to survive (or be spilled) between its uses.
+// lanes_of<M>(j, kind): the lanes whose variable me = (lane mod 16) mod M is == j (kind 0) resp. > j (kind 1)
+template <int M>
+constexpr unsigned long long lanes_of(int j, int kind) {
+    unsigned long long m = 0;
+    for(int l = 0; l < 64; l++) {
+        const int me = (l & 15) % M;
+        if(kind == 0 ? me == j : me > j) m |= 1ull << l;
+    }
+    return m;
+}
+// (lane in MASK) ? a : b
+template <unsigned long long MASK>
+ILQG_DEV double lane_pick(const double a, const double b) {
+    int lo, hi;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(b)), "v"(__double2loint(a)), "s"(MASK));
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(MASK));
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------
+// Square root, reciprocal and quotient for operands in a "plain" range, bit for bit what sqrt(x), 1.0 / d and v / d
+// give.  The compiler expands a double-precision sqrt into 18 instructions and a division into 11; 8 resp. 3 of them
+// scale very small or large operands and patch up 0, Inf and NaN.  With the operand known to lie in [2^-200, 2^200]
+// (the box QP's pivots: tested once per pivot, on the scalar unit) what is left is the same arithmetic, i.e. the same
+// bits.  The quotient by a divisor whose correctly rounded reciprocal rd is at hand: q = v rd, q' = q + (v - d q) rd
+// (two fused operations; Markstein's theorem: q' is the correctly rounded v / d provided nothing underflows —
+// |v| >= 2^-970 or v == 0 with d in the range above; checked against v / d on 3e8 random pairs, oracle/README).
+// The box QP factorises once or twice per backward step with 8 square roots and 24 divisions each time (cholesky.c:6-74).
+// ---------------------------------------------------------------------------
+ILQG_DEV double sqrt_plain(const double x) {
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y0, h0 = y0 * 0.5;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0);
+    const double d0 = __builtin_fma(-g1, g1, x);
+    const double h1 = __builtin_fma(h0, r0, h0);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, x);
+    return __builtin_fma(d1, h1, g2);
+}
+ILQG_DEV double rcp_plain(const double d) {
+    const double y0 = __builtin_amdgcn_rcp(d);
+    const double y1 = __builtin_fma(y0, __builtin_fma(-d, y0, 1.0), y0);
+    const double y2 = __builtin_fma(y1, __builtin_fma(-d, y1, 1.0), y1);
+    return __builtin_fma(__builtin_fma(-d, y2, 1.0), y2, y2);
+}
+ILQG_DEV double div_plain(const double v, const double d, const double rd) {
+    const double q = v * rd;
+    return __builtin_fma(__builtin_fma(-d, q, v), rd, q);
+}
+// x in [2^-200, 2^200]?  x wave-uniform (the same in every lane); evaluated on the scalar unit
+ILQG_DEV bool plain_range(const double x) {
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return hi - 0x33700000u < 0x4c700000u - 0x33700000u;
+}
+
 // ---------------------------------------------------------------------------
 // boxQP.c:39-238 for the wave mapping, cooperative as box_qp_rows (ilqg_wave.hpp: lane i owns variable i — its x, g,
 // limits, clamp flag, row i of H and of the inverse, column i of the Cholesky factor), with every exchange between the
@@ -139,15 +208,16 @@ constexpr int pad64(int n) { return (n + 63) / 64 * 64; }
 // Expression trees, operand order and exits are those of box_qp_rows, i.e. of the reference, bit for bit.
 //
 // LD = 0: H and the inverse are packed upper triangles (the reference's storage; the inverse zeroed on entry).
-// LD > 0: full squares of leading dimension LD with both triangles stored (the backward step's; the inverse is written
-// by the first factorisation, and without one — every variable clamped at once — nothing reads it).  Also handed
-// back: this lane's clamp flag (of variable (lane mod 16) mod M) and the flags of all variables as two wave-uniform
-// masks (at the lower / at the upper limit).
+// LD > 0: H is a full square of leading dimension LD with both triangles stored (the backward step's), S_invH (LD x M)
+// is scratch, and the inverse is handed back in registers: inv_row_out[j] = entry (me, j), me = (lane mod 16) mod M
+// (zeros without a factorisation — every variable clamped at once — where nothing uses it).  Also handed back: this
+// lane's clamp flag (of variable me) and the flags of all variables as two wave-uniform masks (at the lower / at the
+// upper limit).
 // ---------------------------------------------------------------------------
 template <int M, int LD = 0>
 ILQG_DEV int box_qp_row(const double *H /* LDS */, const double g, const double lower, const double upper, double *S_l,
                         int *S_clamp, double *S_invH, int &n_free_out, int *clamp_out = nullptr, unsigned *lo_mask = nullptr,
-                        unsigned *hi_mask = nullptr) {
+                        unsigned *hi_mask = nullptr, double *inv_row_out = nullptr) {
     static_assert(M <= 16, "one 16-lane row holds all variables");
     constexpr int T = tri(M);
     int lane = threadIdx.x & 63;
@@ -227,7 +297,8 @@ ILQG_DEV int box_qp_row(const double *H /* LDS */, const double g, const double 
         if(iter == 0 || changed) {
             // Cholesky of the Hessian with clamped rows and columns replaced by identity (boxQP.c:131-160,
             // cholesky.c:6-27): lane i computes column i of U, row j in step j
-            bool pd = true;
+            bool pd = true, plain = true;  // plain: every pivot in the range of the short forms above
+            double dg[M], rdg[M];          // the factor's diagonal and its reciprocals (the same in every lane)
             static_for<0, M>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 double dot = 0.0;
@@ -236,54 +307,69 @@ ILQG_DEV int box_qp_row(const double *H /* LDS */, const double g, const double 
                     row_fma<j>(dot, Ucol[k], Ucol[k]);  // U[k, j] * U[k, me]
                 });
                 const bool masked = clamp != 0 || ((cm >> j) & 1u);
-                const double a = masked ? ((me == j) ? 1.0 : 0.0) : Hrow[j];
+                const double unit = lane_pick<lanes_of<M>(j, 0)>(1.0, 0.0);  // (me == j) ? 1 : 0
+                const double a = masked ? unit : Hrow[j];
                 double sv = a - dot;
                 dpp_source(sv);
                 const double piv = row_get<j>(sv);
-                if(piv <= 0.0) pd = false;
-                const double d = sqrt(piv);
-                Ucol[j] = (me == j) ? d : ((me > j) ? 1.0 / d * sv : 0.0);
+                if(plain_range(piv)) {  // wave-uniform
+                    dg[j] = sqrt_plain(piv);
+                    rdg[j] = rcp_plain(dg[j]);
+                } else {
+                    plain = false;
+                    if(piv <= 0.0) pd = false;
+                    dg[j] = sqrt(piv);
+                    rdg[j] = 1.0 / dg[j];
+                }
+                // (me == j) ? d : ((me > j) ? 1.0 / d * sv : 0.0)
+                Ucol[j] = lane_pick<lanes_of<M>(j, 0)>(dg[j], lane_pick<lanes_of<M>(j, 1)>(rdg[j] * sv, 0.0));
                 dpp_source(Ucol[j]);
             });
             if(!pd) { rc = -1; break; }
             // explicit inverse (cholesky.c:51-74): lane l solves U'U y = e_l; y[k] for k >= l is row l of the inverse
-            double y[M], ny[M];
-            static_for<0, M>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                double v = (k == me) ? 1.0 : 0.0;
-                static_for<0, k>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    row_fma<k>(v, Ucol[i], ny[i]);  // v -= y[i] * U[i, k]    (y[i] = 0 for i < l: exact zeros)
+            double y[M];
+            auto solve = [&](auto plain_c) {
+                constexpr bool PLAIN = decltype(plain_c)::value;
+                static_for<0, M>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    double v = lane_pick<lanes_of<M>(k, 0)>(1.0, 0.0);  // (k == me) ? 1 : 0
+                    static_for<0, k>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        row_fnma<k>(v, Ucol[i], y[i]);  // v -= y[i] * U[i, k]    (y[i] = 0 for i < l: exact zeros)
+                    });
+                    y[k] = PLAIN ? div_plain(v, dg[k], rdg[k]) : v / dg[k];
                 });
-                y[k] = v / row_get<k>(Ucol[k]);
-                ny[k] = -y[k];
-            });
-            static_for<0, M>([&](auto kr) {
-                constexpr int k = M - 1 - decltype(kr)::value;
-                double v = y[k];
-                static_for<k + 1, M>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    row_fma<i>(v, Ucol[k], ny[i]);  // v -= y[i] * U[k, i]
+                static_for<0, M>([&](auto kr) {
+                    constexpr int k = M - 1 - decltype(kr)::value;
+                    double v = y[k];
+                    static_for<k + 1, M>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        row_fnma<i>(v, Ucol[k], y[i]);  // v -= y[i] * U[k, i]
+                    });
+                    y[k] = PLAIN ? div_plain(v, dg[k], rdg[k]) : v / dg[k];
                 });
-                y[k] = v / row_get<k>(Ucol[k]);
-                ny[k] = -y[k];
-            });
+            };
+            if(plain)
+                solve(std::true_type{});
+            else
+                solve(std::false_type{});
             wave_sync();
             if constexpr(LD > 0) {
-                // lane l < M writes its entries (l, k), k >= l, into both triangles
+                // Row `me` of the (symmetric) inverse for every lane: entries j >= me are the lane's own y[j]; entry
+                // j < me is y[me] of lane j, fetched through LDS — every lane < M lays down its y (a whole row; what
+                // lies left of the diagonal is never read) and every lane reads column `me`.  No store predicates.
                 if(lane < M) {
-                    const LdsBase pr = lds_base(inv_at + me * (LD * 8)), pc = lds_base(inv_at + me * 8);
+                    const LdsBase pr = lds_base(inv_at + me * (LD * 8));
 #pragma unroll
-                    for(int k = 0; k < M; k++)
-                        if(k >= me) {
-                            pr[k] = y[k];
-                            pc[k * LD] = y[k];
-                        }
+                    for(int k = 0; k < M; k++) pr[k] = y[k];
                 }
                 wave_sync();
-                const LdsBase pi = lds_base(inv_at + me * (LD * 8));
-#pragma unroll
-                for(int j = 0; j < M; j++) invrow[j] = pi[j];
+                const LdsBase pc = lds_base(inv_at + me * 8);
+                static_for<0, M>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const double other = pc[j * LD];
+                    invrow[j] = lane_pick<lanes_of<M>(j, 1)>(other, y[j]);  // (me > j) ? lane j's : own
+                });
             } else {
                 if(lane < M) {
 #pragma unroll
@@ -309,7 +395,7 @@ ILQG_DEV int box_qp_row(const double *H /* LDS */, const double g, const double 
         double sr = -x;
         static_for<0, M>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if(!((cm >> j) & 1u)) row_fma<j>(sr, gc, -invrow[j]);
+            if(!((cm >> j) & 1u)) row_fnma<j>(sr, gc, invrow[j]);
         });
         double search = clamp ? 0.0 : sr;
         dpp_source(search);
@@ -340,6 +426,10 @@ ILQG_DEV int box_qp_row(const double *H /* LDS */, const double g, const double 
         S_clamp[me] = clamp;
     }
     if(clamp_out) *clamp_out = clamp;
+    if(inv_row_out) {
+#pragma unroll
+        for(int j = 0; j < M; j++) inv_row_out[j] = invrow[j];
+    }
     if(lo_mask) *lo_mask = (unsigned)__ballot(clamp == 1) & all;
     if(hi_mask) *hi_mask = (unsigned)__ballot(clamp == 2) & all;
     wave_sync();
@@ -363,7 +453,7 @@ struct RowLds {
         };
         struct {                         // from the box QP to the end of the step
             double K[LDU * NX], BA[LDU * NX];    // gains (NU x NX), Quu K
-            double invH[LDU * NU];               // full square
+            double invH[LDU * NU];               // (scratch of the box QP)
         };
     };
     int clamp[NU + NU % 2];
@@ -387,7 +477,11 @@ struct RecordSource {
     const char *rec;  // wave-uniform
     template <unsigned OFF>
     ILQG_DEV double ld(unsigned byte_off) const {
-        return *reinterpret_cast<const double *>(rec + OFF + byte_off);
+        // the member's address in a scalar register pair of its own: the lane part stays a 32-bit offset
+        using gchar = const __attribute__((address_space(1))) char;
+        gchar *member = (gchar *)(rec + OFF);
+        asm("" : "+s"(member));
+        return *(const __attribute__((address_space(1))) double *)(member + byte_off);
     }
     // d??[q] += sum_i Vx[i] * f??_i[lane + 64 q], i ascending (vxl: Vx[c] in lane c of every row)
     ILQG_DEV void contract(const double vxl, double (&dxx)[NTX], double (&duu)[NTU], double (&dxu)[NTC], const int lane) const {
@@ -409,6 +503,16 @@ struct RecordSource {
     }
 };
 
+// the lanes (g, c) whose row 4g + j is == c (kind 0), <= c (kind 1)
+constexpr unsigned long long row_lanes(int j, int kind) {
+    unsigned long long m = 0;
+    for(int l = 0; l < 64; l++) {
+        const int r = 4 * (l >> 4) + j, c = l & 15;
+        if(kind == 0 ? r == c : r <= c) m |= 1ull << l;
+    }
+    return m;
+}
+
 // One backward step.  S: LDS block of the wavefront (Vx, Vxx, l carry over between steps); nom_u / lout / Kout: the
 // step's nominal inputs and gains in global memory.  Returns the box-QP code (wave-uniform); < 1 abandons the sweep
 // (back_pass.c:168-171).
@@ -421,104 +525,116 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     using R = typename Source::R;
     constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
     constexpr int LDX = NX + 1, LDU = NU + 1;
-#define ROW_OFF(m) ((unsigned)offsetof(L, m))
-    // Everything below that depends on the lane alone (rows, columns, the LDS and record addresses made of them) is
-    // loop invariant in the sweep, and the optimiser would move all of it — some hundred values — in front of the
-    // loop and keep it in registers, i.e. spill it.  The lane number is made opaque here, once per step: the
-    // addresses are recomputed by a few integer instructions where they are used.
-    int lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));
-    lane &= 63;  // (the range, for the optimiser: clamps that can never act fold away)
-    const int g = lane >> 4, c = lane & 15;
-    // this lane's column and block of four rows, moved into range where the matrix is smaller than 16: such lanes
-    // compute along on entries that exist, their results are never stored
     constexpr bool P2U = (NU & (NU - 1)) == 0, P2GU = NU % 4 == 0 && ((NU / 4) & (NU / 4 - 1)) == 0;
-    const int cx_ = (c < NX) ? c : 0, cu_ = P2U ? (c & (NU - 1)) : ((c < NU) ? c : 0);
-    const int gx = (4 * g < NX) ? g : 0, gu = P2GU ? (g & (NU / 4 - 1)) : ((4 * g < NU) ? g : 0);
-    const int me = (lane & 15) % NU;  // the input whose limits and clamp flag this lane holds in the box QP
-    int a[4];                         // this lane's rows 4g+j
-#pragma unroll
-    for(int j = 0; j < 4; j++) a[j] = 4 * g + j;
+#define ROW_OFF(m) ((unsigned)offsetof(L, m))
+    // Everything that depends on the lane alone (rows, columns, the LDS and record addresses made of them, the
+    // conditions on them) is loop invariant in the sweep, and the optimiser would move all of it — some hundred values
+    // — in front of the loop and keep it in registers, i.e. spill it; conditions held in scalar register pairs are
+    // spilled through v_writelane / v_readlane, which cost vector instructions.  So the lane number is made opaque at the
+    // start of the step and again behind the box QP (ROW_LANE): what is needed is recomputed there by a few integer
+    // instructions and nothing of it lives across the box QP or the step boundary.  `lane &= 63` gives the optimiser the range back: clamps that can never
+    // act fold away.
+    //   g, c      this lane's block of four rows (4g .. 4g+3) and its column
+    //   cx_, cu_, gx, gu   the same moved into range where the matrix is smaller than 16 (such lanes compute along on
+    //             entries that exist; their results are never stored)
+    //   me        the input whose limits, clamp flag and row of the inverse this lane holds in the box QP
+#define ROW_LANE                                                                              \
+    lane = threadIdx.x & 63;                                                                  \
+    asm volatile("" : "+v"(lane));                                                            \
+    lane &= 63;                                                                               \
+    g = lane >> 4, c = lane & 15;                                                             \
+    cx_ = (c < NX) ? c : 0, cu_ = P2U ? (c & (NU - 1)) : ((c < NU) ? c : 0);                  \
+    gx = (4 * g < NX) ? g : 0, gu = P2GU ? (g & (NU / 4 - 1)) : ((4 * g < NU) ? g : 0);       \
+    me = (lane & 15) % NU;
+    int lane, g, c, cx_, cu_, gx, gu, me;
     const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(&S));  // the block's LDS address
 
-    // ---- value function of step k+1
-    double vxl = lds_base(sb + ROW_OFF(Vx) + cx_ * 8)[0];  // Vx[c]
-    double vxx_r[4];                                       // Vxx[4g+j, c]
+    ROW_LANE
+    double vxl, vxx_r[4];                    // Vx[c], Vxx[4g+j, c] of step k+1
+    double cxl, cul;                         // cx[c], cu[c]
+    double cxu_e[4], cuu_e[4], cxx_e[4];     // cxu[4g+j, c], this lane's entries of the packed cuu and cxx
+    double lo_k, up_k, u_l;                  // limits of input me, u[c]
     {
-        const LdsBase p = lds_base(sb + ROW_OFF(Vxx) + (cx_ * LDX + 4 * gx) * 8);
+        // ---- value function of step k+1
+        vxl = lds_base(sb + ROW_OFF(Vx) + cx_ * 8)[0];
+        {
+            const LdsBase p = lds_base(sb + ROW_OFF(Vxx) + (cx_ * LDX + 4 * gx) * 8);
 #pragma unroll
-        for(int j = 0; j < 4; j++) vxx_r[j] = p[j];
-    }
-    dpp_source(vxl);
-    dpp_source(vxx_r);
-
-    // ---- the step's record.  Everything but the tensors is requested here and consumed behind the tensor
-    // contraction, which hides its latency: fx, fu (on their way to LDS), this lane's entries of the cost derivatives
-    constexpr int NFX = (NX * NX + 63) / 64, NFU = (NXU + 63) / 64;
-    double fx_in[NFX], fu_in[NFU];
-#pragma unroll
-    for(int q = 0; q < NFX; q++) fx_in[q] = D.template ld<R::fx>((unsigned)((lane + 64 * q < NX * NX) ? lane + 64 * q : 0) * 8u);
-#pragma unroll
-    for(int q = 0; q < NFU; q++) fu_in[q] = D.template ld<R::fu>((unsigned)((lane + 64 * q < NXU) ? lane + 64 * q : 0) * 8u);
-    const double cxl = D.template ld<R::cx>((unsigned)cx_ * 8u), cul = D.template ld<R::cu>((unsigned)cu_ * 8u);
-    // this lane's 4 entries of a packed triangle are consecutive: rows 4g..4g+3 of column c where 4g <= c (rows
-    // beyond the diagonal, and all four where 4g > c, are never used: any address inside the array will do)
-    const int rxx = (4 * g <= cx_) ? 4 * g : 0, ruu = (4 * g <= cu_) ? 4 * g : 0;
-    const int txx0 = ut(rxx, cx_), tuu0 = ut(ruu, cu_);  // the first of the four
-    const int xu0 = 4 * gx + cu_ * NX;                    // entry (4g, c) of cxu / dxu; the other three follow
-    double cxu_e[4], cuu_e[4], cxx_e[4];
-#pragma unroll
-    for(int j = 0; j < 4; j++) {
-        // (clamped to the array's last entry unless the largest index a lane can form is inside anyway)
-        constexpr bool in_xu = NX % 4 == 0, in_uu = NU >= 4 && ut(NU - 1 - (NU - 1) % 4, NU - 1) + 3 < SUU,
-                       in_xx = NX >= 4 && ut(NX - 1 - (NX - 1) % 4, NX - 1) + 3 < SXX;
-        cxu_e[j] = D.template ld<R::cxu>((unsigned)(in_xu ? xu0 + j : ((xu0 + j < NXU) ? xu0 + j : NXU - 1)) * 8u);
-        cuu_e[j] = D.template ld<R::cuu>((unsigned)(in_uu ? tuu0 + j : ((tuu0 + j < SUU) ? tuu0 + j : SUU - 1)) * 8u);
-        cxx_e[j] = D.template ld<R::cxx>((unsigned)(in_xx ? txx0 + j : ((txx0 + j < SXX) ? txx0 + j : SXX - 1)) * 8u);
-    }
-    const double lo_k = D.template ld<R::lower>((unsigned)me * 8u), up_k = D.template ld<R::upper>((unsigned)me * 8u);
-    const double u_l = nom_u[(unsigned)cu_];
-
-    // ---- second-order terms of the dynamics (back_pass.c:95-131): d[e] = sum_i Vx[i] * tensor_i[e], i ascending.
-    // Here the lanes take the entries e of a tensor slice in the array's own order (e = lane, lane + 64, ...: consecutive
-    // lanes on consecutive doubles, every lane busy) and hand the sums to the lanes that own them through LDS.
-    if constexpr(FULL) {
-        constexpr int NTX = (SXX + 63) / 64, NTU = (SUU + 63) / 64, NTC = (NXU + 63) / 64;
-        double dxx[NTX], duu[NTU], dxu[NTC];
-#pragma unroll
-        for(int q = 0; q < NTX; q++) dxx[q] = 0.0;
-#pragma unroll
-        for(int q = 0; q < NTU; q++) duu[q] = 0.0;
-#pragma unroll
-        for(int q = 0; q < NTC; q++) dxu[q] = 0.0;
-        D.contract(vxl, dxx, duu, dxu, lane);
-        const LdsBase pd = lds_base(sb + lane * 8);  // (the arrays are padded to whole wavefronts: no lane is left out)
-#pragma unroll
-        for(int q = 0; q < NTC; q++) pd[ROW_OFF(dxu) / 8 + 64 * q] = dxu[q];
-#pragma unroll
-        for(int q = 0; q < NTU; q++) pd[ROW_OFF(duu) / 8 + 64 * q] = duu[q];
-#pragma unroll
-        for(int q = 0; q < NTX; q++) pd[ROW_OFF(dxx) / 8 + 64 * q] = dxx[q];
-    }
-    // fx, fu into LDS
-    if constexpr(NX == 16) {
-        // entry lane + 64 q is (row c, column g + 4 q)
-        const LdsBase pf_ = lds_base(sb + ROW_OFF(fx) + (c + g * LDX) * 8), pu_ = lds_base(sb + ROW_OFF(fu) + (c + g * LDX) * 8);
-#pragma unroll
-        for(int q = 0; q < NFX; q++) pf_[4 * q * LDX] = fx_in[q];
-#pragma unroll
-        for(int q = 0; q < NFU; q++)
-            if(64 * (q + 1) <= NXU || lane + 64 * q < NXU) pu_[4 * q * LDX] = fu_in[q];
-    } else {
-#pragma unroll
-        for(int q = 0; q < NFX; q++) {
-            const int i = lane + 64 * q;
-            if(i < NX * NX) S.fx[(i % NX) + (i / NX) * LDX] = fx_in[q];
+            for(int j = 0; j < 4; j++) vxx_r[j] = p[j];
         }
+        dpp_source(vxl);
+        dpp_source(vxx_r);
+
+        // ---- the step's record.  Everything but the tensors is requested here and consumed behind the tensor
+        // contraction, which hides its latency: fx, fu (on their way to LDS), this lane's entries of the cost derivatives
+        constexpr int NFX = (NX * NX + 63) / 64, NFU = (NXU + 63) / 64;
+        double fx_in[NFX], fu_in[NFU];
 #pragma unroll
-        for(int q = 0; q < NFU; q++) {
-            const int i = lane + 64 * q;
-            if(i < NXU) S.fu[(i % NX) + (i / NX) * LDX] = fu_in[q];
+        for(int q = 0; q < NFX; q++) fx_in[q] = D.template ld<R::fx>((unsigned)((lane + 64 * q < NX * NX) ? lane + 64 * q : 0) * 8u);
+#pragma unroll
+        for(int q = 0; q < NFU; q++) fu_in[q] = D.template ld<R::fu>((unsigned)((lane + 64 * q < NXU) ? lane + 64 * q : 0) * 8u);
+        cxl = D.template ld<R::cx>((unsigned)cx_ * 8u);
+        cul = D.template ld<R::cu>((unsigned)cu_ * 8u);
+        // this lane's 4 entries of a packed triangle are consecutive: rows 4g..4g+3 of column c where 4g <= c (rows
+        // beyond the diagonal, and all four where 4g > c, are never used: any address inside the array will do)
+        const int rxx = (4 * g <= cx_) ? 4 * g : 0, ruu = (4 * g <= cu_) ? 4 * g : 0;
+        const int txx0 = ut(rxx, cx_), tuu0 = ut(ruu, cu_);  // the first of the four
+        const int xu0 = 4 * gx + cu_ * NX;                    // entry (4g, c) of cxu; the other three follow
+#pragma unroll
+        for(int j = 0; j < 4; j++) {
+            // (clamped to the array's last entry unless the largest index a lane can form is inside anyway)
+            constexpr bool in_xu = NX % 4 == 0, in_uu = NU >= 4 && ut(NU - 1 - (NU - 1) % 4, NU - 1) + 3 < SUU,
+                           in_xx = NX >= 4 && ut(NX - 1 - (NX - 1) % 4, NX - 1) + 3 < SXX;
+            cxu_e[j] = D.template ld<R::cxu>((unsigned)(in_xu ? xu0 + j : ((xu0 + j < NXU) ? xu0 + j : NXU - 1)) * 8u);
+            cuu_e[j] = D.template ld<R::cuu>((unsigned)(in_uu ? tuu0 + j : ((tuu0 + j < SUU) ? tuu0 + j : SUU - 1)) * 8u);
+            cxx_e[j] = D.template ld<R::cxx>((unsigned)(in_xx ? txx0 + j : ((txx0 + j < SXX) ? txx0 + j : SXX - 1)) * 8u);
+        }
+        lo_k = D.template ld<R::lower>((unsigned)me * 8u);
+        up_k = D.template ld<R::upper>((unsigned)me * 8u);
+        u_l = nom_u[(unsigned)cu_];
+
+        // ---- second-order terms of the dynamics (back_pass.c:95-131): d[e] = sum_i Vx[i] * tensor_i[e], i ascending.
+        // Here the lanes take the entries e of a tensor slice in the array's own order (e = lane, lane + 64, ...:
+        // consecutive lanes on consecutive doubles, every lane busy) and hand the sums to the lanes that own them
+        // through LDS.
+        if constexpr(FULL) {
+            constexpr int NTX = (SXX + 63) / 64, NTU = (SUU + 63) / 64, NTC = (NXU + 63) / 64;
+            double dxx[NTX], duu[NTU], dxu[NTC];
+#pragma unroll
+            for(int q = 0; q < NTX; q++) dxx[q] = 0.0;
+#pragma unroll
+            for(int q = 0; q < NTU; q++) duu[q] = 0.0;
+#pragma unroll
+            for(int q = 0; q < NTC; q++) dxu[q] = 0.0;
+            D.contract(vxl, dxx, duu, dxu, lane);
+            const LdsBase pd = lds_base(sb + lane * 8);  // (the arrays are padded to whole wavefronts: no lane is left out)
+#pragma unroll
+            for(int q = 0; q < NTC; q++) pd[ROW_OFF(dxu) / 8 + 64 * q] = dxu[q];
+#pragma unroll
+            for(int q = 0; q < NTU; q++) pd[ROW_OFF(duu) / 8 + 64 * q] = duu[q];
+#pragma unroll
+            for(int q = 0; q < NTX; q++) pd[ROW_OFF(dxx) / 8 + 64 * q] = dxx[q];
+        }
+        // fx, fu into LDS
+        if constexpr(NX == 16) {
+            // entry lane + 64 q is (row c, column g + 4 q)
+            const LdsBase pf_ = lds_base(sb + ROW_OFF(fx) + (c + g * LDX) * 8), pu_ = lds_base(sb + ROW_OFF(fu) + (c + g * LDX) * 8);
+#pragma unroll
+            for(int q = 0; q < NFX; q++) pf_[4 * q * LDX] = fx_in[q];
+#pragma unroll
+            for(int q = 0; q < NFU; q++)
+                if(64 * (q + 1) <= NXU || lane + 64 * q < NXU) pu_[4 * q * LDX] = fu_in[q];
+        } else {
+#pragma unroll
+            for(int q = 0; q < NFX; q++) {
+                const int i = lane + 64 * q;
+                if(i < NX * NX) S.fx[(i % NX) + (i / NX) * LDX] = fx_in[q];
+            }
+#pragma unroll
+            for(int q = 0; q < NFU; q++) {
+                const int i = lane + 64 * q;
+                if(i < NXU) S.fu[(i % NX) + (i / NX) * LDX] = fu_in[q];
+            }
         }
     }
     wave_sync();
@@ -536,7 +652,7 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         const LdsBase w = lds_base(sb + ROW_OFF(T1) + (cx_ * LDX + 4 * gx) * 8);
 #pragma unroll
         for(int j = 0; j < 4; j++)
-            if(a[j] < NX && c < NX) w[j] = t1[j];
+            if(4 * g + j < NX && c < NX) w[j] = t1[j];
     }
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -550,9 +666,9 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         const LdsBase w = lds_base(sb + ROW_OFF(T2) + (cu_ * LDX + 4 * gx) * 8);
 #pragma unroll
         for(int j = 0; j < 4; j++)
-            if(a[j] < NX && c < NU) w[j] = t2[j];
+            if(4 * g + j < NX && c < NU) w[j] = t2[j];
+        if(lane < NU) S.Qu[lane] = qul;
     }
-    if(lane < NU) S.Qu[lane] = qul;
     wave_sync();
     if(pf) pf->probe(0);
 
@@ -563,11 +679,11 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     {
         double t2c[NX];  // column c of T2
         {
-            const LdsBase p = lds_base(sb + ROW_OFF(T2) + cu_ * (LDX * 8));
+                {
+                const LdsBase p = lds_base(sb + ROW_OFF(T2) + cu_ * (LDX * 8));
 #pragma unroll
-            for(int s = 0; s < NX; s++) t2c[s] = p[s];
-        }
-        {
+                for(int s = 0; s < NX; s++) t2c[s] = p[s];
+            }
             double fxt[4];  // fx[c, 4g+j]: what the row mates read
             const LdsBase p = lds_base(sb + ROW_OFF(fx) + (cx_ + 4 * gx * LDX) * 8);
 #pragma unroll
@@ -575,18 +691,19 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
             dpp_source(fxt);
             double dxu[4] = {0.0, 0.0, 0.0, 0.0};
             row_product<NX>(dxu, fxt, t2c);  // sum_si fx[si, r] * T2[si, c]
-            const LdsBase pd = lds_base(sb + ROW_OFF(dxu) + xu0 * 8), w = lds_base(sb + ROW_OFF(Qxu) + (cu_ * LDX + 4 * gx) * 8);
+            const LdsBase pd = lds_base(sb + ROW_OFF(dxu) + (4 * gx + cu_ * NX) * 8),
+                          w = lds_base(sb + ROW_OFF(Qxu) + (cu_ * LDX + 4 * gx) * 8);
 #pragma unroll
             for(int j = 0; j < 4; j++) {
                 double v = cxu_e[j] + dxu[j];
                 if(FULL) v += pd[j];
                 qxu_r[j] = v;
-                if(a[j] < NX && c < NU) w[j] = v;
+                if(4 * g + j < NX && c < NU) w[j] = v;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         {
-            double fuc2[NX], fut[4], t2t[4];  // column c of fu; fu[c, 4g+j], T2[c, 4g+j]
+                double fuc2[NX], fut[4], t2t[4];  // column c of fu; fu[c, 4g+j], T2[c, 4g+j]
             {
                 const LdsBase p = lds_base(sb + ROW_OFF(fu) + cu_ * (LDX * 8));
 #pragma unroll
@@ -606,22 +723,23 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
 #pragma unroll
             for(int j = 0; j < 4; j++) suu_d[j] = suu[j];  // a diagonal entry stops here
             row_product_t<NX>(suu, fuc2, t2t);  // ... + sum_si fu[si, c] * T2[si, r]      (r < c)
-            const LdsBase pd = lds_base(sb + ROW_OFF(duu) + tuu0 * 8);
+            const int ruu = (4 * g <= cu_) ? 4 * g : 0;
+            const LdsBase pd = lds_base(sb + ROW_OFF(duu) + ut(ruu, cu_) * 8);
             const unsigned la = (cu_ * LDU + 4 * gu) * 8, lb = (cu_ + 4 * gu * LDU) * 8;  // (4g+j, c) and its mirror image
             const LdsBase wa = lds_base(sb + ROW_OFF(Quu) + la), wb = lds_base(sb + ROW_OFF(Quu) + lb);
             const LdsBase fa = lds_base(sb + ROW_OFF(QuuF) + la), fb = lds_base(sb + ROW_OFF(QuuF) + lb);
-#pragma unroll
-            for(int j = 0; j < 4; j++) {
-                double v = cuu_e[j] + ((a[j] == c) ? suu_d[j] : suu[j] * 0.5);
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                double v = cuu_e[j] + lane_pick<row_lanes(j, 0)>(suu_d[j], suu[j] * 0.5);  // (4g+j == c) ? .. : ..
                 if(FULL) v += pd[j];
-                if(a[j] <= c && c < NU) {
-                    const double vf = (regType == 1 && a[j] == c) ? v + lambda : v;
+                const double vf = lane_pick<row_lanes(j, 0)>(v + ((regType == 1) ? lambda : 0.0), v);
+                if(4 * g + j <= c && c < NU) {
                     wa[j] = v;
                     wb[j * LDU] = v;
-                    fa[j] = vf;
-                    fb[j * LDU] = vf;
+                    fa[j] = (regType == 1) ? vf : v;
+                    fb[j * LDU] = (regType == 1) ? vf : v;
                 }
-            }
+            });
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -649,13 +767,14 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
 #pragma unroll
         for(int j = 0; j < 4; j++) sxx_d[j] = sxx[j];
         row_product_t<NX>(sxx, fxc2, t1t);
-        const LdsBase pd = lds_base(sb + ROW_OFF(dxx) + txx0 * 8);
-#pragma unroll
-        for(int j = 0; j < 4; j++) {
-            double v = cxx_e[j] + ((a[j] == c) ? sxx_d[j] : sxx[j] * 0.5);
+        const int rxx = (4 * g <= cx_) ? 4 * g : 0;
+        const LdsBase pd = lds_base(sb + ROW_OFF(dxx) + ut(rxx, cx_) * 8);
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            double v = cxx_e[j] + lane_pick<row_lanes(j, 0)>(sxx_d[j], sxx[j] * 0.5);
             if(FULL) v += pd[j];
             qxx_r[j] = v;
-        }
+        });
     }
     __builtin_amdgcn_sched_barrier(0);
     wave_sync();
@@ -679,7 +798,7 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         }
 #pragma unroll
         for(int j = 0; j < 4; j++) {
-            const int i = (a[j] < NX) ? a[j] : 0, q = cu_;
+            const int i = (4 * g + j < NX) ? 4 * g + j : 0, q = cu_;
             double acc = 0.0;
 #pragma unroll
             for(int s = 0; s < NX; s++) acc += S.fx[s + i * LDX] * S.fu[((s + q * NU) % NX) + ((s + q * NU) / NX) * LDX];
@@ -690,38 +809,35 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
     if(pf) pf->probe(2);
 
     // ---- box QP, one lane per input (box_qp_rows); warm start: the later step's solution in S.l (back_pass.c:163-166)
-    // (from here on fx .. dxu are dead: K, Quu K and the inverse take their place)
+    // (from here on fx .. dxu are dead: K, Quu K and the box QP's scratch take their place)
     int nf, mine;
     unsigned cm_lo, cm_hi;
-    const int rc = box_qp_row<NU, LDU>(S.QuuF, S.Qu[me], lo_k, up_k, S.l, S.clamp, S.invH, nf, &mine, &cm_lo, &cm_hi);
+    double ih[NU];  // invH[me, :]
+    // (the gradient of input me: with NU a power of two that is this lane's own Qu[c])
+    const int rc = box_qp_row<NU, LDU>(S.QuuF, P2U ? qul : S.Qu[me], lo_k, up_k, S.l, S.clamp, S.invH, nf, &mine, &cm_lo, &cm_hi, ih);
     if(pf) pf->probe(3);
     if(rc < 1) return rc;
 
     // ---- feedback gains (back_pass.c:175-201): lane (g, i) computes K[i, 4g+j], input i = c, state 4g+j
     double kt[4] = {0.0, 0.0, 0.0, 0.0};
+    ROW_LANE
     {
-        double nih[NU];  // -invH[i, jj]
-        {
-            const LdsBase p = lds_base(sb + ROW_OFF(invH) + cu_ * (LDU * 8));
-#pragma unroll
-            for(int jj = 0; jj < NU; jj++) nih[jj] = -p[jj];
-        }
         dpp_source(qxur_r);
         static_for<0, NU>([&](auto jc) {
             constexpr int jj = decltype(jc)::value;
             const int cl = ((cm_lo >> jj) & 1u) ? 1 : (((cm_hi >> jj) & 1u) ? 2 : 0);  // wave-uniform: scalar branches
             if(!cl) {
 #pragma unroll
-                for(int j = 0; j < 4; j++) row_fma<jj>(kt[j], qxur_r[j], nih[jj]);
+                for(int j = 0; j < 4; j++) row_fnma<jj>(kt[j], qxur_r[j], ih[jj]);  // K -= Qxu(reg) invH
             } else if(HX) {
                 double w = 0.0;
 #pragma unroll
                 for(int s = 0; s < NU; s++)
-                    if(!(((cm_lo | cm_hi) >> s) & 1u)) w -= S.invH[cu_ * LDU + s] * S.QuuF[s + jj * LDU];
+                    if(!(((cm_lo | cm_hi) >> s) & 1u)) w -= ih[s] * S.QuuF[s + jj * LDU];
                 const double sg = (cl == 1) ? D.template ld<R::lower_sign>(jj * 8u) : D.template ld<R::upper_sign>(jj * 8u);
 #pragma unroll
                 for(int j = 0; j < 4; j++) {
-                    const unsigned o = (unsigned)(((a[j] < NX) ? a[j] : 0) + jj * NX) * 8u;
+                    const unsigned o = (unsigned)(((4 * g + j < NX) ? 4 * g + j : 0) + jj * NX) * 8u;
                     const double hx = (cl == 1) ? D.template ld<R::lower_hx>(o) : D.template ld<R::upper_hx>(o);
                     kt[j] -= w * (sg * hx);
                 }
@@ -732,7 +848,7 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
             for(int j = 0; j < 4; j++) {
                 double v = 0.0;
                 if(HX) {
-                    const unsigned o = (unsigned)(((a[j] < NX) ? a[j] : 0) + me * NX) * 8u;
+                    const unsigned o = (unsigned)(((4 * g + j < NX) ? 4 * g + j : 0) + me * NX) * 8u;
                     const double sg = (mine == 1) ? D.template ld<R::lower_sign>((unsigned)me * 8u)
                                                   : D.template ld<R::upper_sign>((unsigned)me * 8u);
                     const double hx = (mine == 1) ? D.template ld<R::lower_hx>(o) : D.template ld<R::upper_hx>(o);
@@ -745,7 +861,7 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         double *const ko = Kout + (unsigned)(cu_ + 4 * gx * NU);
 #pragma unroll
         for(int j = 0; j < 4; j++)
-            if(a[j] < NX && c < NU) {
+            if(4 * g + j < NX && c < NU) {
                 w[j * LDU] = kt[j];
                 ko[j * NU] = kt[j];
             }
@@ -756,34 +872,32 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
 
     // ---- Quu l, Quu K; expected cost change (back_pass.c:205-214)
     double kc[NU];           // column c of K: K[s, c], state c
-    double ql[NU];           // Quu[c, s]: row c of Quu
-    double quu_r[4];         // Quu[4g+j, c]
-    double ll = lds_base(sb + ROW_OFF(l) + cu_ * 8)[0];    // l[c]
+    double ll, bcl = 0.0;    // l[c], (Quu l)[c]
     {
-        const LdsBase pk = lds_base(sb + ROW_OFF(K) + cx_ * (LDU * 8)), pq = lds_base(sb + ROW_OFF(Quu) + cu_ * (LDU * 8));
+        double ql[NU];       // Quu[c, s]: row c of Quu
+        double quu_r[4];     // Quu[4g+j, c]
+        ll = lds_base(sb + ROW_OFF(l) + cu_ * 8)[0];
+        {
+            const LdsBase pk = lds_base(sb + ROW_OFF(K) + cx_ * (LDU * 8)), pq = lds_base(sb + ROW_OFF(Quu) + cu_ * (LDU * 8));
 #pragma unroll
-        for(int s = 0; s < NU; s++) {
-            kc[s] = pk[s];
-            ql[s] = pq[s];
+            for(int s = 0; s < NU; s++) {
+                kc[s] = pk[s];
+                ql[s] = pq[s];
+            }
+            const LdsBase pr = lds_base(sb + ROW_OFF(Quu) + (cu_ * LDU + 4 * gu) * 8);
+#pragma unroll
+            for(int j = 0; j < 4; j++) quu_r[j] = pr[j];
         }
-        const LdsBase pr = lds_base(sb + ROW_OFF(Quu) + (cu_ * LDU + 4 * gu) * 8);
-#pragma unroll
-        for(int j = 0; j < 4; j++) quu_r[j] = pr[j];
-    }
-    dpp_source(quu_r);
-    dpp_source(ll);
-    double bcl = 0.0;        // (Quu l)[c]
-    row_dot<NU>(bcl, ll, ql);
-    {
+        dpp_source(quu_r);
+        dpp_source(ll);
+        row_dot<NU>(bcl, ll, ql);
         double ba[4] = {0.0, 0.0, 0.0, 0.0};
         row_product<NU>(ba, quu_r, kc);  // (Quu K)[4g+j, c]
         const LdsBase w = lds_base(sb + ROW_OFF(BA) + (cx_ * LDU + 4 * gu) * 8);
 #pragma unroll
         for(int j = 0; j < 4; j++)
-            if(a[j] < NU && c < NX) w[j] = ba[j];
-    }
-    // dV += [l'Qu, 0.5 l'Quu l], term by term over the inputs (the same sums in every lane)
-    {
+            if(4 * g + j < NU && c < NX) w[j] = ba[j];
+        // dV += [l'Qu, 0.5 l'Quu l], term by term over the inputs (the same sums in every lane)
         double hl = 0.5 * ll;
         dpp_source(hl);
         dpp_source(bcl);
@@ -832,8 +946,10 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         double vv[4], qx2[NU];
 #pragma unroll
         for(int s = 0; s < NU; s++) qx2[s] = qxc[s] * 2.0;
-#pragma unroll
-        for(int j = 0; j < 4; j++) vv[j] = qxx_r[j] + ((a[j] == c) ? sq_d[j] : sq[j] * 0.5);
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            vv[j] = qxx_r[j] + lane_pick<row_lanes(j, 0)>(sq_d[j], sq[j] * 0.5);
+        });
         // the reference's loop nest touches packed entry (r, c) first as (i = r, j = c), then as (i = c, j = r);
         // a diagonal entry once, with the term doubled
         double vd[4];
@@ -843,13 +959,14 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         row_product<NU>(vv, kt, qxc);
         row_product_t<NU>(vv, kc, qxu_r);
         const LdsBase wa = lds_base(sb + ROW_OFF(Vxx) + (cx_ * LDX + 4 * gx) * 8), wb = lds_base(sb + ROW_OFF(Vxx) + (cx_ + 4 * gx * LDX) * 8);
-#pragma unroll
-        for(int j = 0; j < 4; j++)
-            if(a[j] <= c && c < NX) {
-                const double v = (a[j] == c) ? vd[j] : vv[j];
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const double v = lane_pick<row_lanes(j, 0)>(vd[j], vv[j]);
+            if(4 * g + j <= c && c < NX) {
                 wa[j] = v;
                 wb[j * LDX] = v;
             }
+        });
         if(lane < NX) S.Vx[lane] = vx;
     }
 
@@ -859,14 +976,14 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         dpp_source(gl);
         double gmax = 0.0;
         static_for<0, NU>([&](auto ic) {
-            const double gi = row_get<decltype(ic)::value>(gl);
-            if(gi > gmax) gmax = gi;
+            gmax = __builtin_fmax(gmax, row_get<decltype(ic)::value>(gl));  // (none of them negative; a NaN is skipped either way)
         });
         gsum += gmax;
     }
     wave_sync();
     if(pf) pf->probe(6);
 #undef ROW_OFF
+#undef ROW_LANE
     return rc;
 }
 
