@@ -120,6 +120,13 @@ def test_cooperative_boxqp_equals_the_per_lane_one(ilqg, n, strict):
     lo = np.concatenate([g["qp_lo"][sel][:, :n], -np.abs(rng.standard_normal((R, n)))])
     hi = np.concatenate([g["qp_hi"][sel][:, :n], np.abs(rng.standard_normal((R, n)))])
     x0 = np.concatenate([g["qp_x0"][sel][:, :n], rng.standard_normal((R, n))])
+    # the cooperative form takes short forms of sqrt / reciprocal / quotient while the pivots lie in [2^-200, 2^200] and
+    # the compiler's general ones otherwise: the last 120 random problems are scaled so that both happen with large and
+    # with small numbers (pivots ~ 2^+-150: short forms; ~ 2^+-260: general)
+    scale = np.ones(len(H))
+    scale[-120:] = np.repeat(2.0 ** np.array([-260.0, -150.0, 150.0, 260.0]), 30)
+    H = H * scale[:, None]
+    gg = gg * scale[:, None]
     a = ilqg.boxqp_batch(n, H, gg, lo, hi, x0, strict=strict)
     b = ilqg.boxqp_batch(n, H, gg, lo, hi, x0, strict=strict, cooperative=True)
     assert len(set(a["rc"].tolist())) >= 4
@@ -133,7 +140,10 @@ def test_cooperative_boxqp_equals_the_per_lane_one(ilqg, n, strict):
     # product build: the compiler contracts the two code shapes into FMAs differently, so values agree to rounding
     # and an exit taken at rounding resolution (see test_boxqp_golden) may differ
     same = (a["rc"] == b["rc"]) & np.all(a["clamp"] == b["clamp"], axis=1)
-    assert same.mean() > 0.97, same.mean()
+    assert same[scale == 1.0].mean() > 0.97, same[scale == 1.0].mean()
+    # (the scaled problems meet the absolute thresholds of boxQP.c — gradient 1e-8, improvement 1e-8 relative — at
+    # rounding resolution far more often; bit-equality on them is what the strict build asserts above)
+    assert same[scale != 1.0].mean() > 0.7, same[scale != 1.0].mean()
     reg = same & (a["rc"] >= 2)  # (rc 1: 100 iterations on a numerically singular Hessian, rounding-chaotic)
     scale = np.maximum(1.0, np.abs(a["x"][reg]).max(axis=1, keepdims=True))
     assert np.all(np.abs(a["x"][reg] - b["x"][reg]) <= 1e-7 * scale)
