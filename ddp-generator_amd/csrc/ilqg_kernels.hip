@@ -1258,8 +1258,12 @@ __global__ __launch_bounds__(WAVE *PACK_WAVES) void k_pack_records(DevPtrs P) {
 constexpr size_t fact_stride() {
     const size_t A = offsetof(trajEl_t, fxx) + NBASIS * sizeof(double);
     const size_t TAIL = offsetof(trajEl_t, fxu) + sizeof(double) * NX * NXU, T = sizeof(trajEl_t) - TAIL;
-    if(T == 0) return (A + 7) / 8 * 8;
-    for(size_t S = (A + T + 7) / 8 * 8; S < sizeof(trajEl_t); S += 8) {
+#ifndef ILQG_FACT_ALIGN
+#define ILQG_FACT_ALIGN 128
+#endif
+    constexpr size_t AL = ILQG_FACT_ALIGN;  // whole cache lines (measured against 8: k_derivs_wave 116 -> 113 ms per iteration)
+    if(T == 0) return (A + AL - 1) / AL * AL;
+    for(size_t S = (A + T + AL - 1) / AL * AL; S < sizeof(trajEl_t); S += AL) {
         const size_t r = TAIL % S;
         if(r >= A && r + T <= S) return S;
     }
@@ -1372,36 +1376,52 @@ struct RecOffsets {
 constexpr int FACT_SLICE = SXX + SUU + NXU;  // doubles per slice
 struct FactoredSource : RecordSource<NX, NU, true, RecOffsets> {
     unsigned table;  // LDS address of the coefficient tables
+    unsigned basis;  // LDS address of 64 doubles of this wavefront: the step's products, for all lanes to read
     double product;  // lane i: product i of this step (bp_tensor_basis)
     ILQG_DEV void contract(const double vxl, double (&dxx)[NTX], double (&duu)[NTU], double (&dxu)[NTC], const int lane) const {
         constexpr int PER = NTX + NTU + NTC;
-        const LdsBase p = lds_base(table + lane * 8);
-        // the entries of slice i this lane multiplies: xx, uu, xu
-        auto fetch = [&](int i, double (&t)[PER]) {
+        // The products every lane multiplies by are wave-uniform numbers held one per lane.  Through LDS (one store,
+        // then reads of one address by all lanes) they cost no vector instruction; two v_readlane each otherwise.
+        lds_base(basis + lane * 8)[0] = product;
+        wave_sync();
+        const LdsBase p = lds_base(table + lane * 8), pg = lds_base(basis);
+        // what this lane multiplies of slice i: its entries of xx, uu, xu and the three products
+        auto fetch = [&](auto ic, double (&t)[PER], double (&g)[3]) {
+            constexpr int i = decltype(ic)::value;
 #pragma unroll
             for(int q = 0; q < NTX; q++) t[q] = p.fetch(i * FACT_SLICE + 64 * q);
 #pragma unroll
             for(int q = 0; q < NTU; q++) t[NTX + q] = p.fetch(i * FACT_SLICE + SXX + 64 * q);
 #pragma unroll
             for(int q = 0; q < NTC; q++) t[NTX + NTU + q] = p.fetch(i * FACT_SLICE + SXX + SUU + 64 * q);
+            // (entries of constant tables: folded when the loop is unrolled, as are the comparisons below)
+            const int sxx = ilqg_tensor_slice_xx[i], suu = ilqg_tensor_slice_uu[i], sxu = ilqg_tensor_slice_xu[i];
+#ifdef ILQG_BASIS_READLANE  // (comparison build: the products by v_readlane)
+            g[0] = lane_bcast(product, sxx);
+            g[1] = lane_bcast(product, suu);
+            g[2] = lane_bcast(product, sxu);
+#else
+            g[0] = pg.fetch(sxx);
+            g[1] = (suu == sxx) ? g[0] : pg.fetch(suu);
+            g[2] = (sxu == sxx) ? g[0] : ((sxu == suu) ? g[1] : pg.fetch(sxu));
+#endif
         };
-        double cur[PER], nxt[PER];
-        fetch(0, cur);
+        double cur[PER], nxt[PER], gc[3], gn[3];
+        fetch(std::integral_constant<int, 0>{}, cur, gc);
         static_for<0, NX>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if(i + 1 < NX) fetch(i + 1, nxt);  // (in flight during this slice's arithmetic)
-            // the products the entries of slice i are multiples of (wave-uniform)
-            const double gxx = lane_bcast(product, ilqg_tensor_slice_xx[i]), guu = lane_bcast(product, ilqg_tensor_slice_uu[i]),
-                         gxu = lane_bcast(product, ilqg_tensor_slice_xu[i]);
+            if constexpr(i + 1 < NX) fetch(std::integral_constant<int, i + 1>{}, nxt, gn);  // (in flight during this slice's arithmetic)
             // d += Vx[i] * (coefficient * product), Vx[i] broadcast from lane i of the row
 #pragma unroll
-            for(int q = 0; q < NTC; q++) row_fma<i>(dxu[q], vxl, cur[NTX + NTU + q] * gxu);
+            for(int q = 0; q < NTC; q++) row_fma<i>(dxu[q], vxl, cur[NTX + NTU + q] * gc[2]);
 #pragma unroll
-            for(int q = 0; q < NTU; q++) row_fma<i>(duu[q], vxl, cur[NTX + q] * guu);
+            for(int q = 0; q < NTU; q++) row_fma<i>(duu[q], vxl, cur[NTX + q] * gc[1]);
 #pragma unroll
-            for(int q = 0; q < NTX; q++) row_fma<i>(dxx[q], vxl, cur[q] * gxx);
+            for(int q = 0; q < NTX; q++) row_fma<i>(dxx[q], vxl, cur[q] * gc[0]);
 #pragma unroll
             for(int q = 0; q < PER; q++) cur[q] = nxt[q];
+#pragma unroll
+            for(int q = 0; q < 3; q++) gc[q] = gn[q];
         });
     }
 };
@@ -1424,6 +1444,7 @@ __device__ __forceinline__ int step_of_wave(Lds &S, const double *tables, double
         FactoredSource D;
         D.rec = reinterpret_cast<const char *>(t);
         D.table = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(tables));
+        D.basis = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(S.basis));
         D.product = product;
         return back_step_row<NX, NU, FULL, HX>(S, D, u_nom, lout, Kout, lambda, regType, dV0, dV1, gsum, pf);
 #else

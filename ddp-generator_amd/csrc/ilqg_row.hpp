@@ -162,6 +162,13 @@ ILQG_DEV double lane_pick(const double a, const double b) {
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(MASK));
     return __hiloint2double(hi, lo);
 }
+// (lane in MASK) ? 1.0 : 0.0        (the low words agree: one selection)
+template <unsigned long long MASK>
+ILQG_DEV double lane_unit() {
+    int hi;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(hi) : "v"(0x3ff00000), "s"(MASK));
+    return __hiloint2double(hi, 0);
+}
 
 // ---------------------------------------------------------------------------
 // Square root, reciprocal and quotient for operands in a "plain" range, bit for bit what sqrt(x), 1.0 / d and v / d
@@ -307,7 +314,7 @@ ILQG_DEV int box_qp_row(const double *H /* LDS */, const double g, const double 
                     row_fma<j>(dot, Ucol[k], Ucol[k]);  // U[k, j] * U[k, me]
                 });
                 const bool masked = clamp != 0 || ((cm >> j) & 1u);
-                const double unit = lane_pick<lanes_of<M>(j, 0)>(1.0, 0.0);  // (me == j) ? 1 : 0
+                const double unit = lane_unit<lanes_of<M>(j, 0)>();  // (me == j) ? 1 : 0
                 const double a = masked ? unit : Hrow[j];
                 double sv = a - dot;
                 dpp_source(sv);
@@ -332,7 +339,7 @@ ILQG_DEV int box_qp_row(const double *H /* LDS */, const double g, const double 
                 constexpr bool PLAIN = decltype(plain_c)::value;
                 static_for<0, M>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    double v = lane_pick<lanes_of<M>(k, 0)>(1.0, 0.0);  // (k == me) ? 1 : 0
+                    double v = lane_unit<lanes_of<M>(k, 0)>();  // (k == me) ? 1 : 0
                     static_for<0, k>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
                         row_fnma<k>(v, Ucol[i], y[i]);  // v -= y[i] * U[i, k]    (y[i] = 0 for i < l: exact zeros)
@@ -450,6 +457,7 @@ struct RowLds {
             double T1[LDX * NX], T2[LDX * NU];   // Vxx fx, Vxx fu
             // sum_i Vx[i] * (fxx_i, fuu_i, fxu_i), packed as the tensors' slices are; padded: every lane stores its sums
             double dxx[pad64(SXX)], duu[pad64(SUU)], dxu[pad64(NXU)];
+            double basis[64];                    // factored tensors: the step's products (see FactoredSource)
         };
         struct {                         // from the box QP to the end of the step
             double K[LDU * NX], BA[LDU * NX];    // gains (NU x NX), Quu K
