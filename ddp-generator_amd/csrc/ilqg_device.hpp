@@ -110,6 +110,40 @@ ILQG_DEV void add_mul2_tri(double *base, const double *B, const double *A, const
 }
 
 // ---------------------------------------------------------------------------
+// Square root, reciprocal and quotient for operands in a "plain" range, bit for bit what sqrt(x), 1.0 / d and v / d
+// give.  The compiler expands a double-precision sqrt into 18 instructions and a division into 11; 8 resp. 3 of them
+// scale very small or large operands and patch up 0, Inf and NaN.  With the operand known to lie in [2^-200, 2^200]
+// (the box QP's pivots, tested as they come) what is left is the same arithmetic, i.e. the same
+// bits.  The quotient by a divisor whose correctly rounded reciprocal rd is at hand: q = v rd, q' = q + (v - d q) rd
+// (two fused operations; Markstein's theorem: q' is the correctly rounded v / d provided nothing underflows —
+// |v| >= 2^-970 or v == 0 with d in the range above; checked against v / d on 3e8 random pairs, oracle/README).
+// The box QP factorises once or twice per backward step with 8 square roots and 24 divisions each time (cholesky.c:6-74).
+// ---------------------------------------------------------------------------
+ILQG_DEV double sqrt_plain(const double x) {
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y0, h0 = y0 * 0.5;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0);
+    const double d0 = __builtin_fma(-g1, g1, x);
+    const double h1 = __builtin_fma(h0, r0, h0);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, x);
+    return __builtin_fma(d1, h1, g2);
+}
+ILQG_DEV double rcp_plain(const double d) {
+    const double y0 = __builtin_amdgcn_rcp(d);
+    const double y1 = __builtin_fma(y0, __builtin_fma(-d, y0, 1.0), y0);
+    const double y2 = __builtin_fma(y1, __builtin_fma(-d, y1, 1.0), y1);
+    return __builtin_fma(__builtin_fma(-d, y2, 1.0), y2, y2);
+}
+ILQG_DEV double div_plain(const double v, const double d, const double rd) {
+    const double q = v * rd;
+    return __builtin_fma(__builtin_fma(-d, q, v), rd, q);
+}
+// x in [2^-200, 2^200]?  (per lane)
+ILQG_DEV bool plain_range_lane(const double x) { return (unsigned)__double2hiint(x) - 0x33700000u < 0x4c700000u - 0x33700000u; }
+
+// ---------------------------------------------------------------------------
 // cholesky.c (plain part)
 // ---------------------------------------------------------------------------
 // A = U'U on packed upper triangles.  false as soon as a pivot is <= 0.
@@ -156,6 +190,60 @@ ILQG_DEV void chol_inverse(const double *U, double *inv) {
             inv[ut(l, k)] = x[k];
         }
     }
+}
+
+// chol_factor + chol_inverse (what the box QP does with the free block, boxQP.c:131-146) with the short forms above
+// while every pivot of every active lane lies in their range — the same bits — and once more in the general form if
+// one does not (a pivot <= 0 among them: `false` as from chol_factor).  A quotient is then a chain of 3 dependent
+// instructions instead of 11, a square root of 10 instead of 18: with one wavefront per SIMD the chain is what counts.
+template <int M>
+ILQG_DEV bool chol_factor_inverse(const double *A, double *inv) {
+    {
+        double U[tri(M)], rd[M];
+        bool plain = true;
+#pragma unroll
+        for(int i = 0; i < M; i++)
+#pragma unroll
+            for(int j = 0; j <= i; j++) {
+                double dot = 0.0;
+#pragma unroll
+                for(int k = 0; k < j; k++) dot += U[ut(k, i)] * U[ut(k, j)];
+                const double s = A[ut(j, i)] - dot;
+                if(i == j) {
+                    plain = plain && plain_range_lane(s);
+                    U[ut(j, i)] = sqrt_plain(s);
+                    rd[j] = rcp_plain(U[ut(j, i)]);
+                } else {
+                    U[ut(j, i)] = rd[j] * s;
+                }
+            }
+        if(__builtin_amdgcn_ballot_w64(!plain) == 0ull) {
+#pragma unroll
+            for(int l = 0; l < M; l++) {
+                double x[M];
+#pragma unroll
+                for(int k = 0; k < M; k++) x[k] = (k == l) ? 1.0 : 0.0;
+#pragma unroll
+                for(int k = l; k < M; k++) {
+#pragma unroll
+                    for(int i = l; i < k; i++) x[k] -= x[i] * U[ut(i, k)];
+                    x[k] = div_plain(x[k], U[ut(k, k)], rd[k]);
+                }
+#pragma unroll
+                for(int k = M - 1; k >= l; k--) {
+#pragma unroll
+                    for(int i = k + 1; i < M; i++) x[k] -= x[i] * U[ut(k, i)];
+                    x[k] = div_plain(x[k], U[ut(k, k)], rd[k]);
+                    inv[ut(l, k)] = x[k];
+                }
+            }
+            return true;
+        }
+    }
+    double U[tri(M)];
+    const bool pd = chol_factor<M>(A, U);
+    chol_inverse<M>(U, inv);
+    return pd;
 }
 
 // ---------------------------------------------------------------------------
@@ -292,14 +380,13 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
         // factor + explicit inverse of the free block when the free set changed (boxQP.c:129-146)
         if(pf) pf->probe(2);
         if(rc == 0 && (iter == 0 || changed)) {
-            double Hm[T], U[T], inv[T];
+            double Hm[T], inv[T];
 #pragma unroll
             for(int j = 0; j < M; j++)
 #pragma unroll
                 for(int i = 0; i <= j; i++)
                     Hm[ut(i, j)] = (clamp[i] || clamp[j]) ? ((i == j) ? 1.0 : 0.0) : H[ut(i, j)];
-            const bool pd = chol_factor<M>(Hm, U);
-            chol_inverse<M>(U, inv);
+            const bool pd = chol_factor_inverse<M>(Hm, inv);
             if(!pd) rc = -1;
 #pragma unroll
             for(int i = 0; i < T; i++) invH[i] = pd ? inv[i] : invH[i];

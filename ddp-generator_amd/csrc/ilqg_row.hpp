@@ -170,37 +170,7 @@ ILQG_DEV double lane_unit() {
     return __hiloint2double(hi, 0);
 }
 
-// ---------------------------------------------------------------------------
-// Square root, reciprocal and quotient for operands in a "plain" range, bit for bit what sqrt(x), 1.0 / d and v / d
-// give.  The compiler expands a double-precision sqrt into 18 instructions and a division into 11; 8 resp. 3 of them
-// scale very small or large operands and patch up 0, Inf and NaN.  With the operand known to lie in [2^-200, 2^200]
-// (the box QP's pivots: tested once per pivot, on the scalar unit) what is left is the same arithmetic, i.e. the same
-// bits.  The quotient by a divisor whose correctly rounded reciprocal rd is at hand: q = v rd, q' = q + (v - d q) rd
-// (two fused operations; Markstein's theorem: q' is the correctly rounded v / d provided nothing underflows —
-// |v| >= 2^-970 or v == 0 with d in the range above; checked against v / d on 3e8 random pairs, oracle/README).
-// The box QP factorises once or twice per backward step with 8 square roots and 24 divisions each time (cholesky.c:6-74).
-// ---------------------------------------------------------------------------
-ILQG_DEV double sqrt_plain(const double x) {
-    const double y0 = __builtin_amdgcn_rsq(x);
-    const double g0 = x * y0, h0 = y0 * 0.5;
-    const double r0 = __builtin_fma(-h0, g0, 0.5);
-    const double g1 = __builtin_fma(g0, r0, g0);
-    const double d0 = __builtin_fma(-g1, g1, x);
-    const double h1 = __builtin_fma(h0, r0, h0);
-    const double g2 = __builtin_fma(d0, h1, g1);
-    const double d1 = __builtin_fma(-g2, g2, x);
-    return __builtin_fma(d1, h1, g2);
-}
-ILQG_DEV double rcp_plain(const double d) {
-    const double y0 = __builtin_amdgcn_rcp(d);
-    const double y1 = __builtin_fma(y0, __builtin_fma(-d, y0, 1.0), y0);
-    const double y2 = __builtin_fma(y1, __builtin_fma(-d, y1, 1.0), y1);
-    return __builtin_fma(__builtin_fma(-d, y2, 1.0), y2, y2);
-}
-ILQG_DEV double div_plain(const double v, const double d, const double rd) {
-    const double q = v * rd;
-    return __builtin_fma(__builtin_fma(-d, q, v), rd, q);
-}
+// (sqrt_plain / rcp_plain / div_plain: ilqg_device.hpp)
 // x in [2^-200, 2^200]?  x wave-uniform (the same in every lane); evaluated on the scalar unit
 ILQG_DEV bool plain_range(const double x) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(x));
