@@ -116,7 +116,7 @@ ILQG_DEV void add_mul2_tri(double *base, const double *B, const double *A, const
 // (the box QP's pivots, tested as they come) what is left is the same arithmetic, i.e. the same
 // bits.  The quotient by a divisor whose correctly rounded reciprocal rd is at hand: q = v rd, q' = q + (v - d q) rd
 // (two fused operations; Markstein's theorem: q' is the correctly rounded v / d provided nothing underflows —
-// |v| >= 2^-970 or v == 0 with d in the range above; checked against v / d on 3e8 random pairs, oracle/README).
+// |v| >= 2^-970 or v == 0 with d in the range above; checked against v / d on 2.7e8 random pairs, tools/ubench/quotient_check.c).
 // The box QP factorises once or twice per backward step with 8 square roots and 24 divisions each time (cholesky.c:6-74).
 // ---------------------------------------------------------------------------
 ILQG_DEV double sqrt_plain(const double x) {
