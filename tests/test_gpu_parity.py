@@ -675,6 +675,55 @@ def test_wave_mapping_synthetic_golden(ilqg, fd, variant):
     s.close()
 
 
+@pytest.mark.parametrize("log2_scale", [-240, -120, 0, 120, 240])
+def test_wave_mapping_step_with_scaled_costs(ilqg, oracle_built, log2_scale):
+    """The row-mapped backward step takes short forms of sqrt / reciprocal / quotient in its box QP while the pivots lie
+    in [2^-200, 2^200] and the compiler's general ones otherwise (ilqg_row.hpp).  With every cost weight scaled by
+    2^+-120 (and lambda with them) the short forms work on large and small numbers, with 2^+-240 the general ones run:
+    the FMA-free build must give the oracle's gains bit for bit either way (stored derivative records of the oracle, so
+    that nothing but the backward step is compared)."""
+    N, fd = 12, 1
+    sc = 2.0 ** log2_scale
+    params = dict(SYN_PARAMS_TIGHT)
+    for k in ("ru", "qx", "qf"):
+        params[k] = [v * sc for v in params[k]]
+    x0, u0 = syn_inputs(1, N, first=7)
+    d = Driver(lib_path("oracle", "synth16x8", fd), N, params, {})
+    assert d.init(x0[0], u0[0]) == 1
+    assert d.calc_derivs() == 1
+    lam = sc
+    d.set_lambda(lam)
+    rc = d.back_pass()
+    rec, fin = d.derivs()
+    l0, L0 = d.gains()
+    d.close()
+    # (with the large scales the reference's box QP gives up at the first step it meets — its absolute thresholds — and
+    # the sweep is abandoned: then the same has to happen here, and the gains of the steps behind it have to agree)
+    assert rc == (0 if log2_scale <= 0 else 1)
+    s = ilqg.BatchSolver("synth16x8", fd, batch=1, n_hor=N, params=params, strict=True, opts=dict(fuse_derivs=0))
+    s.init(x0, u0)
+    s.set_derivs(rec[None], fin[None])
+    s.set_scalar("lambda", lam)
+    s.back_pass(single_sweep=True)
+    assert s.ints("bp_rc")[0] == rc
+    l, L = s.gains()
+    done = slice(None) if rc == 0 else slice(N - 1, N)  # an abandoned sweep: the last step was the first to be met
+    if rc == 0 or np.any(l0[N - 1] != 0) or np.any(L0[N - 1] != 0):
+        assert np.array_equal(l[0][done], l0[done]) and np.array_equal(L[0][done], L0[done]), (worst(l[0], l0), worst(L[0], L0))
+    s.close()
+    if rc:
+        return
+    # and with the records of the device's own derivative kernel (factored tensors): gains within rounding of the oracle's
+    s = ilqg.BatchSolver("synth16x8", fd, batch=1, n_hor=N, params=params, strict=True)
+    s.init(x0, u0)
+    s.calc_derivs()
+    s.set_scalar("lambda", lam)
+    s.back_pass(single_sweep=True)
+    l, L = s.gains()
+    assert s.ints("bp_rc")[0] == 0 and close(l[0], l0, 1e-9) and close(L[0], L0, 1e-9)
+    s.close()
+
+
 def test_wave_mapping_element_step(ilqg):
     """The backward step of the wave mapping for problems whose rows do not fit a 16-lane DPP row (N_X > 16 or N_U > 16:
     one OUTPUT element per lane, both operands from LDS; ilqg_wave.hpp back_step_wave) — compiled for the n = 16 problem
