@@ -3029,6 +3029,7 @@ struct ilqg_dev {
     size_t cand1_bytes;   // size of P.cand1
     bool keep_first;      // the roll-out launch in progress keeps the first stage's roll-outs in P.cand1
     size_t xpl_bytes, upl_bytes;  // sizes of P.xpl / P.upl (ls_keep = 2)
+    size_t roll_lds;              // wave mapping: dynamic LDS asked for by the second-stage roll-outs (one workgroup per CU)
     int loc_set;          // the set of planes current trajectories may live in (-1: none, all in X / U)
     bool defer_commit, commit_pending, pending_zero;  // ls_keep = 2: k_update commits / clears the pending counter
     int commit_s1, commit_set;
@@ -3306,6 +3307,17 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
     d->P.Bp = d->Bp;
     d->P.N = d->N;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+#if ILQG_WAVE_MAP && defined(ILQG_ROLLOUT_PARTS)
+    {
+        // measured (config 5, ~300 busy workgroups in the second stage): 32.9 / 40.3 ms without, 33.0 / 28.5 ms with;
+        // with fewer than 256 busy workgroups every one of them gets a CU to itself (ILQG_ROLL_LDS_KB=0: off)
+        const char *e = getenv("ILQG_ROLL_LDS_KB");
+        d->roll_lds = (size_t)(e ? atoi(e) : 84) * 1024;
+        if(d->roll_lds)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_parts), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)d->roll_lds));
+    }
+#endif
 #if ILQG_WAVE_MAP
     if(FACTORED) {  // the workgroups that share the coefficient tables need more than the default 64 KB of LDS
         const int lds = (int)((TABLE_DOUBLES + ILQG_FACT_WAVES * WAVE_LDS_DOUBLES) * sizeof(double));
@@ -3811,7 +3823,11 @@ static void launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n
     else if(!HAS_MUL && !getenv("ILQG_NO_ROLLOUT_PARTS")) {  // the generated file offers the step in parts: several wavefronts per 64 trajectories
         DevPtrs Q = d->P;
         if(!d->keep_first) Q.cand1 = nullptr;
-        hipLaunchKernelGGL(k_rollout_parts, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE * RW), 0, stream, Q, d->O, d->pv, mode, a0);
+        // (second stage: a busy workgroup is a chain of N steps that keeps its CU's SIMDs issuing; two of them on one CU
+        // take twice as long, and the dispatcher puts two on one CU while others idle.  Asking for more than half of
+        // the CU's LDS leaves room for one.)
+        const size_t lds = (n_alpha > 1) ? d->roll_lds : 0;
+        hipLaunchKernelGGL(k_rollout_parts, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE * RW), lds, stream, Q, d->O, d->pv, mode, a0);
     }
 #endif
     else
