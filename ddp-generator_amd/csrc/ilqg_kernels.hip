@@ -183,11 +183,26 @@ __device__ __forceinline__ static ilqg_sc ilqg_sincos_hooked(double **p, double 
 __device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_call(double x) { return ilqg_sincos(x); }
 #define sin(x) (ilqg_sincos_call(x).s)
 #define cos(x) (ilqg_sincos_call(x).c)
+// ... except in the parts of a roll-out step (ilqg_step_part, a few dozen call sites): there they are inline, the
+// library behind a branch for what the straight-line path cannot reduce.  A call makes the caller wait for every memory
+// operation in flight — the operands of the NEXT step, requested a step ahead — once per step (ILQG_PART_INLINE_SINCOS=0:
+// calls there too).
+#ifndef ILQG_PART_INLINE_SINCOS
+#define ILQG_PART_INLINE_SINCOS 1
+#endif
+#if ILQG_PART_INLINE_SINCOS
+#define ILQG_PART_SIN(v) (ilqg_sincos(v).s)
+#define ILQG_PART_COS(v) (ilqg_sincos(v).c)
+#endif
 #else
 #define sin(x) (ilqg_sincos_hooked(p, (x)).s)
 #define cos(x) (ilqg_sincos_hooked(p, (x)).c)
 #endif
 #endif
+
+// The parts of a roll-out step belong INTO the kernel: as a called function they get x and u through scratch memory.
+// (The kernel has two instantiations; with two callers the inliner leaves a function of this size alone.)
+#define ILQG_PART_FN static __attribute__((always_inline))
 
 extern "C" {
 #pragma clang attribute push(__attribute__((device)), apply_to = function)
@@ -2383,7 +2398,22 @@ constexpr int JPW = (NU + RW - 1) / RW;  // inputs per wavefront in phase 1
 // flight (vmcnt(0)), i.e. for the operands prefetched for the next step and for the roll-out's stores — twice per step
 // (measured: 14 us per step with it).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... and the same behind the step's records on their way into LDS (DMA below)
+__device__ __forceinline__ void lds_barrier_after_loads() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// DMA: the nominal records of the workgroup's 64 trajectories reach the wavefronts through LDS.  With per-lane loads every
+// wavefront pulled its operands of phase 1 (x_nom, one row of L, u_nom, l: 34 loads of 8 bytes, lane = trajectory, i.e.
+// 64 different cache lines per load instruction) through the CU's vector-memory path: 17 000 line requests per step
+// and workgroup for 1 280 distinct lines — that path, not the arithmetic, set the 10 us a step took.  Now a record
+// (RN doubles, contiguous) is fetched ONCE per step by global_load_lds_dwordx4, 64 consecutive 16-byte pieces per
+// instruction (lanes on consecutive addresses), into s_nom[trajectory][RN + 2] (the two doubles of padding keep a
+// record 16-byte aligned and put the lanes' reads of one entry on different banks); wavefront w fetches the records of
+// trajectories w, w + RW, ...  ONE buffer: a step's record is consumed in phase 1, so the next step's is requested
+// behind the first barrier and has landed at the second (which waits for it).
+constexpr int RNP = RN + 2;
+constexpr int DMA_PIECES = RN / 2, DMA_PER_REC = (DMA_PIECES + WAVE - 1) / WAVE;
+template <bool DMA>
 __global__ __launch_bounds__(WAVE *RW) void k_rollout_parts(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int mode, int a0) {
+    extern __shared__ __attribute__((aligned(16))) double s_nom[];  // DMA: [WAVE][RNP]
     __shared__ __attribute__((aligned(16))) double s_x[WAVE][RPX];
     __shared__ __attribute__((aligned(16))) double s_u[WAVE][RPU];
     __shared__ __attribute__((aligned(16))) double s_t[WAVE][RPT];
@@ -2443,7 +2473,34 @@ __global__ __launch_bounds__(WAVE *RW) void k_rollout_parts(DevPtrs P, ilqg_dev_
     double x[NX];
 #pragma unroll
     for(int i = 0; i < NX; i++) x[i] = rec[NOM_X + i];
-    // phase 1 operands of this wavefront's input(s) part, part + RW, ..., one step ahead
+    // DMA: the records of this wavefront's trajectories (held as uniform addresses; they move on one step per request)
+    constexpr int TPW = (WAVE + RW - 1) / RW;  // trajectories per wavefront
+    const char *drec[DMA ? TPW : 1];
+    if(DMA) {
+#pragma unroll
+        for(int q = 0; q < TPW; q++) {
+            const int t = part + q * RW;  // (the same lane -> trajectory map in every wavefront)
+            const unsigned long long a = (unsigned long long)rec;
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)a, t < WAVE ? t : 0), hi = __builtin_amdgcn_readlane((unsigned)(a >> 32), t < WAVE ? t : 0);
+            drec[q] = (const char *)(((unsigned long long)hi << 32) | lo);
+        }
+    }
+    auto dma_issue = [&]() {
+#pragma unroll
+        for(int q = 0; q < TPW; q++) {
+            if(part + q * RW < WAVE) {
+#pragma unroll
+                for(int m = 0; m < DMA_PER_REC; m++) {
+                    if(m * WAVE + lane < DMA_PIECES)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(drec[q] + (size_t)(m * WAVE + lane) * 16),
+                                                         (__attribute__((address_space(3))) void *)(s_nom + (size_t)(part + q * RW) * RNP + m * WAVE * 2),
+                                                         16, 0, 0);
+                }
+            }
+            drec[q] += (size_t)RN * sizeof(double);
+        }
+    };
+    // phase 1 operands of this wavefront's input(s) part, part + RW, ...: one step ahead in registers, or out of LDS
     double nx[NX], nk[JPW][NX], nu_nom[JPW], nl[JPW];
     auto fetch = [&](const double *r) {
         if(part < NU) {
@@ -2459,13 +2516,19 @@ __global__ __launch_bounds__(WAVE *RW) void k_rollout_parts(DevPtrs P, ilqg_dev_
             }
         }
     };
-    fetch(rec);
+    if(DMA) {
+        dma_issue();
+        lds_barrier_after_loads();
+    } else {
+        fetch(rec);
+    }
     double csum = 0.0;
     int bad = 0;
     double *xo = cur_x(P, 0, b), *uo = cur_u(P, 0, b);
     drain_memory_ops();
     for(int k = 0; k < N; k++) {
         // ---- phase 1: this wavefront's input
+        if(DMA) fetch(s_nom + (size_t)lane * RNP);  // this step's record, out of LDS
         if(part < NU) {
 #pragma unroll
             for(int q = 0; q < JPW; q++) {
@@ -2478,8 +2541,9 @@ __global__ __launch_bounds__(WAVE *RW) void k_rollout_parts(DevPtrs P, ilqg_dev_
             }
         }
         rec += RN;
-        fetch(rec);  // step k+1 (the records have a step N: its gains are not used)
+        if(!DMA) fetch(rec);  // step k+1 (the records have a step N: its gains are not used)
         lds_barrier();
+        if(DMA) dma_issue();  // step k+1 into the buffer every wavefront has just finished reading
         // ---- phase 2: all inputs, the box, this wavefront's part of the step
         double u[NU];
 #pragma unroll
@@ -2494,7 +2558,7 @@ __global__ __launch_bounds__(WAVE *RW) void k_rollout_parts(DevPtrs P, ilqg_dev_
         // this wavefront's part(s) of the step.  (sin / cos stay calls in the large generated files, which handle their
         // huge arguments themselves; small files go through the hooks as everywhere else)
         auto parts = [&]() {
-#pragma unroll
+#pragma unroll  // (the wavefront's number is known to be below RW: every call site keeps the cases it can reach)
             for(int q = 0; q < PPW; q++)
                 if(part + q * RW < RP) ilqg_step_part(part + q * RW, &s_x[lane][0], &s_t[lane][0], &bad_step, x, u, k, C.o.p, N);
         };
@@ -2528,7 +2592,10 @@ __global__ __launch_bounds__(WAVE *RW) void k_rollout_parts(DevPtrs P, ilqg_dev_
         xo += RN;
         uo += RN;
         if(keep) keep += (size_t)CAND_W * P.Bp;
-        lds_barrier();
+        if(DMA)
+            lds_barrier_after_loads();
+        else
+            lds_barrier();
         // ---- the new state; the cost of the step in the order of ddpL's sum
 #pragma unroll
         for(int i = 0; i < NX; i++) x[i] = s_x[lane][i];
@@ -3030,6 +3097,8 @@ struct ilqg_dev {
     bool keep_first;      // the roll-out launch in progress keeps the first stage's roll-outs in P.cand1
     size_t xpl_bytes, upl_bytes;  // sizes of P.xpl / P.upl (ls_keep = 2)
     size_t roll_lds;              // wave mapping: dynamic LDS asked for by the second-stage roll-outs (one workgroup per CU)
+    size_t roll_pad;              //   ... on top of the records' buffer when the records go through LDS
+    bool roll_dma;                // wave mapping: k_rollout_parts fetches the nominal records through LDS
     int loc_set;          // the set of planes current trajectories may live in (-1: none, all in X / U)
     bool defer_commit, commit_pending, pending_zero;  // ls_keep = 2: k_update commits / clears the pending counter
     int commit_s1, commit_set;
@@ -3314,8 +3383,15 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
         const char *e = getenv("ILQG_ROLL_LDS_KB");
         d->roll_lds = (size_t)(e ? atoi(e) : 84) * 1024;
         if(d->roll_lds)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_parts), hipFuncAttributeMaxDynamicSharedMemorySize,
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_parts<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)d->roll_lds));
+        // records through LDS (see k_rollout_parts; ILQG_NO_DMA=1: per-lane loads).  With them a workgroup takes more than
+        // half of a CU's LDS whenever a record is 640 bytes or more; below that the same is asked for explicitly
+        d->roll_dma = !getenv("ILQG_NO_DMA");
+        const size_t need = (size_t)WAVE * RNP * sizeof(double);
+        d->roll_pad = (d->roll_lds > need + 40 * 1024) ? d->roll_lds - need - 40 * 1024 : 0;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_parts<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(need + d->roll_pad)));
     }
 #endif
 #if ILQG_WAVE_MAP
@@ -3826,8 +3902,13 @@ static void launch_rollout(ilqg_dev_t *d, int mode, int kernel_id, int a0, int n
         // (second stage: a busy workgroup is a chain of N steps that keeps its CU's SIMDs issuing; two of them on one CU
         // take twice as long, and the dispatcher puts two on one CU while others idle.  Asking for more than half of
         // the CU's LDS leaves room for one.)
-        const size_t lds = (n_alpha > 1) ? d->roll_lds : 0;
-        hipLaunchKernelGGL(k_rollout_parts, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE * RW), lds, stream, Q, d->O, d->pv, mode, a0);
+        if(d->roll_dma) {
+            hipLaunchKernelGGL(k_rollout_parts<true>, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE * RW), (size_t)WAVE * RNP * sizeof(double) + d->roll_pad,
+                               stream, Q, d->O, d->pv, mode, a0);
+        } else {
+            const size_t lds = (n_alpha > 1) ? d->roll_lds : 0;
+            hipLaunchKernelGGL(k_rollout_parts<false>, dim3(d->Bp / WAVE, n_alpha), dim3(WAVE * RW), lds, stream, Q, d->O, d->pv, mode, a0);
+        }
     }
 #endif
     else
