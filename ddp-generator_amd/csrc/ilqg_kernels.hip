@@ -2731,25 +2731,41 @@ __global__ void k_adopt(DevPtrs P, int a0, int n2) {
 }
 
 // Wave mapping, ls_keep = 2: the roll-outs the first stage accepted, kept by trajectory in P.cand1, become the current
-// trajectory (the records' x and u): one thread per (step, trajectory), consecutive threads = consecutive trajectories
-// on the reading side, 192 contiguous bytes per thread on the writing side.  Replaces the winner pass: a copy at the
-// speed of the memory system instead of 16 384 chains of N steps beside the second stage's.
-__global__ void k_adopt_first(DevPtrs P, int s1) {
-    const size_t total = (size_t)(P.N + 1) * P.Bp, stride = (size_t)gridDim.x * blockDim.x;
-    for(size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
-        const int b = (int)(w % P.Bp), k = (int)(w / P.Bp);
-        if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE || !P.i[ILQG_I_ACCEPTED][b]) continue;
-        const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1;
-        if(a >= s1) continue;
-        const double *src = P.cand1 + ((size_t)a * (P.N + 1) + k) * CAND_W * P.Bp + b;
-        double *xo = cur_x(P, k, b);
+// trajectory (the records' x and u).  Replaces the winner pass: a copy at the speed of the memory system instead of
+// 16 384 chains of N steps beside the second stage's.  One wavefront per (step, tile of 64 trajectories): it reads the
+// step's NX + NU components lane = trajectory (512 contiguous bytes per load), turns the tile round in LDS and writes
+// lane = (trajectory, component): each trajectory's x | u of the step is one run of 192 contiguous bytes in its record
+// (with one thread per (step, trajectory) writing its own run: 64 cache lines per store instruction, 5.1 ms for config 5).
+__global__ __launch_bounds__(256) void k_adopt_first(DevPtrs P, int s1) {
+    constexpr int TW = CAND_W + 1;  // (padded rows: the lanes' stores fall on different banks)
+    __shared__ double tile[4][WAVE][TW];
+    __shared__ int take[4][WAVE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tiles = P.Bp / WAVE;
+    const size_t total = (size_t)(P.N + 1) * tiles, stride = (size_t)gridDim.x * 4;
+    for(size_t w = (size_t)blockIdx.x * 4 + wave; w < total; w += stride) {
+        const int k = (int)(w / tiles), b0 = (int)(w % tiles) * WAVE, b = b0 + lane;
+        int a = -1;
+        if(b < P.B && P.i[ILQG_I_STATUS][b] == ILQG_ST_ACTIVE && P.i[ILQG_I_ACCEPTED][b]) a = P.i[ILQG_I_ALPHA_IDX][b] - 1;
+        if(a >= s1) a = -1;
+        if(__builtin_amdgcn_ballot_w64(a >= 0) == 0ull) continue;
+        take[wave][lane] = a >= 0;
+        if(a >= 0) {
+            const double *src = P.cand1 + ((size_t)a * (P.N + 1) + k) * CAND_W * P.Bp + b;
 #pragma unroll
-        for(int i = 0; i < NX; i++) xo[i * XSI] = src[(size_t)i * P.Bp];
-        if(k < P.N) {
-            double *uo = cur_u(P, k, b);
-#pragma unroll
-            for(int i = 0; i < NU; i++) uo[i * XSI] = src[(size_t)(NX + i) * P.Bp];
+            for(int i = 0; i < CAND_W; i++) tile[wave][lane][i] = src[(size_t)i * P.Bp];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int W = (k < P.N) ? CAND_W : NX;  // (the last step has a state only)
+        for(int e = lane; e < WAVE * CAND_W; e += WAVE) {
+            const int t = e / CAND_W, c = e - t * CAND_W;
+            if(c < W && take[wave][t]) (c < NX ? cur_x(P, k, b0 + t) + c * XSI : cur_u(P, k, b0 + t) + (c - NX) * XSI)[0] = tile[wave][t][c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
