@@ -1294,7 +1294,11 @@ __device__ __forceinline__ trajEl_t *work_rec(const DevPtrs &P, int bw, int k) {
 
 // factored: the first-order part of the record and, in place of the tensors, the products they are multiples of
 // (NBASIS doubles at the start of the record's fxx member)
-__global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first,
+// (workgroups of four wavefronts: 105 against 112 ms per iteration of config 5 with one; 16: 128 registers, 165 ms)
+#ifndef ILQG_DERIVS_BLOCK
+#define ILQG_DERIVS_BLOCK 256
+#endif
+__global__ __launch_bounds__(ILQG_DERIVS_BLOCK) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first,
                                                     int chunk_count, int init_consts, int factored) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int bw = (int)(tid / (P.N + 1));
@@ -1317,17 +1321,23 @@ __global__ __launch_bounds__(64) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O
         auto body = [&]() {
             for(int i = 0; i < NX; i++) t->x[i] = nomp(P, k, b)[NOM_X + i];
             for(int i = 0; i < NU; i++) t->u[i] = nomp(P, k, b)[NOM_U + i];
-            ok = calcXVariableAux(t, mp, k, &o);
-            ok &= calcXUVariableAux(t, mp, k, &o);
-            ok &= calcLAuxDeriv(t, mp, k, &o);
+#ifndef ILQG_ABLATE  // timing experiments: leave parts of the evaluation out (profiles/README.md)
+#define ILQG_ABLATE 0
+#endif
+            ok = 1;
+            if(!(ILQG_ABLATE & 1)) ok = calcXVariableAux(t, mp, k, &o);
+            if(!(ILQG_ABLATE & 1)) ok &= calcXUVariableAux(t, mp, k, &o);
+            if(!(ILQG_ABLATE & 2)) ok &= calcLAuxDeriv(t, mp, k, &o);
 #if ILQG_FACTORED
             if(factored) {
-                ok &= bp_derivsL_first(t, k, o.p);
-                ok &= bp_tensor_basis(t->fxx, t, k, o.p);
+                // (the two as ONE generated function, so that the products share the first derivatives' 32 sin / cos
+                // evaluations, was measured: 64 shared products alive at once, k_derivs_wave 105 -> 169 ms)
+                if(!(ILQG_ABLATE & 4)) ok &= bp_derivsL_first(t, k, o.p);
+                if(!(ILQG_ABLATE & 8)) ok &= bp_tensor_basis(t->fxx, t, k, o.p);
             } else
 #endif
                 ok &= bp_derivsL(t, k, o.p);
-            limitsU(t, k, o.p, P.N);
+            if(!(ILQG_ABLATE & 16)) limitsU(t, k, o.p, P.N);
         };
 #if ILQG_UNIFORM_GUARDS
         ok = run_guarded([&]() { body(); return ok; });
@@ -4018,7 +4028,7 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
             Timed t(d, ILQG_K_DERIVS, st);
             const size_t total = (size_t)cnt * (d->N + 1);
             const bool have_consts = *whole || (split && half[h]);
-            hipLaunchKernelGGL(k_derivs_wave, grid1(total, 64), dim3(64), 0, st, P, d->O, d->pv, c0, cnt, have_consts ? 0 : 1,
+            hipLaunchKernelGGL(k_derivs_wave, grid1(total, ILQG_DERIVS_BLOCK), dim3(ILQG_DERIVS_BLOCK), 0, st, P, d->O, d->pv, c0, cnt, have_consts ? 0 : 1,
                                fact ? 1 : 0);
             if(cnt == part) {  // every element of this (half of the) buffer that is ever used has its constants now
                 if(split) half[h] = true;
