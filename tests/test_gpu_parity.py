@@ -1109,6 +1109,40 @@ def test_line_search_staging_in_the_wave_mapping(ilqg):
         assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2]), opts
 
 
+@pytest.mark.parametrize("problem,n_hor", [("synth16x8", 40), ("carparking_wave", 60)])
+def test_wave_rollouts_through_lds_equal_per_lane_loads(ilqg, monkeypatch, problem, n_hor):
+    """wave mapping: the roll-outs that fetch the nominal records once per step and workgroup into LDS
+    (k_rollout_parts<true>, global_load_lds) against the same kernel with per-lane loads (ILQG_NO_DMA=1): the same bits,
+    with ragged batches (a partly filled last workgroup) and a second stage that walks the pending list"""
+    wave = problem.endswith("_wave")
+    name = problem[:-5] if wave else problem
+    fd = 0 if wave else 1
+    B, iters = (150, 4) if not wave else (200, 5)
+    if wave:
+        n_hor = 500  # (the generator of the CarParking batch makes whole horizons)
+        x0, u0 = load_package().synth.car_batch(B)
+        params = ilqg.CAR_PARAMS
+    else:
+        (x0, u0), params = syn_inputs(B, n_hor), SYN_PARAMS_TIGHT
+    res = []
+    for no_dma in ("", "1"):
+        if no_dma:
+            monkeypatch.setenv("ILQG_NO_DMA", no_dma)
+        else:
+            monkeypatch.delenv("ILQG_NO_DMA", raising=False)
+        s = ilqg.BatchSolver(name, fd, batch=B, n_hor=n_hor, params=params, opts=dict(max_iter=iters + 1, zMin=0.9),
+                             strict="wave" if wave else False)
+        assert s.problem.wave_mapping
+        s.init(x0, u0)
+        s.iterate(iters)
+        res.append((s.ints("alpha_idx").copy(), s.ints("accepted").copy(), s.scalar("cost").copy(), s.x(), s.u()))
+        s.close()
+    monkeypatch.delenv("ILQG_NO_DMA", raising=False)
+    assert res[0][0].max() >= 2  # (later step sizes are needed: the second stage ran)
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("fd", [0, 1])
 def test_backward_on_two_wavefronts_equals_one(ilqg, synth, fd):
     """option bw_split: the fused backward pass with the derivatives of step k-1 on a second wavefront (hand-over of the
