@@ -1298,7 +1298,12 @@ __device__ __forceinline__ trajEl_t *work_rec(const DevPtrs &P, int bw, int k) {
 #ifndef ILQG_DERIVS_BLOCK
 #define ILQG_DERIVS_BLOCK 256
 #endif
-__global__ __launch_bounds__(ILQG_DERIVS_BLOCK) void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first,
+#ifdef ILQG_DERIVS_WAVES  // experiments: that many wavefronts per SIMD (register cap)
+#define ILQG_DERIVS_ATTR __attribute__((amdgpu_waves_per_eu(ILQG_DERIVS_WAVES, ILQG_DERIVS_WAVES)))
+#else
+#define ILQG_DERIVS_ATTR
+#endif
+__global__ __launch_bounds__(ILQG_DERIVS_BLOCK) ILQG_DERIVS_ATTR void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first,
                                                     int chunk_count, int init_consts, int factored) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int bw = (int)(tid / (P.N + 1));
