@@ -61,12 +61,14 @@ struct ilqg_hooks {
     double nonfinite;  // p[-1]: 0.0, or NaN once a guarded value was NaN/Inf
     double huge;       // p[-2]: != 0 once sin/cos saw an argument the straight-line path cannot reduce
     double slow;       // p[-3]: != 0: sin/cos go to the device library (the rarely taken re-evaluation)
+    double limgrad;    // p[-4]: != 0 (the default): limitsU() also stores the limits' signs and gradients
 };
 #include "ilqg_param_layout.h"  // generated at build time from the problem's paramdesc[]: ILQG_NP, sizes, offsets
-#define ILQG_HOOK_SLOTS 3
+#define ILQG_HOOK_SLOTS 4
 #define ILQG_HOOK_NONFINITE (ILQG_NP)
 #define ILQG_HOOK_HUGE (ILQG_NP + 1)
 #define ILQG_HOOK_SLOW (ILQG_NP + 2)
+#define ILQG_HOOK_LIMGRAD (ILQG_NP + 3)
 
 __device__ __forceinline__ int ilqg_note_nonfinite(double **p, double v) {
     double *f = p[ILQG_HOOK_NONFINITE];
@@ -209,6 +211,14 @@ extern "C" {
 #pragma clang attribute push(__attribute__((internal_linkage)), apply_to = variable(is_global))
 #include "iLQG.h"
 #include "matMult.h"
+// Limits that do not depend on the state (the header's hint): their gradients are zeros and their signs constants that
+// nothing on the device reads (the backward steps' HX = false) — but limitsU() stores them into the element for every
+// step, 2 N_X N_U + 2 N_U doubles: half as many bytes again as the time-varying entries of the n = 16 problem's record
+// (measured: 26 of k_derivs_wave's 106 ms per iteration of config 5).  The generated file asks this condition; the hook
+// is on unless a kernel clears it for records nobody but the backward pass will read (k_derivs_wave, `transient`).
+#if defined(ILQG_STATE_DEPENDENT_LIMITS) && !ILQG_STATE_DEPENDENT_LIMITS
+#define ILQG_LIMIT_GRADIENTS_WANTED (*p[ILQG_HOOK_LIMGRAD] != 0.0)
+#endif
 #include "iLQG_func.c"
 #pragma clang attribute pop
 #pragma clang attribute pop
@@ -473,9 +483,11 @@ __device__ __forceinline__ void load_params(ParamValues &V, ParamTable &T, ilqg_
     H.nonfinite = 0.0;
     H.huge = 0.0;
     H.slow = 0.0;
+    H.limgrad = 1.0;
     T.ptr[ILQG_HOOK_NONFINITE] = &H.nonfinite;
     T.ptr[ILQG_HOOK_HUGE] = &H.huge;
     T.ptr[ILQG_HOOK_SLOW] = &H.slow;
+    T.ptr[ILQG_HOOK_LIMGRAD] = &H.limgrad;
 }
 
 // What a kernel needs to call the generated callbacks.  Four separate private objects, each pointing
@@ -1304,7 +1316,7 @@ __device__ __forceinline__ trajEl_t *work_rec(const DevPtrs &P, int bw, int k) {
 #define ILQG_DERIVS_ATTR
 #endif
 __global__ __launch_bounds__(ILQG_DERIVS_BLOCK) ILQG_DERIVS_ATTR void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first,
-                                                    int chunk_count, int init_consts, int factored) {
+                                                    int chunk_count, int init_consts, int factored, int limit_gradients) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int bw = (int)(tid / (P.N + 1));
     const int k = (int)(tid % (P.N + 1));
@@ -1312,6 +1324,7 @@ __global__ __launch_bounds__(ILQG_DERIVS_BLOCK) ILQG_DERIVS_ATTR void k_derivs_w
     if(bw >= chunk_count || b >= P.B) return;
     ILQG_CALLBACKS(C, H);
     load_penalty_weights_der(C, P, b);
+    if(!limit_gradients) H.limgrad = 0.0;  // (records only the backward pass reads: see ILQG_LIMIT_GRADIENTS_WANTED)
     tOptSet &o = C.o;
     // constant entries, once per buffer (init_opt, iLQG_func.tem:402-415) — of EVERY record of the chunk: the slot of a
     // trajectory that is finished serves another one in a later chunk
@@ -1347,6 +1360,12 @@ __global__ __launch_bounds__(ILQG_DERIVS_BLOCK) ILQG_DERIVS_ATTR void k_derivs_w
             // (the limits — which re-read u behind the 400 stores of the derivatives — moved in front of them, and the
             // products in front of the first derivatives: measured, no difference)
             if(!(ILQG_ABLATE & 16)) limitsU(t, k, o.p, P.N);
+            if(ILQG_ABLATE & 64) {  // (timing experiment: the limits' 16 stores without the function)
+                for(int i = 0; i < NU; i++) {
+                    t->lower[i] = -1.0 - t->u[i];
+                    t->upper[i] = 1.0 - t->u[i];
+                }
+            }
         };
 #if ILQG_UNIFORM_GUARDS
         ok = run_guarded([&]() { body(); return ok; });
@@ -4037,8 +4056,10 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
             Timed t(d, ILQG_K_DERIVS, st);
             const size_t total = (size_t)cnt * (d->N + 1);
             const bool have_consts = *whole || (split && half[h]);
+            // (transient records are read by the backward pass alone: the limits' signs and gradients, which it does not
+            // use unless the limits depend on the state, are left out of them)
             hipLaunchKernelGGL(k_derivs_wave, grid1(total, ILQG_DERIVS_BLOCK), dim3(ILQG_DERIVS_BLOCK), 0, st, P, d->O, d->pv, c0, cnt, have_consts ? 0 : 1,
-                               fact ? 1 : 0);
+                               fact ? 1 : 0, (transient && !HX) ? 0 : 1);
             if(cnt == part) {  // every element of this (half of the) buffer that is ever used has its constants now
                 if(split) half[h] = true;
                 else *whole = half[0] = half[1] = true;

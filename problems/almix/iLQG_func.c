@@ -132,6 +132,12 @@ static void limitsU(trajEl_t *t, int k, double **p, int N) {
         t->upper[iu]-= t->u[iu];
     }
 
+    /* additive: a back-end that will not read *_sign / *_hx of this element (limits that do not depend on the
+     * state: constants) may say so through a condition of its own */
+#ifndef ILQG_LIMIT_GRADIENTS_WANTED
+#define ILQG_LIMIT_GRADIENTS_WANTED 1
+#endif
+    if(ILQG_LIMIT_GRADIENTS_WANTED)
     for(side= 0; side<2; side++) {
         double *const sign= side? t->upper_sign: t->lower_sign;
         double *const grad= side? t->upper_hx: t->lower_hx;

@@ -726,6 +726,11 @@ typedef struct {{
             out += "    if(t->%s[%d]%sbound) { t->%s[%d]= bound; active[%d][%d]= %d; }\n" % (arr, j, cmp_, arr, j, side, j, c["index"])
         out += ("\n    /* the solver works with the change of u */\n"
                 "    for(iu= 0; iu<N_U; iu++) {\n        t->lower[iu]-= t->u[iu];\n        t->upper[iu]-= t->u[iu];\n    }\n\n"
+                + ("" if self.plain else
+                   "    /* additive: a back-end that will not read *_sign / *_hx of this element (limits that do not depend on the\n"
+                   "     * state: constants) may say so through a condition of its own */\n"
+                   "#ifndef ILQG_LIMIT_GRADIENTS_WANTED\n#define ILQG_LIMIT_GRADIENTS_WANTED 1\n#endif\n"
+                   "    if(ILQG_LIMIT_GRADIENTS_WANTED)\n") +
                 "    for(side= 0; side<2; side++) {\n"
                 "        double *const sign= side? t->upper_sign: t->lower_sign;\n"
                 "        double *const grad= side? t->upper_hx: t->lower_hx;\n"
