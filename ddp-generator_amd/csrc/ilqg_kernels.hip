@@ -1351,7 +1351,8 @@ __global__ __launch_bounds__(ILQG_DERIVS_BLOCK) ILQG_DERIVS_ATTR void k_derivs_w
 #if ILQG_FACTORED
             if(factored) {
                 // (the two as ONE generated function, so that the products share the first derivatives' 32 sin / cos
-                // evaluations, was measured: 64 shared products alive at once, k_derivs_wave 105 -> 169 ms)
+                // evaluations, was measured twice: all shared products first, 105 -> 169 ms; statements grouped by the
+                // sin / cos they use, 83 -> 141 ms)
                 if(!(ILQG_ABLATE & 4)) ok &= bp_derivsL_first(t, k, o.p);
                 if(!(ILQG_ABLATE & 8)) ok &= bp_tensor_basis(t->fxx, t, k, o.p);
             } else
