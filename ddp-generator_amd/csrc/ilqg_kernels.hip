@@ -225,6 +225,11 @@ extern "C" {
 }
 #undef sin
 #undef cos
+// The function file's own macros end here: the reference's template leaves `mcond`, `sec`, `csc` and one `aux_<name>` /
+// `daux_<name>` / `mu_<kind>_<i>` per auxiliary and multiplier defined to the end of the translation unit
+// (iLQG_func.tem:5-30), which on the host is the end of the file and here would be the kernels.  The list is made from
+// the file at build time (csrc/Makefile); ILQG_* names, the additive surface the kernels ask for, stay.
+#include "ilqg_problem_undefs.h"
 
 // Mapping: lane mapping (one lane per trajectory, everything in registers) for small problems,
 // wave mapping (one wavefront per trajectory, matrices in LDS) when a lane's registers cannot

@@ -131,10 +131,10 @@ ILQG_DEV unsigned lds_addr(const void *p) {  // p: a generic pointer INTO LDS
 }
 struct LdsBase {
     unsigned a;
-    ILQG_DEV lds_double &operator[](int i) const { return ((lds_double *)a)[i]; }
+    ILQG_DEV lds_double &operator[](int i) const { return ((lds_double *)(uintptr_t)a)[i]; }
     // a read the optimiser neither merges with a neighbour (a merged pair takes small offsets only and gets a new
     // base register computed for it) nor moves: offset i (doubles) is the instruction's immediate
-    ILQG_DEV double fetch(int i) const { return ((volatile lds_double *)a)[i]; }
+    ILQG_DEV double fetch(int i) const { return ((volatile lds_double *)(uintptr_t)a)[i]; }
 };
 ILQG_DEV LdsBase lds_base(unsigned a) {
     asm("" : "+v"(a));

@@ -35,12 +35,27 @@ class IlqgError(RuntimeError):
     pass
 
 
+_extra_libdirs = []
+
+
+def add_library_dir(path):
+    """another directory problem libraries are looked up in (a `make ... LIBDIR=<dir>` of the caller: a problem built
+    from its own <problem>_gen_files/)"""
+    path = os.path.abspath(path)
+    if path not in _extra_libdirs:
+        _extra_libdirs.append(path)
+
+
 def library_path(problem="carparking", full_ddp=0, strict=False):
     """strict=True: the -ffp-contract=off build (bit-for-bit CPU parity of the backward pass; tests only);
     strict="wave": the build of a small problem forced into the one-wavefront-per-trajectory mapping;
     strict="elem": the n = 16 problem built with the one-output-element-per-lane backward step (FMA-free)"""
     suffix = "_wave" if strict == "wave" else ("_elem" if strict == "elem" else ("_strict" if strict else ""))
-    return os.path.join(LIBDIR, "libilqg_%s_fd%d_hip%s.so" % (problem, int(full_ddp), suffix))
+    name = "libilqg_%s_fd%d_hip%s.so" % (problem, int(full_ddp), suffix)
+    for d in [LIBDIR] + _extra_libdirs:
+        if os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return os.path.join(LIBDIR, name)
 
 
 _libs = {}

@@ -116,10 +116,14 @@ def test_batch_of_different_starts_against_the_oracle(ilqg, oracle_built):
 def test_all_constraint_kinds_bit_exact_without_fma(ilqg, fd):
     """hle, hli, hfe, hfi at once, arrays of multipliers, a clamped input, a rejected first iteration (weights raised
     by w_pen_fact2 and cost re-swept, iLQG.c:345-349): iteration by iteration against the reference's fixture"""
+    check_almix_strict(ilqg, "almix", fd)
+
+
+def check_almix_strict(ilqg, problem, fd):
     g = golden("almix.npz")
     tag = "fd%d_" % fd
     params, opts, x0, u0 = almix_case()
-    s = ilqg.BatchSolver("almix", fd, batch=1, n_hor=len(u0), params=params, opts=opts, strict=True)
+    s = ilqg.BatchSolver(problem, fd, batch=1, n_hor=len(u0), params=params, opts=opts, strict=True)
     assert s.multiplier_dims() == (g[tag + "mul"].shape[1], g[tag + "mul_fin"].shape[0]) == (6, 6)
     s.init(x0[None], u0[None])
     assert s.scalar("cost")[0] == g[tag + "init_cost"]

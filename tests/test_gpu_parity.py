@@ -233,9 +233,14 @@ def test_boxqp_random_vs_oracle(ilqg, oracle_built):
 @pytest.mark.parametrize("variant", ["", "_plain"])
 @pytest.mark.parametrize("fd", [0, 1])
 def test_single_pass_golden(ilqg, fd, variant):
+    check_single_pass(ilqg, "carparking" + variant, fd)
+
+
+def check_single_pass(ilqg, problem, fd):
+    """(also run on CarParking libraries built from other directories: tests/test_out_of_tree.py, test_template_literal.py)"""
     g = golden("car_single_fd%d.npz" % fd)
     # ls_split=0: every step size is rolled out, so all eight per-alpha costs can be compared
-    s = ilqg.BatchSolver("carparking" + variant, fd, batch=1, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(ls_split=0))
+    s = ilqg.BatchSolver(problem, fd, batch=1, n_hor=500, params=ilqg.CAR_PARAMS, opts=dict(ls_split=0))
     s.init(g["x0"][None], g["u0"][None])
     assert close(s.scalar("cost")[0], g["init_cost"])
     assert close(s.x()[0], g["x_nom"]) and close(s.u()[0], g["u_nom"])
@@ -573,8 +578,12 @@ def test_mex_entry_without_mex(ilqg, oracle_built):
 def test_state_dependent_limits_golden(ilqg, fd):
     """problems/hxtest: limits that depend on the state put the constraint gradients into the
     feedback gains (back_pass.c:186-199); device record carries *_sign and *_hx here"""
+    check_hxtest_golden(ilqg, "hxtest", fd)
+
+
+def check_hxtest_golden(ilqg, problem, fd):
     g = golden("hxtest_fd%d.npz" % fd)
-    s = ilqg.BatchSolver("hxtest", fd, batch=1, n_hor=HX_N, params=HX_PARAMS, opts=dict(ls_split=0))
+    s = ilqg.BatchSolver(problem, fd, batch=1, n_hor=HX_N, params=HX_PARAMS, opts=dict(ls_split=0))
     assert s.problem.state_dep_limits == 1 and s.problem.rec_dev == s.problem.rec_host
     s.init(g["x0"][:1], g["u0"][:1])
     for tag in ("", "it3_"):
@@ -602,7 +611,7 @@ def test_state_dependent_limits_golden(ilqg, fd):
         assert close(s.x()[0], g[tag + "x_cand"], 1e-9) and close(s.u()[0], g[tag + "u_cand"], 1e-9)
     s.close()
     B = len(g["solve_rc"])
-    s = ilqg.BatchSolver("hxtest", fd, batch=B, n_hor=HX_N, params=HX_PARAMS, opts=dict(max_iter=100))
+    s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=HX_N, params=HX_PARAMS, opts=dict(max_iter=100))
     s.init(g["x0"], g["u0"])
     s.solve()
     assert np.array_equal(s.success(), g["solve_rc"]) and np.array_equal(s.ints("iterations"), g["solve_iterations"])

@@ -61,8 +61,13 @@ def test_matmult_helpers(K, tag, n, m):
 
 @pytest.mark.parametrize("fd", [0, 1])
 def test_single_backward_pass_and_line_search(oracle_built, fd):
+    check_car_single(lib_path("oracle", full_ddp=fd), fd)
+
+
+def check_car_single(path, fd):
+    """(also run on builds from other problem files of the same problem: tests/test_template_literal.py)"""
     g = golden("car_single_fd%d.npz" % fd)
-    d = Driver(lib_path("oracle", full_ddp=fd), 500, CAR_PARAMS)
+    d = Driver(path, 500, CAR_PARAMS)
     assert d.init(g["x0"], g["u0"]) == 1
     assert d.scalars()["cost"] == float(g["init_cost"])
     x, u = d.traj(0)
@@ -113,9 +118,13 @@ def test_full_solves(oracle_built, fd):
 @pytest.mark.parametrize("fd", [0, 1])
 def test_state_dependent_limits_problem(oracle_built, fd):
     """problems/hxtest: the constraint-gradient terms of the gains (back_pass.c:186-199)"""
+    check_hxtest(lib_path("oracle", "hxtest", fd), fd)
+
+
+def check_hxtest(path, fd):
     g = golden("hxtest_fd%d.npz" % fd)
     for tag, pre in (("", 0), ("it3_", 3)):
-        d = Driver(lib_path("oracle", "hxtest", fd), HX_N, HX_PARAMS, dict(max_iter=max(pre, 1)))
+        d = Driver(path, HX_N, HX_PARAMS, dict(max_iter=max(pre, 1)))
         assert d.init(g["x0"][0], g["u0"][0]) == 1
         if pre:
             d.solve()
@@ -131,7 +140,7 @@ def test_state_dependent_limits_problem(oracle_built, fd):
         assert np.array_equal(xc, g[tag + "x_cand"]) and np.array_equal(uc, g[tag + "u_cand"])
         d.close()
     for b in range(len(g["solve_rc"])):
-        d = Driver(lib_path("oracle", "hxtest", fd), HX_N, HX_PARAMS, dict(max_iter=100))
+        d = Driver(path, HX_N, HX_PARAMS, dict(max_iter=100))
         assert d.init(g["x0"][b], g["u0"][b]) == 1
         assert d.solve() == g["solve_rc"][b]
         assert d.scalars()["cost"] == g["solve_cost"][b] and np.array_equal(d.traj(0)[0], g["solve_x"][b])
@@ -203,10 +212,14 @@ def test_multiplier_problems(oracle_built, tag, problem, case):
 @pytest.mark.parametrize("fd", [0, 1])
 def test_all_constraint_kinds(oracle_built, fd):
     """hle, hli, hfe, hfi together with a clamped input and a rejected first iteration (problems/defs/almix.py)"""
+    check_almix(lib_path("oracle", "almix", fd), fd)
+
+
+def check_almix(path, fd):
     g = golden("almix.npz")
     tag = "fd%d_" % fd
     params, opts, x0, u0 = almix_case()
-    d = Driver(lib_path("oracle", "almix", fd), len(u0), params, opts)
+    d = Driver(path, len(u0), params, opts)
     assert d.init(x0, u0) == 1
     assert d.scalars()["cost"] == g[tag + "init_cost"]
     assert d.solve() == int(g[tag + "rc"])
