@@ -247,6 +247,111 @@ ILQG_DEV bool chol_factor_inverse(const double *A, double *inv) {
 }
 
 // ---------------------------------------------------------------------------
+// Factor and inverse of the free block for EVERY pattern of clamped variables at once (M <= 3: 2^M - 1 patterns with
+// at least one free variable).  What boxQP.c:129-146 computes when the free set changes is a pure function of H and
+// the pattern — the reference compacts the free rows / columns and runs cholesky_tri / cholesky_tri_inv on the small
+// matrix — so it is evaluated here ONCE per call for each pattern, on the compacted block with the reference's
+// operations for that size (the same bits), and an outer iteration of the box QP SELECTS by its pattern.  In the lane
+// mapping a factorisation under `if(free set changed)` runs whenever ANY of the 64 lanes needs it, i.e. in nearly
+// every outer iteration of the slowest lane (measured: 1 234 -> 1 672 cycles per step between iteration 1 and 20 of
+// the benchmark); the patterns of one call are independent instruction streams that overlap instead.
+// Pattern p = bit mask of the CLAMPED variables, p in [0, 2^M - 2].  inv[p]: the inverse in full index form (free
+// block at the original indices, identity on the clamped ones — what the embedded factorisation of box_qp gives),
+// pd[p]: every pivot > 0.  Short forms of sqrt / reciprocal / quotient while every pivot of every pattern and lane is in
+// their range, else everything once more in the general form (a pattern the iteration never visits may have any
+// pivots: nothing of it is used).
+// ---------------------------------------------------------------------------
+template <int M, unsigned P, bool PLAIN>
+ILQG_DEV void chol_pattern(const double *H, double *inv, bool &pd, bool &plain) {
+    constexpr int NF = M - __builtin_popcount(P);
+    int idx[NF > 0 ? NF : 1];  // the free variables, ascending (compile-time after unrolling)
+    {
+        int q = 0;
+#pragma unroll
+        for(int i = 0; i < M; i++)
+            if(!((P >> i) & 1u)) idx[q++] = i;
+    }
+    double A[tri(NF)], U[tri(NF)], iv[tri(NF)], rd[NF];
+#pragma unroll
+    for(int c = 0; c < NF; c++)
+#pragma unroll
+        for(int r = 0; r <= c; r++) A[ut(r, c)] = H[ut(idx[r], idx[c])];
+    if constexpr(PLAIN) {
+        pd = true;  // (a pivot in the plain range is positive; out of range: the general form decides)
+#pragma unroll
+        for(int i = 0; i < NF; i++)
+#pragma unroll
+            for(int j = 0; j <= i; j++) {
+                double dot = 0.0;
+#pragma unroll
+                for(int k = 0; k < j; k++) dot += U[ut(k, i)] * U[ut(k, j)];
+                const double sv = A[ut(j, i)] - dot;
+                if(i == j) {
+                    plain = plain && plain_range_lane(sv);
+                    U[ut(j, i)] = sqrt_plain(sv);
+                    rd[j] = rcp_plain(U[ut(j, i)]);
+                } else {
+                    U[ut(j, i)] = rd[j] * sv;
+                }
+            }
+#pragma unroll
+        for(int l = 0; l < NF; l++) {
+            double x[NF];
+#pragma unroll
+            for(int k = 0; k < NF; k++) x[k] = (k == l) ? 1.0 : 0.0;
+#pragma unroll
+            for(int k = l; k < NF; k++) {
+#pragma unroll
+                for(int i = l; i < k; i++) x[k] -= x[i] * U[ut(i, k)];
+                x[k] = div_plain(x[k], U[ut(k, k)], rd[k]);
+            }
+#pragma unroll
+            for(int k = NF - 1; k >= l; k--) {
+#pragma unroll
+                for(int i = k + 1; i < NF; i++) x[k] -= x[i] * U[ut(k, i)];
+                x[k] = div_plain(x[k], U[ut(k, k)], rd[k]);
+                iv[ut(l, k)] = x[k];
+            }
+        }
+    } else {
+        pd = chol_factor<NF>(A, U);
+        chol_inverse<NF>(U, iv);
+    }
+#pragma unroll
+    for(int c = 0; c < M; c++)
+#pragma unroll
+        for(int r = 0; r <= c; r++) inv[ut(r, c)] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for(int c = 0; c < NF; c++)
+#pragma unroll
+        for(int r = 0; r <= c; r++) inv[ut(idx[r], idx[c])] = iv[ut(r, c)];
+}
+
+template <int M, bool PLAIN, unsigned P = 0>
+ILQG_DEV void chol_pattern_all(const double *H, double (*inv)[tri(M)], bool *pd, bool &plain) {
+    if constexpr(P < (1u << M) - 1u) {
+        chol_pattern<M, P, PLAIN>(H, inv[P], pd[P], plain);
+        chol_pattern_all<M, PLAIN, P + 1>(H, inv, pd, plain);
+    }
+}
+
+template <int M>
+ILQG_DEV void chol_pattern_table(const double *H, double (*inv)[tri(M)], bool *pd) {
+    bool plain = true;
+    chol_pattern_all<M, true>(H, inv, pd, plain);
+    if(__builtin_amdgcn_ballot_w64(!plain) != 0ull) chol_pattern_all<M, false>(H, inv, pd, plain);
+}
+// MEASURED (round 4, CarParking headline, same box): no gain.  The section profile of the fused backward kernel at
+// iteration 20 moves 680 cycles per step out of "factorisation + inverse" (1 242 -> 565) and 715 into the section that
+// now holds the table and the selects (2 976 -> 3 691); the step stays at 13 035 cycles, the headline 179-180 against
+// 181-182 it/s.  A wavefront factorised ~2 times per step before (once per outer iteration in which some lane's free set
+// changed), each time ONE pattern per lane; the table is three patterns per lane, every step.
+// profiles/r4_sections_qp_table.txt.  Off by default (-DILQG_QP_TABLE=1 turns it on); the unit-test kernel runs both forms.
+#ifndef ILQG_QP_TABLE
+#define ILQG_QP_TABLE 0
+#endif
+
+// ---------------------------------------------------------------------------
 // boxQP.c
 // ---------------------------------------------------------------------------
 template <int M>
@@ -315,7 +420,7 @@ ILQG_DEV bool armijo_exact(double vc, double oldvalue, double step, double sdotg
 // block's factor and inverse embedded at the original indices (all extra terms
 // are exact zeros), so `invH` is returned in FULL index form: invH[sy(i,j)]
 // for free i,j equals the reference's invHfree[sy(i_free,j_free)].
-template <int M>
+template <int M, bool WITH_TABLE = (ILQG_QP_TABLE != 0)>
 ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const double *upper, double *x,
                     int *clamp, int &n_free_out, double *invH, Prof *pf = nullptr) {
     // Control flow.  The reference leaves its loop through seven `return`s; compiled literally for 64 lanes in
@@ -343,6 +448,12 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
     for(int i = 0; i < T; i++) invH[i] = 0.0;
     n_free_out = 0;
     value = qp_value<M>(H, g, x);
+    // factor and inverse of the free block for every pattern of clamped variables (see chol_pattern_table)
+    constexpr bool TABLE = WITH_TABLE && M <= 3;
+    constexpr int NPAT = TABLE ? (1 << M) - 1 : 1;
+    double inv_of[NPAT][T];
+    bool pd_of[NPAT];
+    if constexpr(TABLE) chol_pattern_table<M>(H, inv_of, pd_of);
 
     for(int iter = 0; iter < max_iter; iter++) {
         if(iter > 0 && (oldvalue - value) < min_rel_improve * fabs(oldvalue)) rc = 4;  // boxQP.c:85-86
@@ -379,7 +490,30 @@ ILQG_DEV int box_qp(const double *H, const double *g, const double *lower, const
 
         // factor + explicit inverse of the free block when the free set changed (boxQP.c:129-146)
         if(pf) pf->probe(2);
-        if(rc == 0 && (iter == 0 || changed)) {
+        if constexpr(TABLE) {
+            // The reference factorises when the free set changed (or in the first iteration); between two such
+            // iterations the pattern — and with it the inverse — stays what it is, so the selection may run in every
+            // iteration: no branch, a handful of selects.
+            int pat = 0;
+#pragma unroll
+            for(int i = 0; i < M; i++) pat |= clamp[i] ? (1 << i) : 0;
+            double inv[T];
+            bool pd = true;
+#pragma unroll
+            for(int i = 0; i < T; i++) inv[i] = inv_of[0][i];
+            pd = pd_of[0];
+#pragma unroll
+            for(int p = 1; p < NPAT; p++) {
+                const bool is = (pat == p);
+#pragma unroll
+                for(int i = 0; i < T; i++) inv[i] = is ? inv_of[p][i] : inv[i];
+                pd = is ? pd_of[p] : pd;
+            }
+            const bool fresh = (rc == 0) & ((iter == 0) | changed);
+            if(fresh & !pd) rc = -1;
+#pragma unroll
+            for(int i = 0; i < T; i++) invH[i] = (fresh & pd) ? inv[i] : invH[i];
+        } else if(rc == 0 && (iter == 0 || changed)) {
             double Hm[T], inv[T];
 #pragma unroll
             for(int j = 0; j < M; j++)

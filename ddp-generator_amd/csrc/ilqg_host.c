@@ -683,6 +683,11 @@ int ilqg_boxqp_wave_batch(int device, int n, int count, const double *H, const d
     return ilqg_dev_boxqp_wave_batch(device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);
 }
 
+int ilqg_boxqp_table_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                           const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
+    return ilqg_dev_boxqp_table_batch(device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);
+}
+
 int ilqg_sincos_batch(int device, int n, const double *x, double *s, double *c) {
     return ilqg_dev_sincos_batch(device, n, x, s, c);
 }

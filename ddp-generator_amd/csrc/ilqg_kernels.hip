@@ -3043,8 +3043,8 @@ __global__ void k_dense_test(int op, int v0, int v1, int v2, const double *in0, 
 #endif
 }
 
-// unit-test kernel for box_qp<M>, one problem per lane
-template <int M>
+// unit-test kernel for box_qp<M>, one problem per lane (TABLE: the pattern-table form, see chol_pattern_table)
+template <int M, bool TABLE = false>
 __global__ __launch_bounds__(64, 1) void k_boxqp_test(int count, const double *H, const double *g, const double *lower, const double *upper,
                              double *x, int *clamp, int *n_free, double *invH, int *rc) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3061,7 +3061,7 @@ __global__ __launch_bounds__(64, 1) void k_boxqp_test(int count, const double *H
         up[i] = upper[(size_t)t * M + i];
         xx[i] = x[(size_t)t * M + i];
     }
-    rc[t] = box_qp<M>(h, gg, lo, up, xx, cl, nf, inv);
+    rc[t] = box_qp<M, TABLE>(h, gg, lo, up, xx, cl, nf, inv);
     n_free[t] = nf;
 #pragma unroll
     for(int i = 0; i < M; i++) {
@@ -4465,8 +4465,15 @@ static int boxqp_batch(int rows, int device, int n, int count, const double *H, 
     HIP_TRY(hipMemcpy(dlo, lower, count * n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dup, upper, count * n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dx, x, count * n * 8, hipMemcpyHostToDevice));
-    const dim3 grid = rows ? dim3(count) : grid1(count, 64), block(64);
-    if(rows && n == 2)
+    const dim3 grid = rows == 1 ? dim3(count) : grid1(count, 64), block(64);
+    if(rows == 2 && n == 2)
+        hipLaunchKernelGGL((k_boxqp_test<2, true>), grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
+    else if(rows == 2 && n == NU)
+        hipLaunchKernelGGL((k_boxqp_test<NU, true>), grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
+    else if(rows == 2) {
+        g_err = "ilqg_dev_boxqp_table_batch: n must be 2 or N_U";
+        return 1;
+    } else if(rows && n == 2)
         hipLaunchKernelGGL(k_boxqp_rows_test<2>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
     else if(rows && n == 8)
         hipLaunchKernelGGL(k_boxqp_rows_test<8>, grid, block, 0, 0, count, dH, dg, dlo, dup, dx, dcl, dnf, dinv, drc);
@@ -4498,6 +4505,11 @@ int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const do
 int ilqg_dev_boxqp_wave_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
                               const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
     return boxqp_batch(1, device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);
+}
+
+int ilqg_dev_boxqp_table_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                               const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
+    return boxqp_batch(2, device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);
 }
 
 // ---------------------------------------------------------------------------

@@ -185,6 +185,11 @@ int ilqg_dev_boxqp_batch(int device, int n, int count, const double *H, const do
 int ilqg_dev_boxqp_wave_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
                               const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
 
+/* ... and for the per-lane form with the factorisations of all clamp patterns made up front (n = 2 or N_U <= 3;
+ * ilqg_device.hpp chol_pattern_table: measured no faster, off in the kernels, kept tested) */
+int ilqg_dev_boxqp_table_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                               const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
+
 /* the reference's small dense helpers on the device (one problem): op 0 addMulVec, 1 addSquareTri, 2 addMul2Tri
  * (shape 0 = (N_X,N_U), 1 = (N_X,N_X), 2 = (N_U,N_X[,1])), 3 cholesky_tri, 4 cholesky_tri_inv (shape = n).
  * flag: 1 ok, 0 Cholesky pivot <= 0, -1 size not built */

@@ -132,6 +132,7 @@ def load_library(problem="carparking", full_ddp=0, strict=False):
     lib.ilqg_batch_get_timing.argtypes = [v, C.c_int, _ip, _dp]
     lib.ilqg_boxqp_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _ip]
     lib.ilqg_boxqp_wave_batch.argtypes = lib.ilqg_boxqp_batch.argtypes
+    lib.ilqg_boxqp_table_batch.argtypes = lib.ilqg_boxqp_batch.argtypes
     lib.ilqg_sincos_batch.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
     lib.ilqg_multi_create.restype = v
     lib.ilqg_multi_create.argtypes = [C.c_int, _ip, C.c_int, C.c_int]
@@ -468,7 +469,8 @@ def solve_single(x0, u_nom, params, opts=None, problem="carparking", full_ddp=0,
 
 def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, device=0, strict=False, cooperative=False):
     """device box-QP on `count` independent problems (arrays [count, ...]); unit-test entry.
-    cooperative: the form of the one-wavefront-per-trajectory mapping (one lane per variable)"""
+    cooperative: the form of the one-wavefront-per-trajectory mapping (one lane per variable);
+    cooperative="table": the per-lane form with the factorisations of all clamp patterns made up front"""
     lib = load_library(problem, full_ddp, strict)
     H = np.ascontiguousarray(H, dtype=np.float64)
     count = H.shape[0]
@@ -478,7 +480,7 @@ def boxqp_batch(n, H, g, lower, upper, x0, problem="carparking", full_ddp=0, dev
     nfree = np.zeros(count, dtype=np.int32)
     invH = np.zeros((count, t))
     rc = np.zeros(count, dtype=np.int32)
-    fn = lib.ilqg_boxqp_wave_batch if cooperative else lib.ilqg_boxqp_batch
+    fn = lib.ilqg_boxqp_table_batch if cooperative == "table" else (lib.ilqg_boxqp_wave_batch if cooperative else lib.ilqg_boxqp_batch)
     r = fn(device, n, count, H.reshape(count, t), np.ascontiguousarray(g, dtype=np.float64),
            np.ascontiguousarray(lower, dtype=np.float64), np.ascontiguousarray(upper, dtype=np.float64),
            x, clamp, nfree, invH, rc)

@@ -211,6 +211,10 @@ int ilqg_boxqp_batch(int device, int n, int count, const double *H, const double
 int ilqg_boxqp_wave_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
                           const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
 
+/* ... and through the per-lane form that factorises every clamp pattern up front (n = 2, or N_U when N_U <= 3) */
+int ilqg_boxqp_table_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
+                           const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc);
+
 /* device sin/cos as the generated callbacks see them, on n arguments (unit tests) */
 int ilqg_sincos_batch(int device, int n, const double *x, double *s, double *c);
 

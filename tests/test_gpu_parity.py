@@ -149,6 +149,36 @@ def test_cooperative_boxqp_equals_the_per_lane_one(ilqg, n, strict):
     assert np.all(np.abs(a["x"][reg] - b["x"][reg]) <= 1e-7 * scale)
 
 
+@pytest.mark.parametrize("strict", [False, True])
+def test_boxqp_with_pattern_table_equals_the_in_loop_factorisation(ilqg, strict):
+    """box_qp<2, TABLE> (factor and inverse of the free block for all three clamp patterns before the iteration, selected
+    by pattern inside it; ilqg_device.hpp chol_pattern_table) against the form that factorises when the free set changes:
+    the same bits in every output, every exit, in both builds — goldens, random problems, problems scaled out of the
+    short forms' range"""
+    n, t = 2, 3
+    g = golden("kernels.npz")
+    sel = np.nonzero(g["qp_n"] == n)[0]
+    rng = np.random.default_rng(11)
+    R = 600
+    A = rng.standard_normal((R, n, n))
+    Mx = A @ np.transpose(A, (0, 2, 1)) + (10.0 ** rng.uniform(-8, 0, R))[:, None, None] * np.eye(n)
+    Mx[:40] -= 2.0 * np.eye(n)  # indefinite ones: failed factorisations (rc -1) of the visited pattern only
+    H = np.concatenate([g["qp_H"][sel][:, :t], np.array([[m[r, c] for c in range(n) for r in range(c + 1)] for m in Mx])])
+    gg = np.concatenate([g["qp_g"][sel][:, :n], rng.standard_normal((R, n))])
+    lo = np.concatenate([g["qp_lo"][sel][:, :n], -np.abs(rng.standard_normal((R, n)))])
+    hi = np.concatenate([g["qp_hi"][sel][:, :n], np.abs(rng.standard_normal((R, n)))])
+    x0 = np.concatenate([g["qp_x0"][sel][:, :n], rng.standard_normal((R, n))])
+    scale = np.ones(len(H))
+    scale[-120:] = np.repeat(2.0 ** np.array([-260.0, -150.0, 150.0, 260.0]), 30)
+    H, gg = H * scale[:, None], gg * scale[:, None]
+    a = ilqg.boxqp_batch(n, H, gg, lo, hi, x0, strict=strict)
+    b = ilqg.boxqp_batch(n, H, gg, lo, hi, x0, strict=strict, cooperative="table")
+    assert len(set(a["rc"].tolist())) >= 5 and (a["rc"] == -1).sum() > 3 and (a["n_free"] == 1).sum() > 20
+    for k in ("rc", "n_free", "clamp"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["x"], b["x"], equal_nan=True) and np.array_equal(a["invH"], b["invH"], equal_nan=True)
+
+
 def test_device_sincos_accuracy(ilqg):
     """the straight-line sincos the callbacks' sin()/cos() are routed through: within 2 ulp of the host
     libm below 8e5 (small, medium, large arguments and next to multiples of pi/2); beyond that, for NaN
