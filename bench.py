@@ -120,6 +120,29 @@ def cpu_baseline(batch_per_gpu, iters, problem, fd, params, n_hor, make_inputs, 
     }
 
 
+def stamped(name):
+    """a committed profile (profiles/<name>) if it was collected on the current kernel sources, else (None, why):
+    ddp-generator_amd/evidence.py"""
+    import __graft_entry__ as g
+    ev = g.load_package().evidence
+    return ev.load_stamped(os.path.join(ROOT, "profiles", name))
+
+
+def issue_object(kernel, name="issue.json"):
+    """roofline.issue: what actually bounds the sweep kernels — vector instructions per step and how much of a wavefront's
+    time goes into issuing them (committed SQ counter passes, tools/round_profile.sh)"""
+    j, why = stamped(name)
+    if j is None:
+        return {"valu_insts_per_step": None, "active_valu_frac": None, "source": None, "stale": why}
+    k = j.get(kernel)
+    if not k:
+        return {"valu_insts_per_step": None, "active_valu_frac": None, "source": "profiles/" + name, "stale": "no entry for " + kernel}
+    return {"kernel": kernel, "valu_insts_per_step": k["valu_insts_per_wave_and_step"], "active_valu_frac": k["active_valu_frac"],
+            "wait_any_frac": k.get("wait_any_frac"), "valu_insts_total": k.get("valu_insts_total"),
+            "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES / %d steps; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; sources %s; "
+                      "not collected in this run)" % (name, j.get("_steps", 0), j.get("_source_sha"))}
+
+
 def with_split(opts, args):
     """the solver options of a run: the library's line-search split unless --ls-split asks for another"""
     if args.ls_split is not None:
@@ -160,6 +183,7 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
     s.sync()
     dt = time.perf_counter() - t0
     times = s.kernel_times()
+    busy = s.kernel_busy()
     sweeps = float(s.ints("bp_calls").mean())
     active = s.active()
     cost = float(s.scalar("cost").mean())
@@ -169,15 +193,17 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
     flops = backpass_flops(nx, nu, 1) * N * B  # one sweep per iteration; lambda retries repeat (parts of) it
     # what an iteration really moves: PMC passes of `bench.py --workload synth` (tools/round_profile.sh), committed
     traffic, traffic_detail = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_config5.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
+    tj, why = stamped("traffic_config5.json")
+    if tj is None:
+        traffic_detail = {"stale": why}
+    else:
         traffic = tj["iteration"]["hbm_bytes"]
         traffic_detail = {"source": "profiles/traffic_config5.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                    "`bench.py --workload synth`, FETCH_SIZE x2 + WRITE_SIZE; not collected in this run)",
+                                    "`bench.py --workload synth`, FETCH_SIZE x2 + WRITE_SIZE, every kernel of an iteration; sources "
+                                    "%s; not collected in this run)" % tj.get("_source_sha"),
                           "hbm_GBs": traffic * it_s / 1e9, "hbm_frac_of_peak": traffic * it_s / 1e9 / HBM_PEAK_GBS,
                           "per_kernel": {k: {"hbm_bytes_per_iteration": v["hbm_bytes_per_launch"] * v["launches_per_iteration"]}
-                                         for k, v in tj.items() if k != "iteration"}}
+                                         for k, v in tj.items() if k not in ("iteration", "_source_sha")}}
     out = {
         "metric": "iLQG iterations/sec, batch 16384 synthetic problem (n=16,m=8,N=1000, FULL_DDP=1)",
         "value": it_s, "unit": "iterations/s", "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "dtype": "f64",
@@ -199,12 +225,45 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
                                        "frac": flops * it_s / 1e12 / FP64_PEAK_TFLOPS,
                                        "note": "reference back_pass arithmetic, one sweep per iteration, over the WHOLE "
                                                "iteration time"}},
-        "kernels_ms_per_iteration_overlapping": {k: v[1] / K for k, v in times.items() if v[0]},
+        # wall clock each kernel occupied per iteration: the union of its launch intervals (the two pieces of the batch run
+        # on two streams and take turns on the chip; the plain sum of their event spans counts the waiting twice)
+        "kernels_busy_ms_per_iteration": {k: v / K for k, v in busy.items()},
+        "kernels_ms_per_iteration_sum_of_spans": {k: v[1] / K for k, v in times.items() if v[0]},
         "trajectories_still_active": int(active), "cost_mean_after_window": cost,
     }
+    out["roofline"]["issue"] = issue_object("k_backward_wave<true>", "issue_config5.json")
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(B, K, "synth16x8", 1, synth.SYNTH16_PARAMS, N, synth.synth16_batch, budget_s=4.0,
                                            max_per_core=2)
+    return out
+
+
+def config2(ilqg, synth, local, K=20, W=2):
+    """BASELINE config 2: CarParking, 4 096 randomised starts, fp64, one GPU — in the lane mapping (the product's choice
+    for n <= 8) and in the one-wavefront-per-trajectory build BASELINE.json words it for"""
+    B, N = 4096, 500
+    x0, u0 = synth.car_batch(B, N)
+    out = {"metric": "iLQG iterations/sec, batch 4096 CarParking (n=4,m=2,N=500)", "unit": "iterations/s", "steps": K, "warmup": W,
+           "config": {"workload": "CarParking batch=4096 randomised x0, 8-alpha line search, FULL_DDP=0, first %d iterations after "
+                                  "the initial roll-out" % K}}
+    for label, variant in (("lane_mapping", False), ("wave_mapping", "wave")):
+        s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=N, device=local, params=ilqg.CAR_PARAMS, opts=dict(max_iter=K + W + 1),
+                             strict=variant)
+        s.init(x0, u0)
+        if W > 0:
+            s.iterate(W)
+            s.sync()
+            s.init(x0, u0)
+        s.sync()
+        t0 = time.perf_counter()
+        s.iterate(K)
+        s.sync()
+        dt = time.perf_counter() - t0
+        out[label] = {"value": K / dt, "ms_per_step": 1e3 * dt / K, "stream_groups": s.groups(),
+                      "cost_mean_after_window": float(s.scalar("cost").mean()), "trajectories_still_active": int(s.active())}
+        s.close()
+    out["note"] = ("4 096 trajectories are 64 wavefronts in the lane mapping (a 16th of the chip's SIMDs, each a chain of 500 "
+                   "dependent steps: the time is that of ONE wavefront's chain) and 4 096 wavefronts in the wave mapping")
     return out
 
 
@@ -220,13 +279,63 @@ def dropin_b1(ilqg, synth, iters=20):
                     "so one trajectory cannot use the GPU — compare cpu_baseline.single_core_ms_per_trajectory_iteration"}
 
 
+class ProtocolShard:
+    """--rehearse-protocol: stands where the solver of a rank stands and does NO numerics — its "costs" are the global
+    indices of the shard's trajectories.  What runs for real is everything around the solver in main(): the shard
+    offsets, the barriers on both sides of the timed region, the single gather of the per-trajectory costs, the maximum
+    over the ranks, the assembly of the JSON line on rank 0.  For boxes without a GPU (the line says `rehearsal`; its
+    `value` is not a measurement)."""
+
+    class _Problem:
+        wave_mapping = False
+
+    problem = _Problem()
+
+    def __init__(self, B, first):
+        self.B, self.first, self.iters = B, first, 0
+
+    def init(self, x0, u0):
+        assert len(x0) == self.B and len(u0) == self.B
+        self.iters = 0
+
+    def iterate(self, n):
+        self.iters += n
+
+    def sync(self):
+        pass
+
+    def timing(self, enable=True):
+        pass
+
+    def set_option(self, name, value):
+        pass
+
+    def scalar(self, name):
+        return np.arange(self.first, self.first + self.B, dtype=np.float64) + 0.001 * self.iters
+
+    def kernel_times(self):
+        return {}
+
+    def active(self):
+        return self.B
+
+    def groups(self):
+        return 1
+
+    def close(self):
+        pass
+
+
 def single_process(args, ilqg, synth):
-    """N GPUs of the node driven by ONE process through ilqg_multi_* (the C counterpart of the torchrun path)"""
+    """N GPUs of the node driven by ONE process through ilqg_multi_* (the C counterpart of the torchrun path);
+    --devices 0,0,...: the shards on the listed devices (equal ids: loop-back rehearsal on one GPU)"""
     G, K, W = args.gpus, args.steps, args.warmup
     per, n_hor = (args.batch or 65536), (args.n_hor or 500)
     B = per * G
+    devices = [int(v) for v in args.devices.split(",")] if args.devices else list(range(G))
+    assert len(devices) == G, "--devices needs one id per shard (--gpus %d)" % G
     x0, u0 = synth.car_batch(B, n_hor)
-    m = ilqg.MultiSolver("carparking", 0, batch=B, n_hor=n_hor, devices=list(range(G)), params=ilqg.CAR_PARAMS,
+    m = ilqg.MultiSolver("carparking", 0, batch=B, n_hor=n_hor, devices=devices, params=ilqg.CAR_PARAMS,
                          opts=with_split(dict(max_iter=max(K, W) + 1), args))
     m.init(x0, u0)
     if W > 0:
@@ -251,7 +360,9 @@ def single_process(args, ilqg, synth):
         "config": {"workload": "CarParking batch=%d per GPU x %d GPU, 8-alpha line search, FULL_DDP=0, first %d iterations "
                                "after the initial roll-out" % (per, G, K),
                    "batch_per_gpu": per, "n_hor": n_hor,
-                   "parallelism": "ONE process, ilqg_multi_*: contiguous shards, one ncclGather of the costs"},
+                   "devices": devices,
+                   "parallelism": "ONE process, ilqg_multi_*: contiguous shards, one ncclGather of the costs"
+                                  + (" (all shards on one device: the gather is device-to-device copies)" if len(set(devices)) == 1 and G > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": "iteration", "achieved": iter_bytes * (K / dt) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": iter_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "note": "per GPU; algorithmic bytes of SURVEY 8(d)"},
@@ -284,6 +395,14 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N > 1 without torch.distributed.run: ONE process drives the N GPUs through the C "
                          "interface ilqg_multi_* (hipSetDevice per shard, ncclCommInitAll, one ncclGather of the costs)")
+    ap.add_argument("--devices", default=None, help="--single-process: device id of every shard, e.g. 0,0,0,0,0,0,0,0")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend of the one-process-per-GPU path; gloo: the collective's tensors go "
+                         "through host memory (rehearsals on boxes with fewer GPUs than ranks, CPU tests)")
+    ap.add_argument("--all-on-device", type=int, default=None, help="every rank uses this device (rehearsal of N ranks on one GPU)")
+    ap.add_argument("--rehearse-protocol", action="store_true",
+                    help="no solver, no GPU: the ranks run the sharding / barrier / gather / JSON protocol around a stand-in "
+                         "(ProtocolShard); the line is marked `rehearsal` and measures nothing")
     ap.add_argument("--groups", type=int, default=0,
                     help="independent sets of trajectories advanced on separate HIP streams (0: library default)")
     args = ap.parse_args()
@@ -297,11 +416,20 @@ def main():
     rank, local, world = pkg.dist.env_world()
     if args.single_process and world == 1 and args.gpus > 1:
         return single_process(args, ilqg, synth)
+    rehearsal = args.rehearse_protocol
+    if rehearsal:
+        args.no_unfused = args.no_cpu_baseline = True  # (nothing of the product runs)
+    if args.all_on_device is not None:
+        local = args.all_on_device
+    host_collective = args.backend == "gloo" or rehearsal  # the collective's tensors live in host memory
     if world > 1:
-        pkg.dist.init("nccl", rank, world, torch.device("cuda", local))
+        pkg.dist.init("gloo" if rehearsal else args.backend, rank, world, None if host_collective else torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if not rehearsal:
+        torch.cuda.set_device(local)
+    dev = torch.device("cpu") if rehearsal else torch.device("cuda", local)
+    cdev = torch.device("cpu") if host_collective else dev
+    device_sync = (lambda: None) if rehearsal else torch.cuda.synchronize
 
     car = args.workload == "car"
     problem = "carparking" if car else "synth16x8"
@@ -314,9 +442,12 @@ def main():
     first = pkg.dist.shard_first(rank, B)
     x0, u0 = synth.car_batch(B, n_hor, first=first) if car else synth.synth16_batch(B, n_hor, first=first)
     params = ilqg.CAR_PARAMS if car else synth.SYNTH16_PARAMS
-    s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=n_hor, device=local, params=params,
-                         opts=with_split(dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, **({"ls_keep": args.ls_keep} if args.ls_keep is not None else {}), **({"bw_split": 1} if args.bw_split else {})), args),
-                         strict=("wave" if args.mapping == "wave" else False), groups=args.groups)
+    if rehearsal:
+        s = ProtocolShard(B, first)
+    else:
+        s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=n_hor, device=local, params=params,
+                             opts=with_split(dict(max_iter=max(K, W) + 1, fuse_derivs=args.fuse_derivs, **({"ls_keep": args.ls_keep} if args.ls_keep is not None else {}), **({"bw_split": 1} if args.bw_split else {})), args),
+                             strict=("wave" if args.mapping == "wave" else False), groups=args.groups)
     if args.resweep >= 0:
         s.set_option("resweep", args.resweep)
     s.init(x0, u0)
@@ -328,18 +459,21 @@ def main():
     cost_dev = torch.empty(B, dtype=torch.float64, device=dev)
 
     def barrier():
-        pkg.dist.barrier(world, torch.cuda.synchronize)
+        pkg.dist.barrier(world, device_sync)
 
     s.timing(True)  # (events come from a pool filled here: none is created inside the window)
     barrier()
     t0 = time.perf_counter()
     s.iterate(K)
-    s.scalar_to_device("cost", cost_dev.data_ptr())  # synchronises the solver's streams
-    # the single collective of the path: per-trajectory costs to rank 0 over RCCL/xGMI
-    gathered = pkg.dist.gather_costs(cost_dev, rank, world)
+    if rehearsal:
+        cost_dev.copy_(torch.from_numpy(s.scalar("cost")))
+    else:
+        s.scalar_to_device("cost", cost_dev.data_ptr())  # synchronises the solver's streams
+    # the single collective of the path: per-trajectory costs to rank 0 over RCCL/xGMI (gloo: through host memory)
+    gathered = pkg.dist.gather_costs(cost_dev if cdev == dev else cost_dev.to(cdev), rank, world)
     barrier()
     dt = time.perf_counter() - t0
-    dt = pkg.dist.max_over_ranks(dt, world, dev)  # MAX over ranks
+    dt = pkg.dist.max_over_ranks(dt, world, cdev)  # MAX over ranks
 
     times = s.kernel_times()
     active = s.active()
@@ -356,11 +490,11 @@ def main():
                        "iLQG iterations/sec, batch %d synthetic problem (n=16,m=8,N=%d, FULL_DDP=%d)" % (B, n_hor, fd)),
             # whole job: every rank advances its own 65 536-trajectory shard by K iterations (weak scaling), so the
             # job does world x K batch-iterations in the slowest rank's time
-            "value": pkg.dist.whole_job_rate(K, dt, world),
+            "value": None if rehearsal else pkg.dist.whole_job_rate(K, dt, world),
             "unit": "iterations/s",
             "value_definition": "iterations of a %d-trajectory batch per second, whole job: %d rank(s) x %d iterations / time of "
                                 "the slowest rank" % (B, world, K),
-            "per_gpu_iterations_per_s": K / dt,
+            "per_gpu_iterations_per_s": None if rehearsal else K / dt,
             "n_gpus": world,
             "steps": K,
             "warmup": W,
@@ -370,6 +504,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            **({"rehearsal": "protocol only (--rehearse-protocol): no solver ran, `value` is not a measurement; the costs "
+                             "gathered are the trajectories' global indices", "gathered_costs_in_order":
+                             bool(np.array_equal(np.floor(cost), np.arange(B * world)))} if rehearsal else {}),
+            "collective": {"backend": "gloo" if rehearsal else args.backend, "tensors": "host memory" if host_collective else "device memory",
+                           "doubles_per_rank": B, "gathered_on_rank_0": int(cost.size)},
             "config": {"workload": "%s batch=%d per GPU x %d GPU, 8-alpha line search, FULL_DDP=%d, "
                                    "first %d iterations after the initial roll-out" % ("CarParking" if car else "Synth16x8", B, world, fd, K),
                        "batch_per_gpu": B, "n_hor": n_hor, "n_x": nx, "n_u": nu, "full_ddp": fd,
@@ -399,10 +538,10 @@ def main():
             #                   FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 correction) / the same duration:
             #                   the real HBM utilisation
             #   valu_fp64       the reference's back_pass arithmetic / duration against the fp64 vector peak
-            tj = {}
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath) and B == 65536:
-                tj = json.load(open(tpath))
+            tj, traffic_stale = stamped("traffic.json")
+            if tj is None or B != 65536:
+                tj = {}
+                traffic_stale = traffic_stale or "profiles/traffic.json is for 65 536 trajectories per GPU"
             per_launch = B / max(1, stream_groups)
 
             def launch_object(name, alg_bytes_per_step, flops_per_step, moved_per_step):
@@ -422,8 +561,10 @@ def main():
                     o["pmc"] = {"hbm_bytes_per_launch": pmc, "GBs": pmc / (avg_ms * 1e-3) / 1e9,
                                 "frac_of_peak": pmc / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                          "command, tools/collect_traffic.sh; per launch of one of the stream groups; not "
-                                          "collected in this run)"}
+                                          "command, tools/collect_traffic.sh; per launch of one of the stream groups; sources "
+                                          "%s; not collected in this run)" % tj.get("_source_sha")}
+                elif traffic_stale:
+                    o["pmc"] = {"hbm_bytes_per_launch": None, "stale": traffic_stale}
                 if flops_per_step:
                     o["valu_fp64"] = {"algorithmic_flops_per_launch": flops_per_step * n_hor * per_launch,
                                       "TFLOPs": flops_per_step * n_hor * per_launch / (avg_ms * 1e-3) / 1e12,
@@ -438,10 +579,14 @@ def main():
                    or launch_object("k_rollout[search]", alg["k_rollout[search]"], 0, (nx + 2 * nu + nx * nu) * 8))
             if bw:
                 out["roofline"] = {
-                    "bound": "valu_fp64", "kernel": bw["kernel"],
+                    # bound / achieved / peak / unit / frac: the contract's HBM figure (algorithmic bytes over the launch's
+                    # duration against 8 TB/s).  What limits the kernel is in `limiter` / `issue`.
+                    "bound": "hbm", "kernel": bw["kernel"],
                     "achieved": bw["hbm_equivalent"]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": bw["hbm_equivalent"]["frac_of_peak"],
                     "traffic": bw.get("pmc", {}).get("hbm_bytes_per_launch"),
+                    "limiter": "valu_issue (fp64 vector instruction issue of ONE wavefront per SIMD, and the divergence of the box QP)",
+                    "issue": issue_object("k_backward<2>"),
                     "dominant_launch": bw, "second_launch": st1,
                     "note": "achieved / frac follow the contract's recipe: SURVEY 8(d)'s ALGORITHMIC bytes of the launch "
                             "(the 1 024 B per step and trajectory of the two stages this kernel replaces x steps x the "
@@ -487,6 +632,10 @@ def main():
                 out["dropin_b1"] = dropin_b1(ilqg, synth)
             except Exception as e:
                 out["dropin_b1"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                out["config2"] = config2(ilqg, synth, local)
+            except Exception as e:
+                out["config2"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if not args.no_config5:
                 try:
                     out["config5"] = config5(ilqg, synth, local, with_cpu=not args.no_cpu_baseline)

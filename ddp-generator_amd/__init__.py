@@ -6,3 +6,4 @@ The directory name contains a hyphen, so load it with `load_package()` from
 from . import synth  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
 from . import ilqg  # noqa: F401,E402
+from . import evidence  # noqa: F401,E402

@@ -673,6 +673,18 @@ int ilqg_batch_get_timing(ilqg_batch_t *c, int kernel, int *launches, double *to
     return 0;
 }
 
+/* wall-clock time a kernel occupied (union of its launch intervals), summed over the groups */
+int ilqg_batch_get_busy(ilqg_batch_t *c, int kernel, double *busy_ms) {
+    int g;
+    double ms;
+    *busy_ms = 0.0;
+    EACH_GROUP(g) {
+        if(ilqg_dev_get_busy(c->dev[g], kernel, &ms)) return fail(c, "get_busy");
+        *busy_ms += ms;
+    }
+    return 0;
+}
+
 int ilqg_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,
                      const double *upper, double *x, int *clamp, int *n_free, double *invH, int *rc) {
     return ilqg_dev_boxqp_batch(device, n, count, H, g, lower, upper, x, clamp, n_free, invH, rc);

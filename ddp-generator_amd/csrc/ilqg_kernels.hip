@@ -25,7 +25,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -312,8 +314,9 @@ struct DevPtrs {
     int *pending;        // trajectories that go to the second line-search stage
     int *n_pending;      // their count (read by the second stage)
     int *n_pending_next; // counter the first-stage selection appends with (same word as n_pending)
-    double *xpl, *upl;   // lane mapping, ls_keep = 2: the kept roll-outs of the first line-search stage, 2 x PLANE_A planes
+    double *xpl, *upl;   // lane mapping, ls_keep = 2: the kept roll-outs of the first line-search stage, 2 x plane_n planes
     size_t xplane, uplane; //   of the layout and size of X resp. U (doubles per plane); see cur_x
+    int plane_n;         //   planes per set = step sizes of the first stage (<= PLANE_A)
     double *cand1;       // wave mapping, ls_keep = 2: what the FIRST stage's lanes roll out, [step size][step 0..N][x u][trajectory]
     double *cand;        // second line-search stage: the trajectories its lanes roll out, [step size][step 0..N][x u]
                          //   [entry of pending] (entry fastest: a wavefront stores whole rows) — the accepted one is
@@ -391,7 +394,7 @@ __device__ __forceinline__ size_t ix(const DevPtrs &P, int W, int steps, int k, 
 // With ls_keep = 2 the tiled representation exists in 1 + 2 PLANE_A copies of identical layout: the arrays X / U
 // ("home") and two sets of PLANE_A planes that the first stage of the line search rolls its candidates out into (set
 // by set in turn).  ILQG_I_LOC says where the CURRENT trajectory of b is: accepting the roll-out of step size a of a
-// search that wrote set s is `loc = 1 + s PLANE_A + a` — no second roll-out of the winner and no copy (both were
+// search that wrote set s is `loc = 1 + s plane_n + a` (plane_n = step sizes of the first stage) — no second roll-out of the winner and no copy (both were
 // measured: the winner pass is a chain of N dependent steps and 376 vector instructions per step and trajectory; a
 // copy out of per-step-size planes reads four lines for every one it needs).  Everything that reads or writes "the
 // current (x, u)" goes through cur_x / cur_u and follows: a lane's base address is chosen once, the strides are
@@ -2143,7 +2146,7 @@ __global__ __launch_bounds__(WAVE, ILQG_SEARCH_OCC) void k_search(DevPtrs P, ilq
         kx = P.cand + (size_t)a * (N + 1) * CAND_W * P.Bp + ee;
         ku = kx + (size_t)NX * P.Bp;
     } else {
-        const int plane = set * PLANE_A + a;
+        const int plane = set * P.plane_n + a;
         kx = P.xpl + (size_t)plane * P.xplane + ix(P, NX, N + 1, 0, 0, b);
         ku = P.upl + (size_t)plane * P.uplane + ix(P, NU, N, 0, 0, b);
     }
@@ -2378,7 +2381,7 @@ __global__ void k_commit(DevPtrs P, int s1, int set) {
     if(b >= P.B || P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) return;
     const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1;
     if(P.i[ILQG_I_ACCEPTED][b])
-        P.i[ILQG_I_LOC][b] = (a < s1) ? 1 + set * PLANE_A + a : 0;
+        P.i[ILQG_I_LOC][b] = (a < s1) ? 1 + set * P.plane_n + a : 0;
     else
         P.i[ILQG_I_LOC][b] = 0;
 }
@@ -2647,6 +2650,7 @@ __global__ __launch_bounds__(WAVE *RW) void k_rollout_parts(DevPtrs P, ilqg_dev_
             double c = s_t[lane][0];
 #pragma unroll
             for(int m = 1; m < RT; m++) c = c + s_t[lane][m];
+            if(!(c - c == 0.0)) bad = 1;  // ddpL's guard on t->c (NaN or Inf: forward_pass returns 0, iLQG_func.tem:175)
             csum += c;
         }
         // (the next step's phase 1 writes s_u, read before this barrier pair's second barrier by everybody; its
@@ -2822,7 +2826,7 @@ __global__ void k_update(DevPtrs P, ilqg_dev_opts_t O, int commit_s1, int commit
     if(b >= P.B) return;
     if(!WAVE_MAP && commit_s1 >= 0 && P.i[ILQG_I_STATUS][b] == ILQG_ST_ACTIVE) {
         const int a = P.i[ILQG_I_ALPHA_IDX][b] - 1;
-        P.i[ILQG_I_LOC][b] = (P.i[ILQG_I_ACCEPTED][b] && a < commit_s1) ? 1 + commit_set * PLANE_A + a : 0;
+        P.i[ILQG_I_LOC][b] = (P.i[ILQG_I_ACCEPTED][b] && a < commit_s1) ? 1 + commit_set * P.plane_n + a : 0;
     }
     if(P.i[ILQG_I_STATUS][b] != ILQG_ST_ACTIVE) {  // finished, possibly in this iteration's backward pass
         P.i[ILQG_I_RESWEEP][b] = 0;
@@ -3187,6 +3191,11 @@ struct ilqg_dev {
     std::vector<hipEvent_t> event_pool;  // events of drained spans, reused: none is created while a window is timed
     double t_ms[ILQG_K_COUNT];
     int t_n[ILQG_K_COUNT];
+    // launches of one kernel on the context's two streams overlap in the event clock (the later one waits for the chip):
+    // t_busy is the length of the UNION of a kernel's launch intervals, measured against an event recorded when timing
+    // was switched on
+    hipEvent_t epoch;
+    double t_busy[ILQG_K_COUNT];
 };
 
 namespace {
@@ -3339,13 +3348,25 @@ int drain_spans(ilqg_dev *d) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream2));
     if(d->roll) HIP_TRY(hipStreamSynchronize(d->roll));
+    std::vector<std::pair<float, float>> iv[ILQG_K_COUNT];
     for(auto &s : d->spans) {
-        float ms = 0.f;
+        float ms = 0.f, t0 = 0.f;
         hipEventElapsedTime(&ms, s.a, s.b);
         d->t_ms[s.kernel] += ms;
         d->t_n[s.kernel]++;
+        if(d->epoch && hipEventElapsedTime(&t0, d->epoch, s.a) == hipSuccess) iv[s.kernel].push_back({t0, t0 + ms});
         d->event_pool.push_back(s.a);
         d->event_pool.push_back(s.b);
+    }
+    (void)hipGetLastError();
+    for(int k = 0; k < ILQG_K_COUNT; k++) {  // union of the intervals of this batch of spans
+        std::sort(iv[k].begin(), iv[k].end());
+        float end = -1.f;
+        for(auto &q : iv[k]) {
+            if(q.second <= end) continue;
+            d->t_busy[k] += q.second - (q.first > end ? q.first : end);
+            end = q.second;
+        }
     }
     d->spans.clear();
     return 0;
@@ -3429,6 +3450,7 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
     d->loc_set = -1;
     memset(d->t_ms, 0, sizeof(d->t_ms));
     memset(d->t_n, 0, sizeof(d->t_n));
+    memset(d->t_busy, 0, sizeof(d->t_busy));
     memset(&d->P, 0, sizeof(d->P));
     memset(&d->O, 0, sizeof(d->O));
     memset(&d->pv, 0, sizeof(d->pv));
@@ -3613,6 +3635,7 @@ void ilqg_dev_destroy(ilqg_dev_t *d) {
     if(d->roll) hipStreamSynchronize(d->roll);
     if(d->roll_in) hipEventDestroy(d->roll_in);
     if(d->roll_out) hipEventDestroy(d->roll_out);
+    if(d->epoch) hipEventDestroy(d->epoch);
     delete d;
 }
 
@@ -3906,6 +3929,23 @@ static int ensure_buffer(ilqg_dev_t *d, double **buf, size_t *have, size_t need,
     return 0;
 }
 
+// the same for a buffer the caller can do without: 2 = the device does not have the memory (the error is cleared)
+static int try_buffer(ilqg_dev_t *d, double **buf, size_t *have, size_t need, hipStream_t rs) {
+    if(*have >= need) return 0;
+    HIP_TRY(hipStreamSynchronize(rs));
+    if(*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    // (ILQG_TEST_NO_PLANES: the tests' way to a device that is out of memory)
+    if(getenv("ILQG_TEST_NO_PLANES") || hipMalloc((void **)buf, need) != hipSuccess) {
+        (void)hipGetLastError();
+        *buf = nullptr;
+        return 2;
+    }
+    *have = need;
+    return 0;
+}
+
 // ls_keep = 2: every current trajectory back into the arrays X / U (the host is about to read or write them, an
 // initial roll-out is about to store there, or a search that does not keep its roll-outs follows)
 static int all_home(ilqg_dev_t *d) {
@@ -4162,13 +4202,33 @@ int ilqg_dev_search(ilqg_dev_t *d) {
     const int s1 = (d->O.ls_split > 0 && d->O.ls_split < A) ? d->O.ls_split : A;
     hipStream_t rs = roll_stream(d);
 #if !ILQG_WAVE_MAP
-    if(d->O.ls_keep >= 2 && s1 <= PLANE_A && WAVE / s1 >= 1 && (A == s1 || WAVE / (A - s1) >= 1)) {
+    bool keep_all = d->O.ls_keep >= 2 && s1 <= PLANE_A && WAVE / s1 >= 1 && (A == s1 || WAVE / (A - s1) >= 1);
+    const size_t xplane = (size_t)(d->N + 1) * NX * d->Bp, uplane = (size_t)d->N * NU * d->Bp;
+    if(keep_all) {
+        // Two sets of s1 planes of the size of X resp. U (12.6 GB for the benchmark: 2 x 4 planes of 65 536 x 501 x 6
+        // doubles).  The planes are laid out s1 to a set: a first stage of another size re-homes the trajectories first.
+        // A device that cannot provide them (a larger batch, several contexts sharing it) searches without keeping
+        // every roll-out instead of failing: the ls_keep = 1 form below needs none of this memory.
+        if(d->P.plane_n != s1) {
+            if(all_home(d)) return 1;
+            d->P.plane_n = s1;
+        }
+        const int rx = try_buffer(d, &d->P.xpl, &d->xpl_bytes, 2 * (size_t)s1 * xplane * sizeof(double), rs);
+        const int ru = rx ? rx : try_buffer(d, &d->P.upl, &d->upl_bytes, 2 * (size_t)s1 * uplane * sizeof(double), rs);
+        if(rx == 1 || ru == 1) return 1;
+        if(rx == 2 || ru == 2) {
+            if(d->P.xpl) HIP_TRY(hipFree(d->P.xpl));
+            d->P.xpl = nullptr;
+            d->xpl_bytes = 0;
+            keep_all = false;  // (all_home() below: nothing lives in a plane any more — there are none)
+            d->loc_set = -1;
+            HIP_TRY(hipMemsetAsync(d->P.i[ILQG_I_LOC], 0, d->Bp * sizeof(int), d->stream));
+        }
+    }
+    if(keep_all) {
         // Every roll-out of the search is kept and the accepted one becomes the current trajectory by a change of its
         // location index (k_search, k_adopt_home, k_commit; see cur_x).
         const int n2 = A - s1, set = (d->loc_set == 0) ? 1 : 0;
-        const size_t xplane = (size_t)(d->N + 1) * NX * d->Bp, uplane = (size_t)d->N * NU * d->Bp;
-        if(ensure_buffer(d, &d->P.xpl, &d->xpl_bytes, 2 * PLANE_A * xplane * sizeof(double), rs)) return 1;
-        if(ensure_buffer(d, &d->P.upl, &d->upl_bytes, 2 * PLANE_A * uplane * sizeof(double), rs)) return 1;
         d->P.xplane = xplane;
         d->P.uplane = uplane;
         if(n2 > 0 && ensure_buffer(d, &d->P.cand, &d->cand_bytes, (size_t)d->Bp * n2 * (d->N + 1) * CAND_W * sizeof(double), rs))
@@ -4387,6 +4447,23 @@ int ilqg_dev_timing(ilqg_dev_t *d, int enable) {
     d->timing = enable != 0;
     memset(d->t_ms, 0, sizeof(d->t_ms));
     memset(d->t_n, 0, sizeof(d->t_n));
+    memset(d->t_busy, 0, sizeof(d->t_busy));
+    if(enable) {
+        if(!d->epoch) HIP_TRY(hipEventCreate(&d->epoch));
+        HIP_TRY(hipEventRecord(d->epoch, d->stream));
+    }
+    return 0;
+}
+
+/* length of the union of the launch intervals of a kernel since timing was switched on (ms): what the kernel occupied
+ * of the wall clock, however its launches on different streams overlap in the event clock */
+int ilqg_dev_get_busy(ilqg_dev_t *d, int kernel, double *busy_ms) {
+    if(kernel < 0 || kernel >= ILQG_K_COUNT) {
+        g_err = "ilqg_dev_get_busy: bad kernel id";
+        return 1;
+    }
+    if(drain_spans(d)) return 1;
+    *busy_ms = d->t_busy[kernel];
     return 0;
 }
 

@@ -174,6 +174,7 @@ int ilqg_dev_section_cycles(unsigned long long *out8);
 /* per-kernel HIP-event timing on the context's stream */
 int ilqg_dev_timing(ilqg_dev_t *d, int enable);
 int ilqg_dev_get_timing(ilqg_dev_t *d, int kernel, int *launches, double *total_ms);
+int ilqg_dev_get_busy(ilqg_dev_t *d, int kernel, double *busy_ms);  /* union of the kernel's launch intervals */
 const char *ilqg_dev_kernel_name(int kernel);
 
 /* unit-test entry for the device box-QP (same template the backward kernel uses):

@@ -130,6 +130,7 @@ def load_library(problem="carparking", full_ddp=0, strict=False):
     lib.ilqg_batch_kernel_name.restype = C.c_char_p
     lib.ilqg_batch_kernel_name.argtypes = [C.c_int]
     lib.ilqg_batch_get_timing.argtypes = [v, C.c_int, _ip, _dp]
+    lib.ilqg_batch_get_busy.argtypes = [v, C.c_int, _dp]
     lib.ilqg_boxqp_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _ip]
     lib.ilqg_boxqp_wave_batch.argtypes = lib.ilqg_boxqp_batch.argtypes
     lib.ilqg_boxqp_table_batch.argtypes = lib.ilqg_boxqp_batch.argtypes
@@ -364,6 +365,18 @@ class BatchSolver:
         for k in range(self.lib.ilqg_batch_kernel_count()):
             self._ck(self.lib.ilqg_batch_get_timing(self.h, k, n, ms))
             out[self.lib.ilqg_batch_kernel_name(k).decode()] = (int(n[0]), float(ms[0]))
+        return out
+
+
+    def kernel_busy(self):
+        """{kernel name: ms of wall clock its launches occupied} (union of the launch intervals: launches of one kernel
+        on two streams overlap in the event clock while they take turns on the chip)"""
+        out = {}
+        ms = np.zeros(1)
+        for k in range(self.lib.ilqg_batch_kernel_count()):
+            self._ck(self.lib.ilqg_batch_get_busy(self.h, k, ms))
+            if ms[0] > 0:
+                out[self.lib.ilqg_batch_kernel_name(k).decode()] = float(ms[0])
         return out
 
 

@@ -201,6 +201,9 @@ int ilqg_batch_timing(ilqg_batch_t *c, int enable);
 int ilqg_batch_kernel_count(void);
 const char *ilqg_batch_kernel_name(int kernel);
 int ilqg_batch_get_timing(ilqg_batch_t *c, int kernel, int *launches, double *total_ms);
+/* ms of wall clock the kernel occupied since timing was switched on: the union of its launch intervals per group of
+ * trajectories, summed over the groups (launches on a group's two streams overlap in the event clock) */
+int ilqg_batch_get_busy(ilqg_batch_t *c, int kernel, double *busy_ms);
 
 /* device box-QP on `count` independent problems of size n in {2, 8, N_U} (unit tests) */
 int ilqg_boxqp_batch(int device, int n, int count, const double *H, const double *g, const double *lower,

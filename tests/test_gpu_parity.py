@@ -179,6 +179,27 @@ def test_boxqp_with_pattern_table_equals_the_in_loop_factorisation(ilqg, strict)
     assert np.array_equal(a["x"], b["x"], equal_nan=True) and np.array_equal(a["invH"], b["invH"], equal_nan=True)
 
 
+def test_search_without_memory_for_the_kept_rollouts_falls_back(ilqg, synth, monkeypatch):
+    """ls_keep = 2 wants two sets of planes of the size of X / U; a device that cannot provide them searches in the
+    ls_keep = 1 form instead of failing — same results (FMA-free build: the same bits)"""
+    B, N, K = 200, 500, 6
+    x0, u0 = synth.car_batch(B, N)
+
+    def run():
+        s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=N, params=ilqg.CAR_PARAMS, opts=dict(max_iter=K), strict=True)
+        s.init(x0, u0)
+        s.iterate(K)
+        out = (s.scalar("cost").copy(), s.x().copy(), s.u().copy(), s.ints("alpha_idx").copy())
+        s.close()
+        return out
+
+    a = run()
+    monkeypatch.setenv("ILQG_TEST_NO_PLANES", "1")
+    b = run()
+    for p, q in zip(a, b):
+        assert np.array_equal(p, q)
+
+
 def test_device_sincos_accuracy(ilqg):
     """the straight-line sincos the callbacks' sin()/cos() are routed through: within 2 ulp of the host
     libm below 8e5 (small, medium, large arguments and next to multiples of pi/2); beyond that, for NaN

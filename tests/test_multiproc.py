@@ -73,3 +73,62 @@ def test_generator_is_shard_invariant():
     xa, ua = synth.car_batch(10)
     xb, ub = synth.car_batch(4, first=6)
     assert np.array_equal(xa[6:], xb) and np.array_equal(ua[6:], ub)
+
+
+def _run_bench(argv, nproc=0, port=0):
+    """bench.py as the driver launches it (nproc > 1: torch.distributed.run, one process per rank); its JSON line"""
+    import json
+    import subprocess
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py")] + argv
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_main_with_two_ranks_protocol_rehearsal():
+    """bench.py's own N > 1 branch (shard offsets, barriers, the single gather, max over ranks, rank-0 JSON) with
+    world = 2 on CPU ranks: --rehearse-protocol puts a stand-in without numerics where the solver stands"""
+    port = 29900 + (os.getpid() % 90)
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "96", "--rehearse-protocol"], nproc=2, port=port)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["value"] is None and "rehearsal" in out  # not a measurement, and says so
+    assert out["gathered_costs_in_order"] is True       # rank r's shard sits at [r * 96, (r + 1) * 96) on rank 0
+    assert out["collective"] == {"backend": "gloo", "tensors": "host memory", "doubles_per_rank": 96, "gathered_on_rank_0": 192}
+    assert out["config"]["batch_per_gpu"] == 96 and "x 2 GPU" in out["config"]["workload"]
+    assert out["roofline"]["bound"] == "hbm" and out["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_main_with_two_ranks_on_one_gpu():
+    """the same branch with the PRODUCT under it: two ranks (gloo, collective through host memory) share device 0, each
+    advances its shard; the line is a real (small) measurement and the gathered costs are those of one 2 x 512 batch"""
+    port = 29800 + (os.getpid() % 90)
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512", "--backend", "gloo", "--all-on-device", "0",
+                      "--no-cpu-baseline"], nproc=2, port=port)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "rehearsal" not in out
+    assert abs(out["value"] - 2 * out["per_gpu_iterations_per_s"]) < 1e-9 * out["value"]  # whole job = 2 shards
+    assert out["collective"]["gathered_on_rank_0"] == 1024 and out["trajectories_still_active"] == 512
+    pkg = load_package()
+    x0, u0 = pkg.synth.car_batch(1024)
+    s = pkg.ilqg.BatchSolver("carparking", 0, batch=1024, n_hor=500, params=pkg.ilqg.CAR_PARAMS, opts=dict(max_iter=4))
+    s.init(x0, u0)
+    s.iterate(3)
+    want = float(s.scalar("cost").mean())
+    s.close()
+    assert abs(out["cost_mean_after_window"] - want) <= 1e-12 * abs(want)
+
+
+@pytest.mark.gpu
+def test_bench_single_process_eight_loopback_shards():
+    """bench.py --single-process --gpus 8 over the device list [0] * 8 (ilqg_multi_*: eight shards, offsets, per-shard
+    contexts, the cost hand-over) emits the line"""
+    out = _run_bench(["--single-process", "--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--batch", "256", "--steps", "3", "--warmup", "1"])
+    assert out["n_gpus"] == 8 and out["value"] > 0 and out["config"]["devices"] == [0] * 8
+    assert abs(out["value"] - 8 * out["per_gpu_iterations_per_s"]) < 1e-9 * out["value"]
+    assert out["trajectories_still_active"] == 8 * 256

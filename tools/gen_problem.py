@@ -1117,6 +1117,10 @@ def _emit_step_parts(self):
     multipliers (their auxiliaries take the multipliers and penalty weights as inputs)."""
     if self.plain or self.mu_c or not self.p.f:
         return ""
+    # a back-end hands clampU() nothing but x (no element with evaluated auxiliaries): limits written with an auxiliary
+    # would read beyond it
+    if any(sp.sympify(c["limit"]).free_symbols & set(self.D.defs) for c in self.cons):
+        return ""
     n = self.n
     L = self.csub(self.p.L, None)
     terms = _printer._as_ordered_terms(L, order=None) if L.is_Add else [L]

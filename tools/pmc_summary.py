@@ -3,6 +3,16 @@
 usage: python tools/pmc_summary.py gpurun_out/pmc_dir [more dirs...]"""
 import csv, glob, os, sys, collections
 
+def source_sha():
+    """digest of the kernel sources the counters were collected on (ddp-generator_amd/evidence.py)"""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("ilqg_evidence", os.path.join(here, "..", "ddp-generator_amd", "evidence.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.source_sha()
+
+
 def load(d):
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
@@ -56,7 +66,9 @@ def main():
         for (k, g), cs in sorted(acc.items()):
             if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs or "k_rollout<1>" in k:  # (<1>: the initial roll-out, not part of an iteration)
                 continue
-            if not any(x in k for x in ("k_rollout", "k_backward", "k_derivs")):
+            # every kernel an iteration dispatches (derivatives, backward, roll-outs, selection, adoption of the kept
+            # roll-outs, update); not the set-up of a solve: layout kernels, reset, runtime fills / copies
+            if not any(x in k for x in ("k_rollout", "k_backward", "k_derivs", "k_adopt", "k_select", "k_update", "k_search", "k_commit", "k_multipliers")):
                 continue
             f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
             w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
@@ -66,7 +78,9 @@ def main():
                                           "fetch_size_KiB_raw": f, "write_size_KiB_raw": w}
             total += per_launch * per_iter
         out["iteration"] = {"hbm_bytes": total, "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), both KiB -> bytes",
-                            "iterations_profiled": config5_iters}
+                            "iterations_profiled": config5_iters,
+                            "kernels_included": "every dispatch of k_derivs*, k_backward*, k_rollout* (but the initial roll-out), k_search*, k_select, k_adopt*, k_commit, k_update, k_multipliers"}
+        out["_source_sha"] = source_sha()
         json.dump(out, open(config5_json, "w"), indent=1, sort_keys=True)
         print("wrote", config5_json)
 
@@ -101,6 +115,7 @@ def main():
             out[label] = {"fetch_size_KiB_raw": f, "write_size_KiB_raw": w, "launches": len(cs["FETCH_SIZE"]),
                           "hbm_bytes_per_launch": 2.0 * f * 1024 + w * 1024,
                           "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), both KiB -> bytes"}
+        out["_source_sha"] = source_sha()
         json.dump(out, open(traffic_json, "w"), indent=1, sort_keys=True)
         print("wrote", traffic_json)
 

@@ -45,7 +45,7 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_ACTIVE_IN
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/sq_synth/$n -- python3 $R/bench.py --workload synth --steps 1 --warmup 0 --no-cpu-baseline --no-unfused > $OUT/sq_synth_$n.log 2>&1 || echo "sq $n failed"
 done
 cd $R
-python3 tools/pmc_kernels.py $OUT/sq_synth > $OUT/pmc_config5_sq.txt
+python3 tools/pmc_kernels.py --issue-json $OUT/issue_config5.json 1000 $OUT/sq_synth > $OUT/pmc_config5_sq.txt
 cat $OUT/pmc_config5_sq.txt | cut -c1-400
 echo "== SQ counters, headline"
 cd /tmp
@@ -54,7 +54,7 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_ACTIVE_IN
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/sq_car/$n -- python3 $R/bench.py --steps 10 --warmup 0 --no-cpu-baseline --no-unfused > $OUT/sq_car_$n.log 2>&1 || echo "sq car $n failed"
 done
 cd $R
-python3 tools/pmc_kernels.py $OUT/sq_car > $OUT/pmc_headline_sq.txt
+python3 tools/pmc_kernels.py --issue-json $OUT/issue.json 500 $OUT/sq_car > $OUT/pmc_headline_sq.txt
 grep "k_backward\|k_rollout" $OUT/pmc_headline_sq.txt | cut -c1-400
 echo "== accepted step sizes"
 python3 tools/alpha_hist.py carparking > $OUT/alpha_hist_car.txt 2>&1
