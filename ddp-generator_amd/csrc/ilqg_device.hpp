@@ -27,7 +27,9 @@ __device__ unsigned long long ilqg_prof_cycles[8];  // summed over wavefronts: s
 #endif
 struct Prof {
     long long last, acc[8];
+    long long wave_steps;  // quad mapping: steps of the wavefront
     ILQG_DEV void start() {
+        wave_steps = 0;
         for(int i = 0; i < 8; i++) acc[i] = 0;
         last = __builtin_readcyclecounter();
     }

@@ -243,6 +243,7 @@ extern "C" {
 #include "ilqg_device.hpp"
 #include "ilqg_wave.hpp"
 #include "ilqg_row.hpp"
+#include "ilqg_quad.hpp"
 #include "ilqg_shim.h"
 
 namespace {
@@ -1687,6 +1688,189 @@ void k_backward_wave(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_f
         if(bw >= chunk_count || chunk_first + bw >= P.B) break;
         backward_of_trajectory<FACT>(S, wave_lds, P, O, single_sweep, chunk_first + bw, bw);
         wave_sync();  // the LDS block goes to the next trajectory
+    }
+}
+// ---------------------------------------------------------------------------
+// Quad mapping (ilqg_quad.hpp): 16 lanes per trajectory, four trajectories per wavefront, each 16-lane row a worker of its
+// own — it takes the next trajectory of the piece from the queue, walks its sweeps (lambda retries included) at its own
+// pace and goes back to the queue.  Nothing in a step depends on the other rows of the wavefront but the instruction
+// stream, so there is no hand-over and no waiting between trajectories; a row without work computes along on a valid
+// record and commits nothing.  Used where the records are small (factored tensors, or no tensors), the limits do not
+// depend on the state and regType is 1; the row mapping above takes the rest.
+// ---------------------------------------------------------------------------
+constexpr bool QUAD_STEP = ROW_STEP && !HX && (FACTORED || !FULL) && NU <= NX;
+#ifndef ILQG_QUAD_WAVES  // wavefronts per workgroup (one workgroup per CU: the coefficient tables are shared)
+#define ILQG_QUAD_WAVES 4
+#endif
+constexpr int QUAD_WAVES = ILQG_QUAD_WAVES;
+using QRow = QuadRow<(QUAD_STEP ? NX : 1), (QUAD_STEP ? NU : 1)>;
+struct QuadTab {
+    static constexpr int NBASIS = ::NBASIS > 0 ? ::NBASIS : 1;
+#if ILQG_FACTORED
+    static constexpr int SLICE = FACT_SLICE;
+    static __device__ __forceinline__ int slice_xx(int i) { return ilqg_tensor_slice_xx[i]; }
+    static __device__ __forceinline__ int slice_uu(int i) { return ilqg_tensor_slice_uu[i]; }
+    static __device__ __forceinline__ int slice_xu(int i) { return ilqg_tensor_slice_xu[i]; }
+#else
+    static constexpr int SLICE = 1;
+    static __device__ __forceinline__ int slice_xx(int) { return 0; }
+    static __device__ __forceinline__ int slice_uu(int) { return 0; }
+    static __device__ __forceinline__ int slice_xu(int) { return 0; }
+#endif
+};
+
+template <bool FACT>
+__global__ __launch_bounds__(64 * QUAD_WAVES) void k_backward_quad(DevPtrs P, ilqg_dev_opts_t O, int single_sweep, int chunk_first, int chunk_count) {
+    extern __shared__ double quad_lds[];  // [coefficient tables][per wavefront: four QuadRow blocks]
+    if constexpr(QUAD_STEP) {
+#if ILQG_FACTORED
+        if(FACT) {
+            for(int i = threadIdx.x; i < NX * SXX; i += 64 * QUAD_WAVES) quad_lds[i / SXX * FACT_SLICE + i % SXX] = ilqg_tensor_coef_xx[i];
+            for(int i = threadIdx.x; i < NX * SUU; i += 64 * QUAD_WAVES) quad_lds[i / SUU * FACT_SLICE + SXX + i % SUU] = ilqg_tensor_coef_uu[i];
+            for(int i = threadIdx.x; i < NX * NXU; i += 64 * QUAD_WAVES) quad_lds[i / NXU * FACT_SLICE + SXX + SUU + i % NXU] = ilqg_tensor_coef_xu[i];
+            __syncthreads();  // the only meeting of the workgroup's wavefronts
+        }
+#endif
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+        const int cx_ = (c < NX) ? c : 0;
+        const int N = P.N;
+        const unsigned table = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(quad_lds));
+        const unsigned rb = (unsigned)lds_addr(quad_lds + (FACT ? TABLE_DOUBLES : 0) + (wave * 4 + g) * QRow::SIZE);
+        // state of this row's trajectory (the same in its 16 lanes)
+        bool busy = false, start = false, drained = false;
+        int b = 0, bw = 0, k = 0, calls = 0;
+        double lambda = 1.0, dlambda = 1.0, dV0 = 0.0, dV1 = 0.0, gsum = 0.0, g_norm = 0.0;
+        double vx = 0.0, vxx[NX], lcur = 0.0;
+#pragma unroll
+        for(int r = 0; r < NX; r++) vxx[r] = 0.0;
+
+#ifdef ILQG_PROFILE_SECTIONS
+        Prof prof;
+        prof.start();
+        Prof *pf = &prof;
+#else
+        Prof *pf = nullptr;
+#endif
+        for(;;) {
+            if(pf) pf->probe(7);
+            // ---- rows without a trajectory take the next ones of the piece: one atomic per wavefront and round
+            while(any_lane(!busy && !drained)) {
+                const bool want = !busy && !drained;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(want && c == 0);
+                const int first = __builtin_ctzll(m);
+                int base = 0;
+                if(lane == first) base = atomicAdd(P.queue, __builtin_popcountll(m));
+                base = __shfl(base, first);
+                int mine = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));  // (the row's first lane)
+                mine = __shfl(mine, lane & 48);
+                if(want) {
+                    if(mine >= chunk_count || chunk_first + mine >= P.B) {
+                        drained = true;
+                    } else {
+                        bw = mine;
+                        b = chunk_first + mine;
+                        if(P.i[ILQG_I_STATUS][b] == ILQG_ST_ACTIVE) {
+                            if(P.derivs_failed[b]) {
+                                if(c == 0) {
+                                    P.i[ILQG_I_NEED_DERIVS][b] = 0;
+                                    P.i[ILQG_I_STATUS][b] = ILQG_ST_DERIVS_FAILED;
+                                }
+                            } else {
+                                lambda = P.f[ILQG_F_LAMBDA][b];
+                                dlambda = P.f[ILQG_F_DLAMBDA][b];
+                                g_norm = P.f[ILQG_F_GNORM][b];
+                                dV0 = dV1 = 0.0;
+                                calls = 0;
+                                busy = start = true;
+                            }
+                        }
+                    }
+                }
+            }
+            if(!any_lane(busy)) break;  // every row is out of work and the queue is used up
+#ifdef ILQG_PROFILE_SECTIONS
+            prof.wave_steps++;
+#endif
+            // ---- a sweep begins: the value function behind the last step (the final cost's), back_pass.c:60-67
+            if(any_lane(start)) {
+                if(start) {
+                    const double *fin = P.f[ILQG_F_FIN] + (size_t)b * FIN;
+                    vx = fin[cx_];
+#pragma unroll
+                    for(int r = 0; r < NX; r++) vxx[r] = fin[NX + ((r <= cx_) ? ut(r, cx_) : ut(cx_, r))];
+                    lcur = 0.0;  // warm start of the last step (back_pass.c:163-164)
+                    dV0 = dV1 = gsum = 0.0;
+                    k = N - 1;
+                    start = false;
+                }
+            }
+            // ---- one step of every busy row
+            const int kk = busy ? k : 0, bb = busy ? b : ((chunk_first < P.B) ? chunk_first : 0), ww = busy ? bw : 0;
+            const char *rec = reinterpret_cast<const char *>(work_rec(P, ww, kk));
+            double *nom = nomp(P, kk, bb);
+            const int rc = back_step_quad<NX, NU, FULL, FACT, RecOffsets, QuadTab>(rb, table, rec, nom + NOM_U, nom + NOM_L, nom + NOM_K, busy, vx, vxx,
+                                                                                  lcur, lambda, dV0, dV1, gsum, pf);
+#ifdef ILQG_PROFILE_SECTIONS
+            prof.acc[7] = 0;  // (queue, sweep starts, row transitions: not charged to a section)
+#endif
+            // ---- what the row does next
+            if(busy) {
+                bool done = false;
+                int bp_rc = 0;
+                if(rc < 1) {  // the sweep is abandoned (back_pass.c:168-171): raise lambda and sweep again (iLQG.c:267-275)
+                    calls++;
+                    bp_rc = 1;
+                    done = true;
+                    if(!single_sweep) {
+                        const double t1 = dlambda * O.lambdaFactor;
+                        dlambda = (t1 > O.lambdaFactor) ? t1 : O.lambdaFactor;
+                        const double t2 = lambda * dlambda;
+                        lambda = (t2 > O.lambdaMin) ? t2 : O.lambdaMin;
+                        if(!(lambda > O.lambdaMax)) {
+                            done = false;
+                            start = true;
+                        }
+                    }
+                } else if(k == 0) {
+                    calls++;
+                    g_norm = gsum / ((double)(N - 1));  // N summands over N-1 (back_pass.c:254)
+                    done = true;
+                } else {
+                    k--;
+                }
+                if(done) {
+                    int status = ILQG_ST_ACTIVE;
+                    if(!single_sweep) {
+                        if(bp_rc) {
+                            status = ILQG_ST_NO_DESCENT;
+                        } else if(g_norm < O.tolGrad && lambda < 1e-5) {  // iLQG.c:297-303
+                            const double t1 = dlambda / O.lambdaFactor, t2 = 1.0 / O.lambdaFactor;
+                            dlambda = (t1 < t2) ? t1 : t2;
+                            lambda = lambda * dlambda * (lambda > O.lambdaMin);
+                            status = ILQG_ST_CONVERGED_GRAD;
+                        }
+                    }
+                    if(c == 0) {
+                        P.i[ILQG_I_NEED_DERIVS][b] = 0;
+                        P.i[ILQG_I_STATUS][b] = status;
+                        P.f[ILQG_F_LAMBDA][b] = lambda;
+                        P.f[ILQG_F_DLAMBDA][b] = dlambda;
+                        P.f[ILQG_F_DV0][b] = dV0;
+                        P.f[ILQG_F_DV1][b] = dV1;
+                        P.f[ILQG_F_GNORM][b] = g_norm;
+                        P.i[ILQG_I_BP_CALLS][b] = calls;
+                        P.i[ILQG_I_BP_RC][b] = bp_rc;
+                    }
+                    busy = false;
+                }
+            }
+        }
+#ifdef ILQG_PROFILE_SECTIONS
+        if(lane == 0) {
+            for(int i = 0; i < 7; i++) atomicAdd(&ilqg_prof_cycles[i], (unsigned long long)prof.acc[i]);
+            atomicAdd(&ilqg_prof_cycles[7], (unsigned long long)prof.wave_steps);  // steps of the wavefront (1 to 4 rows busy)
+        }
+#endif
     }
 }
 #endif  // ILQG_WAVE_MAP
@@ -3482,6 +3666,13 @@ static int dev_fill(ilqg_dev *d, int device, int batch, int n_hor) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_backward_wave<FACTORED>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
+    if(QUAD_STEP) {
+        const int lds = (int)((TABLE_DOUBLES + QUAD_WAVES * 4 * QRow::SIZE) * sizeof(double));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_backward_quad<FACTORED>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_backward_quad<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
 #endif
     d->chunk = 0;
     d->own_chunk = 0;
@@ -4059,7 +4250,12 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
     // the derivatives of one chunk are evaluated while the other's backward pass runs and the end of one backward
     // kernel (few wavefronts still busy) is filled by the next.  The pieces are of equal size.
     // (a batch that fits as a whole goes in two pieces as well, if it is large enough to fill the chip twice)
-    const bool split = transient && chunk >= 2 && (d->B > chunk || d->B >= 16 * d->cus);
+    // (Quad mapping: a batch whose records fit goes as ONE piece.  Its rows are workers that take trajectories from a queue,
+    // four to a wavefront: the more trajectories a queue holds per worker, the less the workers' last ones — 1 to 4 sweeps
+    // each — stick out at the end; measured, config 5: 197.8 ms per iteration in two pieces, 181.6 in one.
+    // ILQG_TWO_PIECES=1 restores the halves.)
+    const bool quad_here = QUAD_STEP && d->O.regType == 1 && (fact || !FULL) && !getenv("ILQG_NO_QUAD");
+    const bool split = transient && chunk >= 2 && (d->B > chunk || (d->B >= 16 * d->cus && (!quad_here || getenv("ILQG_TWO_PIECES"))));
     const int half_cap = split ? chunk / 2 : chunk;              // trajectories a half of the buffer holds
     const int pieces = (d->B + half_cap - 1) / half_cap;
     int part = chunk;
@@ -4114,7 +4310,19 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
         if(do_backward) {
             HIP_TRY(hipMemsetAsync(P.queue, 0, sizeof(int), st));
             Timed t(d, ILQG_K_BACKWARD, st);
-            if(fact) {
+            // quad mapping (16 lanes per trajectory) where it applies; ILQG_NO_QUAD=1: the row mapping (comparison)
+            const bool quad = quad_here;
+            if(quad) {
+                const size_t lds = (size_t)((fact ? TABLE_DOUBLES : 0) + QUAD_WAVES * 4 * QRow::SIZE) * sizeof(double);
+                const int per_wg = 4 * QUAD_WAVES;
+                const int wgs = (cnt + per_wg - 1) / per_wg;  // one workgroup per CU at a time
+                if(fact)
+                    hipLaunchKernelGGL(k_backward_quad<FACTORED>, dim3(wgs < d->cus ? wgs : d->cus), dim3(64 * QUAD_WAVES), lds, st, P, d->O,
+                                       single_sweep, c0, cnt);
+                else
+                    hipLaunchKernelGGL(k_backward_quad<false>, dim3(wgs < d->cus ? wgs : d->cus), dim3(64 * QUAD_WAVES), lds, st, P, d->O,
+                                       single_sweep, c0, cnt);
+            } else if(fact) {
                 constexpr int WV = ILQG_FACT_WAVES;
                 const size_t lds = (size_t)(TABLE_DOUBLES + WV * WAVE_LDS_DOUBLES) * sizeof(double);
                 const int wgs = (cnt + WV - 1) / WV;  // one workgroup per CU at a time (LDS)

@@ -735,6 +735,46 @@ def test_wave_mapping_synthetic_golden(ilqg, fd, variant):
     s.close()
 
 
+@pytest.mark.parametrize("fd", [0, 1])
+@pytest.mark.parametrize("strict", [True, False])
+def test_quad_mapping_equals_the_row_mapping(ilqg, monkeypatch, fd, strict):
+    """The backward pass with 16 lanes per trajectory (ilqg_quad.hpp: four trajectories per wavefront, every 16-lane row
+    at its own step, sweep and lambda) against the one-wavefront-per-trajectory row mapping (ILQG_NO_QUAD=1) on a ragged
+    batch whose trajectories need different numbers of sweeps: gains, value changes, gradient norms, lambdas, sweep counts
+    and the solves that follow — the same bits in the FMA-free build, to rounding in the product build"""
+    B, N, K = 37, 300, 4
+    x0, u0 = syn_inputs(B, N, first=7)
+    x0 = x0 * np.linspace(0.2, 3.0, B)[:, None]  # spread: some starts need lambda retries, some none
+
+    def run():
+        # (a small initial lambda: the first sweeps of some trajectories meet an indefinite Quu and are abandoned)
+        s = ilqg.BatchSolver("synth16x8", fd, batch=B, n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=K + 1, lambdaInit=1e-7), strict=strict)
+        s.init(x0, u0)
+        out = []
+        for it in range(K):
+            s.back_pass(fused=True)
+            l, L = s.gains()
+            out.append(dict(l=l.copy(), L=L.copy(), dV0=s.scalar("dV0").copy(), dV1=s.scalar("dV1").copy(), g=s.scalar("g_norm").copy(),
+                            lam=s.scalar("lambda").copy(), calls=s.ints("bp_calls").copy(), rc=s.ints("bp_rc").copy()))
+            s.line_search()
+            s.update()
+        out.append(dict(cost=s.scalar("cost").copy(), x=s.x().copy()))
+        s.close()
+        return out
+
+    quad = run()
+    monkeypatch.setenv("ILQG_NO_QUAD", "1")
+    row = run()
+    calls = np.concatenate([o["calls"] for o in quad[:-1]])
+    assert calls.min() == 1 and (fd == 0 or calls.max() > 1), np.bincount(calls)
+    for a, b in zip(quad, row):
+        for k in a:
+            if strict or k in ("calls", "rc"):
+                assert np.array_equal(a[k], b[k]), k
+            else:
+                assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-12), (k, np.abs(a[k] - b[k]).max())
+
+
 @pytest.mark.parametrize("log2_scale", [-240, -120, 0, 120, 240])
 def test_wave_mapping_step_with_scaled_costs(ilqg, oracle_built, log2_scale):
     """The row-mapped backward step takes short forms of sqrt / reciprocal / quotient in its box QP while the pivots lie
