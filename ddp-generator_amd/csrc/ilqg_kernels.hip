@@ -204,6 +204,27 @@ __device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_call(doub
 #endif
 #endif
 
+// sin and cos of one argument at once for the derivative record in parts (ilqg_deriv_prepare)
+#ifndef ILQG_NO_SHARED_SINCOS
+// (straight-line form with the hooks, see ilqg_sincos_hooked: a call to the library on the spot would make every value
+// alive at that point travel through scratch memory around it — 32 call sites in ilqg_deriv_prepare)
+#define ILQG_DERIV_SINCOS(ARG_, SIN_, COS_)               \
+    do {                                                  \
+        const ilqg_sc r_ = ilqg_sincos_hooked(p, (ARG_)); \
+        (SIN_) = r_.s;                                    \
+        (COS_) = r_.c;                                    \
+    } while(0)
+#endif
+
+// Both functions of the derivative record in parts are inlined (what they hand over stays in registers), and every part
+// begins with a statement the optimiser must take as having an effect: a switch over 30 cheap side-effect-free cases is
+// otherwise flattened into selects — every part evaluated in every trip, every part's literals alive at once (measured:
+// 512 registers, 430 spilled).  (Called instead of inlined, a part's inputs and outputs travel through the caller's frame
+// in scratch memory: 17 KB per step for a 4 KB record, 68 ms per iteration against 44 for k_derivs_wave.)
+#define ILQG_DERIV_PREPARE_FN static __attribute__((always_inline))
+#define ILQG_DERIV_PART_FN static __attribute__((always_inline))
+#define ILQG_DERIV_CASE(q) asm volatile("" ::: "memory");
+
 // The parts of a roll-out step belong INTO the kernel: as a called function they get x and u through scratch memory.
 // (The kernel has two instantiations; with two callers the inliner leaves a function of this size alone.)
 #define ILQG_PART_FN static __attribute__((always_inline))
@@ -1325,10 +1346,11 @@ __device__ __forceinline__ trajEl_t *work_rec(const DevPtrs &P, int bw, int k) {
 #define ILQG_DERIVS_ATTR
 #endif
 __global__ __launch_bounds__(ILQG_DERIVS_BLOCK) ILQG_DERIVS_ATTR void k_derivs_wave(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first,
-                                                    int chunk_count, int init_consts, int factored, int limit_gradients) {
+                                                    int chunk_count, int init_consts, int factored, int limit_gradients, int final_only) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int bw = (int)(tid / (P.N + 1));
-    const int k = (int)(tid % (P.N + 1));
+    // (final_only: lane = trajectory, the final record alone — the steps' records come from k_derivs_parts)
+    const int bw = final_only ? (int)tid : (int)(tid / (P.N + 1));
+    const int k = final_only ? P.N : (int)(tid % (P.N + 1));
     const int b = chunk_first + bw;
     if(bw >= chunk_count || b >= P.B) return;
     ILQG_CALLBACKS(C, H);
@@ -1415,6 +1437,111 @@ __global__ __launch_bounds__(ILQG_DERIVS_BLOCK) ILQG_DERIVS_ATTR void k_derivs_w
     }
     if(!ok || H.nonfinite != 0.0) P.derivs_failed[b] = 1;
 }
+
+// ---------------------------------------------------------------------------
+// The time-varying part of the factored derivative records, assembled ON CHIP and written as whole cache lines (round 4).
+// k_derivs_wave runs the generated scalar code on a struct per lane in HBM: every store instruction touches 64 records,
+// the kernel spends most of its time waiting for stores (SQ_WAIT_ANY / SQ_WAVE_CYCLES 0.55, 116 GB written for 72 GB of
+// payload) and evaluates the 64 sin / cos of a step twice (bp_derivsL_first, bp_tensor_basis).  Here a lane still owns a
+// (trajectory, step), but the generated file offers the record's entries in PARTS of 16 outputs (tools/gen_problem.py
+// _emit_deriv_parts: the expressions of bp_derivsL_first, bp_tensor_basis and limitsU as the same printer prints them;
+// ilqg_deriv_prepare evaluates the auxiliaries, every sin / cos ONCE and the products made of them): a part's outputs go into a tile in LDS,
+// [lane][16], and come out of it turned round — 16 consecutive lanes store the 16 outputs of ONE record: a whole line
+// wherever the outputs are neighbours in the record (fx and fu column by column, cx, cu, the products, the limits).
+// The constant entries of the records are written once per buffer by k_derivs_wave as before, the final record too.
+//
+// MEASURED (round 4, config 5): 51.3 ms per iteration against 43.8 for k_derivs_wave — a negative result so far, and why:
+// the parts' arithmetic is a few thousand 64-bit literals.  As ONE block (parts unrolled) they are all materialised ahead
+// (788 scalar registers spilled through vector lanes, 447 vector registers spilled); as a loop over a switch the
+// optimiser first flattens the cheap side-effect-free cases into selects, then — with a statement at the head of every
+// case that stops that — hoists the loop-invariant arithmetic of all 30 parts in front of the loop, then — with the inputs
+// laundered in every trip — still holds ilqg_deriv_prepare's 32 auxiliaries + 64 sin / cos values + 64 products at
+// once whatever order the generator prints them in: 360 vector registers spilled, 1.5 KB of scratch per lane, whose
+// traffic is what the coalesced record stores had saved.  Called instead of inlined, a part's inputs and outputs travel
+// through the caller's frame (68 ms).  What it would take: the auxiliaries and their products in a kernel of their own
+// (lane = (step, auxiliary pair)) handing 64 + 32 doubles per step over in HBM or LDS.  The kernel is kept, tested
+// (test_derivative_records_in_parts_equal_the_per_lane_ones) and off by default (ILQG_DERIV_PARTS=1 turns it on).
+// ---------------------------------------------------------------------------
+#if ILQG_FACTORED && defined(ILQG_DERIV_PARTS) && !defined(ILQG_NO_SHARED_SINCOS)
+#define ILQG_HAVE_DERIV_PARTS 1
+constexpr int DP_OUT = ILQG_DERIV_PART_OUT, DP_PARTS = ILQG_DERIV_PARTS, DP_NOUT = ILQG_DERIV_NOUT, DP_NPROD = ILQG_DERIV_NPROD;
+static_assert(DP_OUT == 16, "a part's outputs are stored by the 16 lanes of a DPP row");
+#define ILQG_OUT_OFFSET(member, index) (unsigned)(offsetof(trajEl_t, member) + (index) * sizeof(double)),
+__device__ const unsigned deriv_out_offset[DP_PARTS * DP_OUT] = {ILQG_DERIV_OUTPUTS(ILQG_OUT_OFFSET)};
+#undef ILQG_OUT_OFFSET
+constexpr int DP_WAVES = 4;
+
+__global__ __launch_bounds__(64 * DP_WAVES) void k_derivs_parts(DevPtrs P, ilqg_dev_opts_t O, ParamValues A, int chunk_first, int chunk_count) {
+    __shared__ double tile[DP_WAVES][WAVE][DP_OUT + 1];  // (+1: the lanes' rows start on different banks)
+    __shared__ unsigned long long recs[DP_WAVES][WAVE];  // the records of the wavefront's lanes (0: not to be written)
+    __shared__ unsigned offs[DP_PARTS * DP_OUT];         // byte offset of every output in a record
+    for(int i = threadIdx.x; i < DP_PARTS * DP_OUT; i += 64 * DP_WAVES) offs[i] = deriv_out_offset[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int bw = (int)(tid / P.N), k = (int)(tid % P.N);
+    const int b = chunk_first + bw;
+    const bool live = bw < chunk_count && b < P.B && P.i[ILQG_I_STATUS][(b < P.B) ? b : 0] == ILQG_ST_ACTIVE;
+    if(__builtin_amdgcn_ballot_w64(live) == 0ull) return;
+    ILQG_CALLBACKS(C, H);
+    const double *nom = nomp(P, k, live ? b : chunk_first);
+    double x[NX], u[NU];
+#pragma unroll
+    for(int i = 0; i < NX; i++) x[i] = nom[NOM_X + i];
+#pragma unroll
+    for(int i = 0; i < NU; i++) u[i] = nom[NOM_U + i];
+    ilqg_deriv_aux_t aux;
+    double prod[DP_NPROD], basis[NBASIS];
+    int bad = 0;
+    H.huge = 0.0;
+    ilqg_deriv_prepare(&aux, prod, basis, &bad, x, u, k, C.o.p, P.N);
+    if(H.huge != 0.0) {  // an argument beyond the fast sin / cos reduction: once more through the library
+        H.slow = 1.0;
+        bad = 0;
+        ilqg_deriv_prepare(&aux, prod, basis, &bad, x, u, k, C.o.p, P.N);
+        H.slow = 0.0;
+    }
+    recs[wave][lane] = live ? (unsigned long long)work_rec(P, bw, k) : 0ull;
+    const int pr0 = lane >> 4, j = lane & 15;
+    // (a LOOP over the parts, not unrolled: the parts' hundreds of 64-bit literals stay with their case of the switch; laid out
+    // as one block they are all materialised ahead — 788 scalar registers spilled through vector lanes)
+    const int nparts = DP_PARTS;
+#pragma unroll 1
+    for(int q = 0; q < nparts; q++) {
+        // (every part's arithmetic is loop invariant — it depends on the step, not on q — and would be hoisted in front of
+        // the loop, all 472 outputs at once; its inputs pass through a statement the optimiser cannot see through)
+#pragma unroll
+        for(int i = 0; i < NX; i++) asm volatile("" : "+v"(x[i]));
+#pragma unroll
+        for(int i = 0; i < NU; i++) asm volatile("" : "+v"(u[i]));
+#pragma unroll
+        for(int i = 0; i < DP_NPROD; i++) asm volatile("" : "+v"(prod[i]));
+#pragma unroll
+        for(int i = 0; i < NBASIS; i++) asm volatile("" : "+v"(basis[i]));
+        double out[DP_OUT];
+#pragma unroll
+        for(int i = 0; i < DP_OUT; i++) out[i] = 0.0;
+        ilqg_deriv_part(q, out, &bad, &aux, prod, basis, x, u, k, C.o.p, P.N);
+
+#pragma unroll
+        for(int i = 0; i < DP_OUT; i++) tile[wave][lane][i] = out[i];
+        wave_sync();
+        if(q * DP_OUT + j < DP_NOUT) {
+            const unsigned off = offs[q * DP_OUT + j];
+#pragma unroll
+            for(int i = 0; i < WAVE / 4; i++) {
+                const int pr = 4 * i + pr0;
+                const unsigned long long base = recs[wave][pr];
+                if(base) *reinterpret_cast<double *>(base + off) = tile[wave][pr][j];
+            }
+        }
+        wave_sync();
+    }
+    if(live && bad) P.derivs_failed[b] = 1;
+}
+#else
+#define ILQG_HAVE_DERIV_PARTS 0
+#endif
 
 using StepLds = std::conditional_t<ROW_STEP, RowLds<(ROW_STEP ? NX : 1), (ROW_STEP ? NU : 1)>, WaveLds<NX, NU>>;
 
@@ -4300,8 +4427,17 @@ static int wave_backward(ilqg_dev_t *d, int single_sweep, int do_derivs, int do_
             const bool have_consts = *whole || (split && half[h]);
             // (transient records are read by the backward pass alone: the limits' signs and gradients, which it does not
             // use unless the limits depend on the state, are left out of them)
+#if ILQG_HAVE_DERIV_PARTS
+            // records of the steps assembled on chip, whole lines out (k_derivs_parts) once the buffer holds the constant
+            // entries.  MEASURED SLOWER than the generated code on a struct per lane (51 against 44 ms per iteration of
+            // config 5, see the kernel): off unless ILQG_DERIV_PARTS=1
+            if(fact && transient && have_consts && getenv("ILQG_DERIV_PARTS")) {
+                hipLaunchKernelGGL(k_derivs_parts, grid1((size_t)cnt * d->N, 64 * DP_WAVES), dim3(64 * DP_WAVES), 0, st, P, d->O, d->pv, c0, cnt);
+                hipLaunchKernelGGL(k_derivs_wave, grid1((size_t)cnt, ILQG_DERIVS_BLOCK), dim3(ILQG_DERIVS_BLOCK), 0, st, P, d->O, d->pv, c0, cnt, 0, 1, 0, 1);
+            } else
+#endif
             hipLaunchKernelGGL(k_derivs_wave, grid1(total, ILQG_DERIVS_BLOCK), dim3(ILQG_DERIVS_BLOCK), 0, st, P, d->O, d->pv, c0, cnt, have_consts ? 0 : 1,
-                               fact ? 1 : 0, (transient && !HX) ? 0 : 1);
+                               fact ? 1 : 0, (transient && !HX) ? 0 : 1, 0);
             if(cnt == part) {  // every element of this (half of the) buffer that is ever used has its constants now
                 if(split) half[h] = true;
                 else *whole = half[0] = half[1] = true;

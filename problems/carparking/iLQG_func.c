@@ -614,26 +614,26 @@ ILQG_PART_FN void ilqg_step_part(int part, double x_next[], double term[], int b
     switch(part) {
     case 0:
         aux_s= p[3][0] + p[4][0]*x[3]*ILQG_PART_COS(u[0]) - sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(ILQG_PART_SIN(u[0])*ILQG_PART_SIN(u[0])));
-        if(!((aux_s) - (aux_s) == 0.0)) bad[0]= 1;
+        if(!(fabs(aux_s) <= 1.7976931348623157e308)) bad[0]= 1;
         x_next[0]= aux_s*ILQG_PART_COS(x[2]) + x[0];
-        if(!((x_next[0]) - (x_next[0]) == 0.0)) bad[0]= 1;
+        if(!(fabs(x_next[0]) <= 1.7976931348623157e308)) bad[0]= 1;
         term[0]= p[1][0]*(u[0]*u[0]);
         break;
     case 1:
         aux_s= p[3][0] + p[4][0]*x[3]*ILQG_PART_COS(u[0]) - sqrt((p[3][0]*p[3][0]) - (p[4][0]*p[4][0])*(x[3]*x[3])*(ILQG_PART_SIN(u[0])*ILQG_PART_SIN(u[0])));
-        if(!((aux_s) - (aux_s) == 0.0)) bad[0]= 1;
+        if(!(fabs(aux_s) <= 1.7976931348623157e308)) bad[0]= 1;
         x_next[1]= aux_s*ILQG_PART_SIN(x[2]) + x[1];
-        if(!((x_next[1]) - (x_next[1]) == 0.0)) bad[0]= 1;
+        if(!(fabs(x_next[1]) <= 1.7976931348623157e308)) bad[0]= 1;
         term[1]= p[1][1]*(u[1]*u[1]);
         break;
     case 2:
         x_next[2]= x[2] + asin(p[4][0]*x[3]*ILQG_PART_SIN(u[0])/p[3][0]);
-        if(!((x_next[2]) - (x_next[2]) == 0.0)) bad[0]= 1;
+        if(!(fabs(x_next[2]) <= 1.7976931348623157e308)) bad[0]= 1;
         term[2]= p[2][0]*(-p[8][0] + sqrt((p[8][0]*p[8][0]) + (x[0]*x[0])));
         break;
     case 3:
         x_next[3]= p[4][0]*u[1] + x[3];
-        if(!((x_next[3]) - (x_next[3]) == 0.0)) bad[0]= 1;
+        if(!(fabs(x_next[3]) <= 1.7976931348623157e308)) bad[0]= 1;
         term[3]= p[2][1]*(-p[8][1] + sqrt((p[8][1]*p[8][1]) + (x[1]*x[1])));
         break;
     default: break;

@@ -506,23 +506,23 @@ ILQG_PART_FN void ilqg_step_part(int part, double x_next[], double term[], int b
     switch(part) {
     case 0:
         aux_e= exp(-1.0/4.0*(x[2]*x[2]))*ILQG_PART_SIN(x[0]);
-        if(!((aux_e) - (aux_e) == 0.0)) bad[0]= 1;
+        if(!(fabs(aux_e) <= 1.7976931348623157e308)) bad[0]= 1;
         x_next[0]= p[3][0]*x[1] + x[0];
-        if(!((x_next[0]) - (x_next[0]) == 0.0)) bad[0]= 1;
+        if(!(fabs(x_next[0]) <= 1.7976931348623157e308)) bad[0]= 1;
         term[0]= (1.0/10.0)*(aux_e*aux_e);
         term[3]= p[2][0]*(sqrt((x[0]*x[0]) + 1.0) - 1.0);
         break;
     case 1:
         aux_e= exp(-1.0/4.0*(x[2]*x[2]))*ILQG_PART_SIN(x[0]);
-        if(!((aux_e) - (aux_e) == 0.0)) bad[0]= 1;
+        if(!(fabs(aux_e) <= 1.7976931348623157e308)) bad[0]= 1;
         x_next[1]= p[3][0]*(-aux_e*p[4][3] + u[0]) + x[1];
-        if(!((x_next[1]) - (x_next[1]) == 0.0)) bad[0]= 1;
+        if(!(fabs(x_next[1]) <= 1.7976931348623157e308)) bad[0]= 1;
         term[1]= p[1][0]*(u[0]*u[0]);
         term[4]= p[2][1]*(x[1]*x[1]);
         break;
     case 2:
         x_next[2]= p[3][0]*(u[1] + (1.0/4.0)*x[0]*x[1] - 1.0/2.0*x[2]) + x[2];
-        if(!((x_next[2]) - (x_next[2]) == 0.0)) bad[0]= 1;
+        if(!(fabs(x_next[2]) <= 1.7976931348623157e308)) bad[0]= 1;
         term[2]= p[1][1]*(u[1]*u[1]);
         term[5]= p[2][2]*(x[2]*x[2]);
         break;

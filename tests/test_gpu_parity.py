@@ -775,6 +775,39 @@ def test_quad_mapping_equals_the_row_mapping(ilqg, monkeypatch, fd, strict):
                 assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-12), (k, np.abs(a[k] - b[k]).max())
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_derivative_records_in_parts_equal_the_per_lane_ones(ilqg, monkeypatch, strict):
+    """k_derivs_parts (ILQG_DERIV_PARTS=1: the time-varying record entries from the generated file's PARTS — auxiliaries,
+    sin / cos once, products, 16 outputs at a time through an LDS tile, whole lines out) against k_derivs_wave (the
+    generated code on a struct per lane): the solves that consume the records — gains, value changes, accepted steps,
+    costs — the same bits in the FMA-free build, to rounding in the product build"""
+    B, N, K = 70, 200, 4
+    x0, u0 = syn_inputs(B, N, first=3)
+
+    def run():
+        s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=K + 1), strict=strict)
+        s.init(x0, u0)
+        out = []
+        for it in range(K):
+            s.iterate(1)
+            l, L = s.gains()
+            out.append(dict(l=l.copy(), L=L.copy(), dV0=s.scalar("dV0").copy(), g=s.scalar("g_norm").copy(), cost=s.scalar("cost").copy(),
+                            idx=s.ints("alpha_idx").copy(), status=s.ints("status").copy()))
+        s.close()
+        return out
+
+    plain = run()
+    monkeypatch.setenv("ILQG_DERIV_PARTS", "1")
+    parts = run()
+    assert all((o["status"] == 0).all() for o in parts)
+    for a, b in zip(plain, parts):
+        for k in a:
+            if strict or k in ("idx", "status"):
+                assert np.array_equal(a[k], b[k]), k
+            else:
+                assert np.allclose(a[k], b[k], rtol=1e-8, atol=1e-11), (k, np.abs(a[k] - b[k]).max())
+
+
 @pytest.mark.parametrize("log2_scale", [-240, -120, 0, 120, 240])
 def test_wave_mapping_step_with_scaled_costs(ilqg, oracle_built, log2_scale):
     """The row-mapped backward step takes short forms of sqrt / reciprocal / quotient in its box QP while the pivots lie

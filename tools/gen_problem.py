@@ -684,6 +684,7 @@ typedef struct {{
           "int calcG(double g[], trajEl_t *t, int k, double **p) { return 1; }\n")
         w(self.emit_factored_tensors())
         w(self.emit_step_parts())
+        w(self.emit_deriv_parts())
         return "".join(o)
 
     def emit_cost_and_dynamics(self):
@@ -1162,7 +1163,8 @@ def _emit_step_parts(self):
         return _re.sub(r"(?<![A-Za-z0-9_])cos\(", "ILQG_PART_COS(", text)
 
     def guarded(lhs, rhs):
-        return "        %s= %s;\n        if(!((%s) - (%s) == 0.0)) bad[0]= 1;\n" % (lhs, part_math(rhs), lhs, lhs)
+        # (not `v - v == 0`: where v is a product, FMA contraction turns v - v into the product's rounding error)
+        return "        %s= %s;\n        if(!(fabs(%s) <= 1.7976931348623157e308)) bad[0]= 1;\n" % (lhs, part_math(rhs), lhs)
 
     out = ("\n/* ---- additive: one step of forward_pass in ILQG_ROLLOUT_PARTS independent parts (batched back-ends that put\n"
            " * several wavefronts on a trajectory's step; the reference's solver never calls this).  Part r: component r of the\n"
@@ -1190,6 +1192,162 @@ def _emit_step_parts(self):
 
 
 Emitter.emit_step_parts = _emit_step_parts
+
+
+def _emit_deriv_parts(self):
+    """Additive (no counterpart in the reference): the time-varying part of a step's derivative record in PARTS of
+    ILQG_DERIV_PART_OUT outputs, for back-ends that assemble records in on-chip memory and write them as whole cache lines
+    (one lane per (trajectory, step) storing into its own struct touches 64 lines per store instruction).  Only for problems
+    with the factored tensor tables, without multipliers, without auxiliary DERIVATIVES among the time-varying members and
+    with limits that do not depend on the state.
+
+      ilqg_deriv_prepare()  the time-varying auxiliaries of the step (the assignments of calcXVariableAux /
+                            calcXUVariableAux, unchanged), sin / cos of every auxiliary the derivatives take them of — ONCE
+                            (bp_derivsL_first and bp_tensor_basis each evaluate them) —, and from them the products the
+                            entries share (prod[]: the `cs` locals of bp_derivsL_first) and the products of
+                            bp_tensor_basis (basis[]);
+      ilqg_deriv_part(q)    outputs [q * OUT, (q + 1) * OUT) of the list ILQG_DERIV_OUTPUTS: the record's fxx[0 .. NBASIS)
+                            (the products), the box limitsU() leaves for a change of u, the entries bp_derivsL_first writes —
+                            each by the expression of the function it comes from, printed by the same printer (only
+                            `sin(aux_..)` / `cos(aux_..)` are replaced, in the printed text, by the values prepared), so
+                            the FMA-free build gives the same bits.
+    A NaN or Inf in a guarded value sets bad[0]."""
+    if self.plain or self.mu_c or not self.tensor_tables or self.has_hx or not self.p.f:
+        return ""
+    D = self.D
+    tv_aux = [q for q in D.order if q in (self.run_need | self.run_need_full) and self.is_time_var(D.defs[q])]
+    if any(D.kind[q] != "aux" for q in tv_aux):
+        return ""
+    cse = self.cse
+    OUT = 16
+    import re as _re
+    trig_args = []  # auxiliary macro names whose sin / cos are used
+
+    def use_trig(text):
+        def sub(mo):
+            arg = mo.group(2)
+            if arg not in trig_args:
+                trig_args.append(arg)
+            return "%s%d_" % ("sn" if mo.group(1) == "sin" else "cn", trig_args.index(arg))
+        return _re.sub(r"(?<![A-Za-z0-9_])(sin|cos)\((aux_\w+)\)", sub, text)
+
+    def use_prod(text):  # the shared products by number: prod[k]
+        return _re.sub(r"(?<![A-Za-z0-9_])%s(\d+)(?![0-9])" % cse.prefix, r"prod[\1]", text)
+
+    def guard(v):  # NaN or Inf (not `v - v == 0`: where v is a product, FMA contraction turns v - v into its rounding error)
+        return "if(!(fabs(%s) <= 1.7976931348623157e308)) bad[0]= 1;" % v
+
+    outputs = []  # (member, index, rhs text, guarded)
+    for i in range(len(self.tensor_tables["basis"])):
+        outputs.append(("fxx", i, "basis[%d]" % i, False))
+    # the box around the nominal input (limitsU): per input and side the tightest constraint, then minus u
+    limit_code = {}
+    for side, arr, cmp_, start in ((0, "lower", "<", "-INF"), (1, "upper", ">", "INF")):
+        for j in range(self.m):
+            code = "double lim_= %s; double bound_;\n" % start
+            for c in self.cons:
+                if c["input"] == j and (1 if c["sign"] > 0 else 0) == side:
+                    code += "            bound_= %s; if(lim_%sbound_) lim_= bound_;\n" % (cexpr(self.csub(c["limit"], None)), cmp_)
+            limit_code[(arr, j)] = code
+            outputs.append((arr, j, "lim_ - u[%d]" % j, False))
+    cse.use("first")
+    groups = [self.jaco_items("fx", self.fx), self.jaco_items("fu", self.fu), self.grad_items("cx", self.Lx),
+              self.hess_items("cxx", self.Lxx), self.grad_items("cu", self.Lu), self.hess_items("cuu", self.Luu),
+              self.hess_items("cxu", self.Lxu)]
+    for items in groups:
+        for lhs, e in items:
+            if self.is_time_var(e):
+                m = _re.fullmatch(r"t->(\w+)\[(\d+)\]", lhs)
+                outputs.append((m.group(1), int(m.group(2)), use_prod(use_trig(cexpr(self.csub(cse.rewrite(e), None)))), True))
+    products = [(int(cse.names[prod].name[len(cse.prefix):]), use_trig(cexpr(self.csub(prod, None)))) for prod in cse.pools["first"]]
+    basis = [use_trig(cexpr(self.csub(prod, None))) for prod in self.tensor_tables["basis"]]
+    n_prod = max([k for k, _ in products] + [0]) + 1
+    n_parts = (len(outputs) + OUT - 1) // OUT
+
+    members = "".join("    double %s;\n" % q.name for q in tv_aux) or "    double unused_;\n"
+    out = ("\n/* ---- additive: the time-varying entries of a step's derivative record in ILQG_DERIV_PARTS parts of\n"
+           " * ILQG_DERIV_PART_OUT outputs each (batched back-ends that assemble records on chip and store whole cache lines; the\n"
+           " * reference's solver never calls this).  Output o of the list ILQG_DERIV_OUTPUTS, X(member, index), is out[o %%\n"
+           " * ILQG_DERIV_PART_OUT] of part o / ILQG_DERIV_PART_OUT.  ilqg_deriv_prepare: the step's auxiliaries, and — from sin and cos\n"
+           " * of the auxiliaries, each evaluated once — the products the entries share (prod[]) and the products of\n"
+           " * bp_tensor_basis (basis[]).  A NaN or Inf in a guarded value sets bad[0]. */\n"
+           "#define ILQG_DERIV_PARTS %d\n#define ILQG_DERIV_PART_OUT %d\n#define ILQG_DERIV_NOUT %d\n#define ILQG_DERIV_NPROD %d\n"
+           % (n_parts, OUT, len(outputs), n_prod))
+    out += "#define ILQG_DERIV_OUTPUTS(X) " + " ".join("X(%s, %d)" % (mem, idx) for mem, idx, _, _ in outputs) + "\n"
+    out += ("#ifndef ILQG_DERIV_SINCOS  /* a back-end may define it before including this file: SIN_ = sin(ARG_), COS_ = cos(ARG_) */\n"
+            "#define ILQG_DERIV_SINCOS(ARG_, SIN_, COS_) ((SIN_)= sin(ARG_), (COS_)= cos(ARG_))\n#endif\n"
+            "#ifndef ILQG_DERIV_PREPARE_FN  /* ... and the two functions' storage class / attributes */\n#define ILQG_DERIV_PREPARE_FN static\n#endif\n"
+            "#ifndef ILQG_DERIV_PART_FN\n#define ILQG_DERIV_PART_FN static\n#endif\n"
+            "#ifndef ILQG_DERIV_CASE  /* ... and what stands at the head of every part */\n#define ILQG_DERIV_CASE(q)\n#endif\n")
+    out += "typedef struct {\n" + members + "} ilqg_deriv_aux_t;\n"
+    out += ("ILQG_DERIV_PREPARE_FN void ilqg_deriv_prepare(ilqg_deriv_aux_t *t, double prod[], double basis[], int bad[], const double *x, const double *u, int k, double **p, int N) {\n")
+    # products made of sin / cos values go to prod[]; the others (each used by a few entries of one array) are evaluated in
+    # the part that uses them, so that they are not alive from here to there
+    in_prepare = {kq for kq, text in products if _re.search(r"(sn|cn)\d+_", text)}
+    slot = {kq: i for i, kq in enumerate(sorted(in_prepare))}  # prod[] holds these alone, densely
+    # Every value is evaluated right in front of its first use — an auxiliary in front of the first sin / cos of it (its
+    # assignment is the one of calcXVariableAux / calcXUVariableAux; an auxiliary defined through others pulls those in
+    # first), a sin / cos pair in front of the first product of it — so that few of the 32 + 64 intermediate values are
+    # alive at a time.
+    aux_by_macro = {self.macro_name(q): q for q in tv_aux}
+    done_aux, done_trig = set(), set()
+
+    def need_aux(nm):
+        text = ""
+        if nm in done_aux or nm not in aux_by_macro:
+            return text
+        done_aux.add(nm)
+        rhs = cexpr(self.csub(D.defs[aux_by_macro[nm]], None))
+        for dep in _re.findall(r"(?<![A-Za-z0-9_])(aux_\w+)", rhs):
+            text += need_aux(dep)
+        return text + "    %s= %s;\n    %s\n" % (nm, rhs, guard(nm))
+
+    def need_trig(text_using):
+        text = ""
+        for j in sorted({int(v) for v in _re.findall(r"(?:sn|cn)(\d+)_", text_using)}):
+            if j not in done_trig:
+                done_trig.add(j)
+                text += need_aux(trig_args[j])
+                text += "    double sn%d_, cn%d_;\n    ILQG_DERIV_SINCOS(%s, sn%d_, cn%d_);\n" % (j, j, trig_args[j], j, j)
+        return text
+
+    body = ""
+    order = [("prod[%d]" % slot[kq], text) for kq, text in products if kq in in_prepare] + [("basis[%d]" % i, text) for i, text in enumerate(basis)]
+    # (by the first sin / cos pair a value needs: the products of one pair of auxiliaries behind each other)
+    order.sort(key=lambda it: min([int(v) for v in _re.findall(r"(?:sn|cn)(\d+)_", it[1])] or [0]))
+    for lhs, text in order:
+        body += need_trig(text) + "    %s= %s;\n    %s\n" % (lhs, text, guard(lhs))
+    for nm in aux_by_macro:  # (auxiliaries nothing above needed: the struct is filled in any case)
+        body += need_aux(nm)
+    out += body + "}\n"
+    out += ("ILQG_DERIV_PART_FN void ilqg_deriv_part(int part, double out[], int bad[], const ilqg_deriv_aux_t *t, const double prod[], const double basis[], const double *x, const double *u, int k, double **p, int N) {\n"
+            "    switch(part) {\n")
+    for q in range(n_parts):
+        mine = outputs[q * OUT:(q + 1) * OUT]
+        out += "    case %d: { ILQG_DERIV_CASE(%d)\n" % (q, q)
+        local = []
+        for _, _, rhs, _ in mine:
+            for kq in _re.findall(r"prod\[(\d+)\]", rhs):
+                if int(kq) not in in_prepare and int(kq) not in local:
+                    local.append(int(kq))
+        text_of = dict(products)
+        for kq in sorted(local):
+            out += "        const double pl%d_= %s;\n        %s\n" % (kq, text_of[kq], guard("pl%d_" % kq))
+        mine = [(mem, idx, _re.sub(r"prod\[(\d+)\]", lambda mo: "prod[%d]" % slot[int(mo.group(1))] if int(mo.group(1)) in in_prepare else "pl%s_" % mo.group(1), rhs), g)
+                for mem, idx, rhs, g in mine]
+        for j, (mem, idx, rhs, guarded) in enumerate(mine):
+            if (mem, idx) in limit_code:
+                out += "        { %s            out[%d]= %s; }\n" % (limit_code[(mem, idx)], j, rhs)
+            else:
+                out += "        out[%d]= %s;\n" % (j, rhs)
+                if guarded and not _re.fullmatch(r"-?[0-9.eE+-]+", rhs):
+                    out += "        %s\n" % guard("out[%d]" % j)
+        out += "        } break;\n"
+    out += "    default: break;\n    }\n}\n"
+    return out.replace("#define ILQG_DERIV_NPROD %d\n" % n_prod, "#define ILQG_DERIV_NPROD %d\n" % max(1, len(slot)))
+
+
+Emitter.emit_deriv_parts = _emit_deriv_parts
 
 
 def load_problem(path):
