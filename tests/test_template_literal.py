@@ -105,8 +105,9 @@ def test_no_macro_of_the_problem_file_reaches_the_kernels(built, problem):
     csrc = os.path.join(ROOT, "ddp-generator_amd", "csrc")
     text = open(os.path.join(csrc, "ilqg_kernels.hip")).read()
     text = text[text.index('#include "ilqg_problem_undefs.h"'):]
-    for h in ("ilqg_device.hpp", "ilqg_wave.hpp", "ilqg_row.hpp", "ilqg_shim.h"):
-        text += open(os.path.join(csrc, h)).read()
+    for h in sorted(os.listdir(csrc)):
+        if h.endswith((".hpp", ".inc")) or h == "ilqg_shim.h":
+            text += open(os.path.join(csrc, h)).read()
     text = re.sub(r"//[^\n]*|/\*.*?\*/", " ", text, flags=re.S)
     used = set(re.findall(r"[A-Za-z_]\w*", text))
     assert not (used & defined), sorted(used & defined)

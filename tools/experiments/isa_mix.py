@@ -1,5 +1,5 @@
 """Static instruction mix of a stretch of device assembly by region (line ranges of the .s file).
-   python tools/scratch/isa_mix.py file.s name:first-last ..."""
+   python tools/experiments/isa_mix.py file.s name:first-last ..."""
 import re, sys, collections
 lines = open(sys.argv[1]).read().split("\n")
 def cat(op):
