@@ -64,13 +64,18 @@ struct ilqg_hooks {
     double huge;       // p[-2]: != 0 once sin/cos saw an argument the straight-line path cannot reduce
     double slow;       // p[-3]: != 0: sin/cos go to the device library (the rarely taken re-evaluation)
     double limgrad;    // p[-4]: != 0 (the default): limitsU() also stores the limits' signs and gradients
+    double alone;      // p[-5]: != 0: the callbacks run with SOME lanes of the wavefront (staged record entries: see below)
+    double *record;    // p[-6] points here: where staged record entries go in HBM (the lane's trajEl_t; the `t` the
+                       //        callbacks get may be a private one, see k_derivs_wave)
 };
 #include "ilqg_param_layout.h"  // generated at build time from the problem's paramdesc[]: ILQG_NP, sizes, offsets
-#define ILQG_HOOK_SLOTS 4
+#define ILQG_HOOK_SLOTS 6
 #define ILQG_HOOK_NONFINITE (ILQG_NP)
 #define ILQG_HOOK_HUGE (ILQG_NP + 1)
 #define ILQG_HOOK_SLOW (ILQG_NP + 2)
 #define ILQG_HOOK_LIMGRAD (ILQG_NP + 3)
+#define ILQG_HOOK_ALONE (ILQG_NP + 4)
+#define ILQG_HOOK_RECORD (ILQG_NP + 5)
 
 __device__ __forceinline__ int ilqg_note_nonfinite(double **p, double v) {
     double *f = p[ILQG_HOOK_NONFINITE];
@@ -172,6 +177,15 @@ __device__ __forceinline__ static ilqg_sc ilqg_sincos(double x) {
     if(!(fabs(x) < 8.0e5)) out = ilqg_sincos_slow(x);
     return out;
 }
+// the same as a LEAF: the library's code inside instead of behind a call.  A function that calls keeps its return
+// address in a lane of a callee-saved vector register, which it first stores to and finally reloads from scratch memory
+// — a memory round trip per sin / cos call, 2 000 to 3 000 cycles each with the memory system busy (measured: 64 such
+// calls were 170 000 of the 320 000 cycles a wavefront of k_derivs_wave took for the n = 16 problem).
+__device__ __forceinline__ static ilqg_sc ilqg_sincos_leaf(double x) {
+    ilqg_sc out = ilqg_sincos_fast(x);
+    if(!(fabs(x) < 8.0e5)) sincos(x, &out.s, &out.c);
+    return out;
+}
 
 // form used by the generated code of small problems: no branch, hooks instead (see above)
 __device__ __forceinline__ static ilqg_sc ilqg_sincos_hooked(double **p, double x) {
@@ -184,7 +198,7 @@ __device__ __forceinline__ static ilqg_sc ilqg_sincos_hooked(double **p, double 
 // Large generated files (thousands of sin/cos call sites, e.g. the tensors of an n = 16 problem): keep
 // every evaluation a CALL to a side-effect-free function.  Calls with equal arguments are merged before
 // anything is inlined, which also keeps the compile time bounded.
-__device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_call(double x) { return ilqg_sincos(x); }
+__device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_call(double x) { return ilqg_sincos_leaf(x); }
 #define sin(x) (ilqg_sincos_call(x).s)
 #define cos(x) (ilqg_sincos_call(x).c)
 // ... except in the parts of a roll-out step (ilqg_step_part, a few dozen call sites): there they are inline, the
@@ -229,6 +243,97 @@ __device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_call(doub
 // (The kernel has two instantiations; with two callers the inliner leaves a function of this size alone.)
 #define ILQG_PART_FN static __attribute__((always_inline))
 
+// ---------------------------------------------------------------------------
+// Record entries collected on chip (wave mapping, k_derivs_wave: one lane = one (trajectory, step), each lane fills the
+// trajEl_t of its step in HBM).  A store of the generated code `t->fx[17]= ...` touches 64 records, 64 cache lines, with
+// 8 or 16 bytes each; the kernel was bound by those requests (round 3: 63 % of a wavefront's cycles waiting, 116 GB
+// written for 72 GB of payload).  The function file of tools/gen_problem.py writes the RUNS of neighbouring entries it
+// assigns (all of fx, fu, cx, cu; the products of the factored tensors) through ILQG_REC(member, index) and closes every
+// run of at most 64 entries with ILQG_REC_DONE(member, first, count) — by default the plain assignment and nothing.  Here
+// an entry goes into a ring of 64 slots per lane in LDS (slot = the entry's place in the record modulo 64; lane-fastest,
+// so the 64 lanes of a store hit 64 different banks), and at the end of a run the WAVEFRONT writes it out record by
+// record: lane l takes entry first + l of the record of lane s, s = 0 .. 63 — one store instruction per record, 512
+// contiguous bytes.  That needs all 64 lanes: k_derivs_wave lets lanes without a record of their own go along as copies
+// of one that has.  Where the callbacks run with some lanes only (the lane-by-lane repetition behind a wave-uniform
+// guard, the re-evaluation with the library's sin / cos), the `alone` hook is set and a lane copies its own column.
+// A file without the macros (Maxima-generated) stores directly as before.
+// ---------------------------------------------------------------------------
+#ifndef ILQG_DERIVS_BLOCK
+#define ILQG_DERIVS_BLOCK 256
+#endif
+#define ILQG_STAGE_LD 65  // doubles between the slots of a lane (64 lanes + 1: the write-out reads a column, lane l slot first + l)
+__shared__ double ilqg_stage[(ILQG_DERIVS_BLOCK / 64) * 64 * ILQG_STAGE_LD];
+#ifdef ILQG_PROFILE_SECTIONS
+// cycle accounting of k_derivs_wave (tools/section_profile_derivs.py): slot = the next probe of the wavefront
+__device__ unsigned long long ilqg_dprof_cycles[32];
+__shared__ unsigned long long ilqg_dprof_last[ILQG_DERIVS_BLOCK / 64];
+__shared__ int ilqg_dprof_next[ILQG_DERIVS_BLOCK / 64];
+__device__ __forceinline__ static void ilqg_dprobe(int set_next = -1) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    const int w = threadIdx.x >> 6;
+    if((threadIdx.x & 63) == 0) {
+        if(set_next >= 0) ilqg_dprof_next[w] = set_next;
+        else {
+            const int i = ilqg_dprof_next[w];
+            atomicAdd(&ilqg_dprof_cycles[i < 31 ? i : 31], now - ilqg_dprof_last[w]);
+            ilqg_dprof_next[w] = i + 1;
+        }
+        ilqg_dprof_last[w] = __builtin_readcyclecounter();
+    }
+}
+#define ILQG_DPROBE(...) ilqg_dprobe(__VA_ARGS__)
+#else
+#define ILQG_DPROBE(...) ((void)0)
+#endif
+__device__ __forceinline__ static double &ilqg_stage_at(unsigned slot) {
+    return ilqg_stage[(threadIdx.x >> 6) * (64 * ILQG_STAGE_LD) + slot * ILQG_STAGE_LD + (threadIdx.x & 63)];
+}
+// entries [first, first + count) (doubles from the start of the record) of all lanes' records, from the ring to HBM
+__device__ __forceinline__ static void ilqg_stage_flush(double **p, unsigned first, int count) {
+    typedef __attribute__((address_space(1))) double gdouble;
+    double *const t = *reinterpret_cast<double **>(p[ILQG_HOOK_RECORD]);
+    asm volatile("" ::: "memory");
+    ILQG_DPROBE();
+    if(*p[ILQG_HOOK_ALONE] != 0.0) {
+        double *const out = t + first;
+#pragma unroll 1
+        for(int i = 0; i < count; i++) out[i] = ilqg_stage_at((first + i) & 63u);
+    } else {
+        const unsigned lane = threadIdx.x & 63;
+        const unsigned long long tb = (unsigned long long)t;
+        const unsigned lo = (unsigned)tb, hi = (unsigned)(tb >> 32);
+        const double *const ring = &ilqg_stage[(threadIdx.x >> 6) * (64 * ILQG_STAGE_LD)];
+        if(count > 32) {
+            // one record per store instruction: lane l its entry first + l; the record's address is wave-uniform
+            const double *const col = ring + ((first + lane) & 63u) * ILQG_STAGE_LD;
+            for(int s0 = 0; s0 < 64; s0 += 8) {
+                double v[8];
+#pragma unroll
+                for(int j = 0; j < 8; j++) v[j] = col[s0 + j];
+#pragma unroll
+                for(int j = 0; j < 8; j++) {
+                    const unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, s0 + j) << 32) |
+                                                    (unsigned)__builtin_amdgcn_readlane((int)lo, s0 + j);
+                    if((int)lane < count) reinterpret_cast<gdouble *>(base)[first + lane] = v[j];
+                }
+            }
+        } else {
+            // short runs: 64 / W records per store instruction, W = 8, 16 or 32 lanes each
+            const int W = count > 16 ? 32 : (count > 8 ? 16 : 8), G = 64 / W;
+            const unsigned e = lane & (W - 1), g = lane / W;
+            const double *const col = ring + ((first + e) & 63u) * ILQG_STAGE_LD;
+            for(int s0 = 0; s0 < 64; s0 += G) {
+                const int s = s0 + (int)g;
+                const unsigned long long base = ((unsigned long long)(unsigned)__shfl((int)hi, s) << 32) | (unsigned)__shfl((int)lo, s);
+                const double v = col[s];
+                if((int)e < count) reinterpret_cast<gdouble *>(base)[first + e] = v;
+            }
+        }
+    }
+    ILQG_DPROBE();
+    asm volatile("" ::: "memory");
+}
+
 extern "C" {
 #pragma clang attribute push(__attribute__((device)), apply_to = function)
 #pragma clang attribute push(__attribute__((internal_linkage)), apply_to = variable(is_global))
@@ -242,6 +347,22 @@ extern "C" {
 #if defined(ILQG_STATE_DEPENDENT_LIMITS) && !ILQG_STATE_DEPENDENT_LIMITS
 #define ILQG_LIMIT_GRADIENTS_WANTED (*p[ILQG_HOOK_LIMGRAD] != 0.0)
 #endif
+// Mapping: lane mapping (one lane per trajectory, everything in registers) for small problems,
+// wave mapping (one wavefront per trajectory, matrices in LDS) when a lane's registers cannot
+// hold the matrices.  -DILQG_WAVE_MAP=1 forces the wave mapping for a small problem.
+#ifndef ILQG_WAVE_MAP
+#define ILQG_WAVE_MAP (N_X > 8)
+#endif
+#if ILQG_WAVE_MAP && !defined(ILQG_NO_STAGED_RECORDS)
+#define ILQG_REC(member, index) ilqg_stage_at((unsigned)((offsetof(trajEl_t, member) / sizeof(double) + (index)) & 63u))
+#define ILQG_REC_DONE(member, first, count) ilqg_stage_flush(p, (unsigned)(offsetof(trajEl_t, member) / sizeof(double) + (first)), count);
+// (the products of the factored tensors: bp_tensor_basis(t->fxx, t, ...) — the kernel passes the start of fxx)
+#define ILQG_BASIS(index) ILQG_REC(fxx, index)
+#define ILQG_BASIS_DONE(count) ILQG_REC_DONE(fxx, 0, count)
+#define ILQG_STAGED_RECORDS 1
+#else
+#define ILQG_STAGED_RECORDS 0
+#endif
 #include "iLQG_func.c"
 #pragma clang attribute pop
 #pragma clang attribute pop
@@ -253,13 +374,6 @@ extern "C" {
 // (iLQG_func.tem:5-30), which on the host is the end of the file and here would be the kernels.  The list is made from
 // the file at build time (csrc/Makefile); ILQG_* names, the additive surface the kernels ask for, stay.
 #include "ilqg_problem_undefs.h"
-
-// Mapping: lane mapping (one lane per trajectory, everything in registers) for small problems,
-// wave mapping (one wavefront per trajectory, matrices in LDS) when a lane's registers cannot
-// hold the matrices.  -DILQG_WAVE_MAP=1 forces the wave mapping for a small problem.
-#ifndef ILQG_WAVE_MAP
-#define ILQG_WAVE_MAP (N_X > 8)
-#endif
 
 #include "ilqg_device.hpp"
 #include "ilqg_wave.hpp"
@@ -366,9 +480,10 @@ __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
 // of them, see the guard), once more with one lane active at a time.  ONE call site for both, so that the repetition
 // is the same machine code and a healthy lane gets the same bits either way.
 template <class Fn>
-__device__ __forceinline__ int run_guarded(Fn &&f) {
+__device__ __forceinline__ int run_guarded(Fn &&f, double *alone = nullptr) {
     int r = 1;
     for(int a = 0; a <= 64; a++) {
+        if(alone) *alone = (a > 0) ? 1.0 : 0.0;  // (the hook of staged record entries: ilqg_stage_flush)
         if(a == 0 || (int)(threadIdx.x & 63) == a - 1) r = f();
         if(a == 0 && __builtin_amdgcn_ballot_w64(r == 0) == 0ull) break;
     }
@@ -520,6 +635,10 @@ __device__ __forceinline__ void load_params(ParamValues &V, ParamTable &T, ilqg_
     T.ptr[ILQG_HOOK_HUGE] = &H.huge;
     T.ptr[ILQG_HOOK_SLOW] = &H.slow;
     T.ptr[ILQG_HOOK_LIMGRAD] = &H.limgrad;
+    H.alone = 0.0;
+    T.ptr[ILQG_HOOK_ALONE] = &H.alone;
+    H.record = nullptr;
+    T.ptr[ILQG_HOOK_RECORD] = reinterpret_cast<double *>(&H.record);
 }
 
 // What a kernel needs to call the generated callbacks.  Four separate private objects, each pointing

@@ -170,6 +170,7 @@ int ilqg_dev_count_active(ilqg_dev_t *d, int *n_active); /* synchronises */
 
 /* builds with -DILQG_PROFILE_SECTIONS: cycles per section of the fused backward step, summed over wavefronts */
 int ilqg_dev_section_cycles(unsigned long long *out8);
+int ilqg_dev_derivs_cycles(unsigned long long *out32);
 
 /* per-kernel HIP-event timing on the context's stream */
 int ilqg_dev_timing(ilqg_dev_t *d, int enable);

@@ -466,7 +466,7 @@ class Emitter:
 
     @staticmethod
     def _neighbours(l1, l2):
-        m1, m2 = re.fullmatch(r"(.*)\[(\d+)\]", l1), re.fullmatch(r"(.*)\[(\d+)\]", l2)
+        m1, m2 = re.fullmatch(r"(.*)[\[(](\d+)[\])]", l1), re.fullmatch(r"(.*)[\[(](\d+)[\])]", l2)
         return bool(m1 and m2 and m1.group(1) == m2.group(1) and int(m2.group(2)) == int(m1.group(2)) + 1)
 
     def jaco_items(self, name, mat):
@@ -857,9 +857,14 @@ int calc_derivs(tOptSet *o) {
         if self.tensor_tables:
             # the part a back-end that evaluates the tensors from the factored tables still needs, on its own
             head = "    const double *const x= t->x;\n    const double *const u= t->u;\n\n"
-            out = ("static int bp_derivsL_first(trajEl_t *t, int k, double **p) {\n" + head +
-                   "    /* products shared by several entries */\n" + cse.declarations("first") + "\n"
-                   "    /* dynamics */\n" + first + "    /* cost */\n" + cost + "    return 1;\n}\n\n"
+            self.direct_entries = []
+            first, cost = self._record_runs(first), self._record_runs(cost)
+            direct = ("/* the entries bp_derivsL_first assigns outside the runs, as X(member, index) ... */\n#define ILQG_REC_DIRECT(X) " +
+                      " ".join("X(%s, %d)" % e for e in self.direct_entries) + "\n")
+            taken, body = self._aux_once("    /* products shared by several entries */\n" + cse.declarations("first") + "\n"
+                                         "    /* dynamics */\n" + first + "    /* cost */\n" + cost)
+            out = (self.RECORD_MACROS + direct + "static int bp_derivsL_first(trajEl_t *t, int k, double **p) {\n" + head + taken + body +
+                   "    return 1;\n}\n\n"
                    "#if FULL_DDP\nstatic int bp_derivsL_second(trajEl_t *t, int k, double **p) {\n" + head +
                    second + "    return 1;\n}\n#endif\n\n"
                    "static int bp_derivsL(trajEl_t *t, int k, double **p) {\n    if(!bp_derivsL_first(t, k, p)) return 0;\n"
@@ -873,6 +878,71 @@ int calc_derivs(tOptSet *o) {
         out += self.block(self.grad_items("cx", self.Fx), True) + "\n" + self.block(self.hess_items("cxx", self.Fxx), True)
         out += "    return 1;\n}\n\n"
         return out
+
+    # Runs of neighbouring record entries that bp_derivsL_first assigns one after the other (all of fx, fu, cx, cu of a
+    # typical problem) are written through ILQG_REC(member, index), each run closed by ILQG_REC_DONE(member, first, count)
+    # in pieces of at most RUN_MAX entries.  By default that is the plain assignment t->member[index]= ...; a batched
+    # back-end whose lanes each own a record may collect a run on chip and store it as whole cache lines.
+    RUN_MIN, RUN_MAX = 8, 64
+    RECORD_MACROS = ("#ifndef ILQG_REC  /* a back-end may define these two before including this file */\n"
+                     "#define ILQG_REC(member, index) t->member[index]\n"
+                     "#define ILQG_REC_DONE(member, first, count)  /* entries first .. first+count-1 have been assigned */\n"
+                     "#endif\n")
+
+    @staticmethod
+    def _aux_once(text, ind=4):
+        """(declarations, text): every auxiliary the statements read, taken into a local once at the head of the function
+        (a back-end whose elements live in device memory gets all these loads in flight together instead of one round
+        trip in front of each use; the values and the arithmetic are the same)"""
+        names = []
+        for m in re.finditer(r"\b(d?aux_\w+)\b", text):
+            if m.group(1) not in names:
+                names.append(m.group(1))
+        if not names:
+            return "", text
+        decl = " " * ind + "/* auxiliaries read here, taken once */\n"
+        for i in range(0, len(names), 4):
+            decl += " " * ind + "const double " + ", ".join("v_%s= %s" % (n, n) for n in names[i:i + 4]) + ";\n"
+        return decl + "\n", re.sub(r"\b(d?aux_\w+)\b", lambda m: "v_" + m.group(1), text)
+
+    def _record_runs(self, text):
+        lines = text.split("\n")
+        seq = []  # (member, index) in the order of their assignments
+        for ln in lines:
+            m = re.match(r"\s*t->(\w+)\[(\d+)\]= ", ln)
+            if m:
+                seq.append((m.group(1), int(m.group(2))))
+        runs, i = [], 0
+        while i < len(seq):
+            j = i
+            while j + 1 < len(seq) and seq[j + 1] == (seq[j][0], seq[j][1] + 1):
+                j += 1
+            if j - i + 1 >= self.RUN_MIN:
+                for a in range(i, j + 1, self.RUN_MAX):
+                    runs.append((seq[i][0], seq[a][1], min(self.RUN_MAX, seq[j][1] - seq[a][1] + 1)))
+            i = j + 1
+        staged = {(m, a + d): (m, a, n) for m, a, n in runs for d in range(n)}
+        self.direct_entries = getattr(self, "direct_entries", []) + [e for e in seq if e not in staged]
+        out, last_line = [], {}
+        for n_, ln in enumerate(lines):
+            def sub(mo):
+                key = (mo.group(1), int(mo.group(2)))
+                if key in staged:
+                    last_line[staged[key]] = n_
+                    return "ILQG_REC(%s, %d)" % key
+                return mo.group(0)
+            # (not inside the guard's message: it names the entry as the reference's files do)
+            pieces = re.split(r'("(?:[^"\\]|\\.)*")', ln)
+            out.append("".join(q if q.startswith('"') else re.sub(r"t->(\w+)\[(\d+)\]", sub, q) for q in pieces))
+        done = {}
+        for run, n_ in last_line.items():
+            done.setdefault(n_, []).append(run)
+        res = []
+        for n_, ln in enumerate(out):
+            res.append(ln)
+            for m, a, n in sorted(done.get(n_, []), key=lambda r: r[1]):
+                res.append("    ILQG_REC_DONE(%s, %d, %d)" % (m, a, n))
+        return "\n".join(res)
 
     def time_varying_list(self, full):
         """the entries emit_derivatives() assigns in bp_derivsL, as X(member, index) ..."""
@@ -1089,10 +1159,13 @@ def _emit_factored_tensors(self):
            " * times ONE product shared by the slice,\n"
            " *     t->fxx[i*sizeofQxx + e] == ilqg_tensor_coef_xx[i*sizeofQxx + e] * basis[ilqg_tensor_slice_xx[i]]   (likewise fuu, fxu)\n"
            " * and bp_tensor_basis() evaluates the ILQG_TENSOR_NBASIS products of one step exactly as bp_derivsL does. */\n"
+           "#ifndef ILQG_BASIS  /* a back-end may define these two before including this file */\n"
+           "#define ILQG_BASIS(index) basis[index]\n"
+           "#define ILQG_BASIS_DONE(count)  /* all products have been assigned */\n#endif\n"
            "static int bp_tensor_basis(double *basis, trajEl_t *t, int k, double **p) {\n"
            "    const double *const x= t->x;\n    const double *const u= t->u;\n\n")
-    out += self.block([("basis[%d]" % i, prod) for i, prod in enumerate(T["basis"])], None, pair=True)
-    out += "    return 1;\n}\n\n"
+    taken, body = self._aux_once(self.block([("ILQG_BASIS(%d)" % i, prod) for i, prod in enumerate(T["basis"])], None, pair=True))
+    out += taken + body + "    ILQG_BASIS_DONE(%d)\n    return 1;\n}\n\n" % len(T["basis"])
     for nm in ("xx", "uu", "xu"):
         coef, slices = T[nm]
         out += "static const double ilqg_tensor_coef_%s[%d]= {\n" % (nm, len(coef))
