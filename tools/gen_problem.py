@@ -903,7 +903,19 @@ int calc_derivs(tOptSet *o) {
         decl = " " * ind + "/* auxiliaries read here, taken once */\n"
         for i in range(0, len(names), 4):
             decl += " " * ind + "const double " + ", ".join("v_%s= %s" % (n, n) for n in names[i:i + 4]) + ";\n"
-        return decl + "\n", re.sub(r"\b(d?aux_\w+)\b", lambda m: "v_" + m.group(1), text)
+        text = re.sub(r"\b(d?aux_\w+)\b", lambda m: "v_" + m.group(1), text)
+        # ... and their sines and cosines, ahead of the first guard: one evaluation per auxiliary and function, in a block
+        # that is always executed (two functions inlined into one caller then share the evaluations)
+        trig = []
+        for m in re.finditer(r"\b(sin|cos)\((v_d?aux_\w+)\)", text):
+            if (m.group(1), m.group(2)) not in trig:
+                trig.append((m.group(1), m.group(2)))
+        if trig:
+            decl += " " * ind + "/* ... and their sines and cosines */\n"
+            for i in range(0, len(trig), 4):
+                decl += " " * ind + "const double " + ", ".join("%s_%s= %s(%s)" % (f, a, f, a) for f, a in trig[i:i + 4]) + ";\n"
+            text = re.sub(r"\b(sin|cos)\((v_d?aux_\w+)\)", lambda m: "%s_%s" % (m.group(1), m.group(2)), text)
+        return decl + "\n", text
 
     def _record_runs(self, text):
         lines = text.split("\n")
