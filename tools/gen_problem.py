@@ -453,7 +453,7 @@ class Emitter:
                 if want_time_var is None or self.is_time_var(e) == want_time_var]
         out, i = "", 0
         while i < len(todo):
-            if pair and i + 1 < len(todo) and self._neighbours(todo[i][0], todo[i + 1][0]):
+            if pair and i + 1 < len(todo) and self._neighbours(todo[i][0], todo[i + 1][0]) and not self._ends_piece(todo[i][0]):
                 a, b = self.assign(todo[i][0], todo[i][1], ind).split("\n")[:-1], self.assign(todo[i + 1][0], todo[i + 1][1], ind).split("\n")[:-1]
                 # (each is the assignment, then its guard unless the value is a plain number)
                 guards = [g.replace("__LINE__-1", "__LINE__-2") for g in a[1:] + b[1:]]
@@ -463,6 +463,12 @@ class Emitter:
                 out += self.assign(todo[i][0], todo[i][1], ind)
                 i += 1
         return out
+
+    def _ends_piece(self, lhs):
+        """the entry is the last one of a piece of a run (see _record_runs): the next one is assigned behind its guard"""
+        m = re.fullmatch(r"t->(\w+)\[(\d+)\]", lhs)
+        place = self.record_offsets()
+        return bool(m and m.group(1) in place and (place[m.group(1)] + int(m.group(2)) + 1) % self.RUN_MAX == 0)
 
     @staticmethod
     def _neighbours(l1, l2):
@@ -858,7 +864,7 @@ int calc_derivs(tOptSet *o) {
             # the part a back-end that evaluates the tensors from the factored tables still needs, on its own
             head = "    const double *const x= t->x;\n    const double *const u= t->u;\n\n"
             self.direct_entries = []
-            first, cost = self._record_runs(first), self._record_runs(cost)
+            first, cost = self._record_runs(first), self._record_runs(cost)  # (fx and fu are one block: `first`)
             direct = ("/* the entries bp_derivsL_first assigns outside the runs, as X(member, index) ... */\n#define ILQG_REC_DIRECT(X) " +
                       " ".join("X(%s, %d)" % e for e in self.direct_entries) + "\n")
             taken, body = self._aux_once("    /* products shared by several entries */\n" + cse.declarations("first") + "\n"
@@ -917,23 +923,46 @@ int calc_derivs(tOptSet *o) {
             text = re.sub(r"\b(sin|cos)\((v_d?aux_\w+)\)", lambda m: "%s_%s" % (m.group(1), m.group(2)), text)
         return decl + "\n", text
 
+    def record_offsets(self):
+        """place (in doubles from the start of trajEl_t) of the members bp_derivsL_first assigns: the layout of
+        problem_h() up to fu, the same with and without FULL_DDP"""
+        n, m = self.n, self.m
+        off, out = 0, {}
+        for name, size in (("x", n), ("u", m), ("lower", m), ("upper", m), ("lower_sign", m), ("upper_sign", m), ("lower_hx", n * m),
+                           ("upper_hx", n * m), ("l", m), ("L", m * n), ("c", 1), ("cx", n), ("cxx", n * (n + 1) // 2), ("cu", m),
+                           ("cuu", m * (m + 1) // 2), ("cxu", n * m), ("fx", n * n), ("fu", n * m)):
+            out[name] = off
+            off += size
+        return out
+
     def _record_runs(self, text):
+        """A run: entries assigned one after the other that are neighbours in the ELEMENT (fx[255] and fu[0] are), at
+        least RUN_MIN of them.  It is closed in pieces that end where the place in the element is a multiple of RUN_MAX
+        (so a back-end that writes a piece as whole cache lines meets every line once), each piece named by its first
+        entry: ILQG_REC_DONE(member, index, count) — the count may reach into the next member."""
         lines = text.split("\n")
+        place = self.record_offsets()
         seq = []  # (member, index) in the order of their assignments
         for ln in lines:
             m = re.match(r"\s*t->(\w+)\[(\d+)\]= ", ln)
             if m:
                 seq.append((m.group(1), int(m.group(2))))
-        runs, i = [], 0
+        at = lambda e: place[e[0]] + e[1]
+        pieces, i = [], 0  # (entries of the piece)
         while i < len(seq):
             j = i
-            while j + 1 < len(seq) and seq[j + 1] == (seq[j][0], seq[j][1] + 1):
+            while j + 1 < len(seq) and seq[j + 1][0] in place and seq[j][0] in place and at(seq[j + 1]) == at(seq[j]) + 1:
                 j += 1
-            if j - i + 1 >= self.RUN_MIN:
-                for a in range(i, j + 1, self.RUN_MAX):
-                    runs.append((seq[i][0], seq[a][1], min(self.RUN_MAX, seq[j][1] - seq[a][1] + 1)))
+            if j - i + 1 >= self.RUN_MIN and seq[i][0] in place:
+                a = i
+                while a <= j:
+                    e = a
+                    while e < j and (at(seq[e]) + 1) % self.RUN_MAX != 0:
+                        e += 1
+                    pieces.append(seq[a:e + 1])
+                    a = e + 1
             i = j + 1
-        staged = {(m, a + d): (m, a, n) for m, a, n in runs for d in range(n)}
+        staged = {e: pc for pc in map(tuple, pieces) for e in pc}
         self.direct_entries = getattr(self, "direct_entries", []) + [e for e in seq if e not in staged]
         out, last_line = [], {}
         for n_, ln in enumerate(lines):
@@ -944,16 +973,16 @@ int calc_derivs(tOptSet *o) {
                     return "ILQG_REC(%s, %d)" % key
                 return mo.group(0)
             # (not inside the guard's message: it names the entry as the reference's files do)
-            pieces = re.split(r'("(?:[^"\\]|\\.)*")', ln)
-            out.append("".join(q if q.startswith('"') else re.sub(r"t->(\w+)\[(\d+)\]", sub, q) for q in pieces))
+            parts = re.split(r'("(?:[^"\\]|\\.)*")', ln)
+            out.append("".join(q if q.startswith('"') else re.sub(r"t->(\w+)\[(\d+)\]", sub, q) for q in parts))
         done = {}
-        for run, n_ in last_line.items():
-            done.setdefault(n_, []).append(run)
+        for pc, n_ in last_line.items():
+            done.setdefault(n_, []).append(pc)
         res = []
         for n_, ln in enumerate(out):
             res.append(ln)
-            for m, a, n in sorted(done.get(n_, []), key=lambda r: r[1]):
-                res.append("    ILQG_REC_DONE(%s, %d, %d)" % (m, a, n))
+            for pc in sorted(done.get(n_, []), key=lambda r: at(r[0])):
+                res.append("    ILQG_REC_DONE(%s, %d, %d)" % (pc[0][0], pc[0][1], len(pc)))
         return "\n".join(res)
 
     def time_varying_list(self, full):
