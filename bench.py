@@ -137,7 +137,10 @@ def issue_object(kernel, name="issue.json"):
     k = j.get(kernel)
     if not k:
         return {"valu_insts_per_step": None, "active_valu_frac": None, "source": "profiles/" + name, "stale": "no entry for " + kernel}
-    return {"kernel": kernel, "valu_insts_per_step": k["valu_insts_per_wave_and_step"], "active_valu_frac": k["active_valu_frac"],
+    per_step = k.get("valu_insts_per_trajectory_step", k["valu_insts_per_wave_and_step"])
+    return {"kernel": kernel, "valu_insts_per_step": per_step, "active_valu_frac": k["active_valu_frac"],
+            "per": "step of a trajectory (wavefront instructions; a wavefront serves four trajectories)" if "valu_insts_per_trajectory_step" in k
+                   else "step of a wavefront",
             "wait_any_frac": k.get("wait_any_frac"), "valu_insts_total": k.get("valu_insts_total"),
             "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES / %d steps; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; sources %s; "
                       "not collected in this run)" % (name, j.get("_steps", 0), j.get("_source_sha"))}
@@ -165,7 +168,7 @@ def kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, iters, **op
 
 
 def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
-    """BASELINE config 5: synthetic n=16, m=8, N=1000, FULL_DDP=1, 16 384 trajectories, one wavefront per trajectory"""
+    """BASELINE config 5: synthetic n=16, m=8, N=1000, FULL_DDP=1, 16 384 trajectories (wave mapping: 16 lanes per trajectory)"""
     B, N, nx, nu = 16384, 1000, 16, 8
     alg = algorithmic_bytes(nx, nu, 1)
     x0, u0 = synth.synth16_batch(B, N)
@@ -209,11 +212,13 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
         "value": it_s, "unit": "iterations/s", "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "dtype": "f64",
         "config": {"workload": "Synth16x8 batch=16384, 8-alpha line search, FULL_DDP=1, first %d iterations after the "
                                "initial roll-out" % K,
-                   "mapping": "one wavefront per trajectory (row-mapped backward step); records carry the first-order "
-                              "derivatives and the 32 products the tensors are multiples of (factored tensor tables of "
-                              "the generated file), the backward step multiplies the tensors out",
+                   "mapping": "quad mapping: 16 lanes per trajectory in the backward step, four trajectories per wavefront, "
+                              "each 16-lane row a worker that takes trajectories from a queue (k_backward_quad); records carry "
+                              "the first-order derivatives and the 32 products the tensors are multiples of (factored tensor "
+                              "tables of the generated file), written as whole cache lines from LDS (k_derivs_wave), the "
+                              "backward step multiplies the tensors out",
                    "backward_sweeps_per_trajectory_in_last_iteration": sweeps},
-        "roofline": {"bound": "hbm", "kernel": "iteration (k_derivs_wave + k_backward_wave + roll-outs)",
+        "roofline": {"bound": "hbm", "kernel": "iteration (k_derivs_wave + k_backward_quad + roll-outs)",
                      "achieved": iter_bytes * it_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": iter_bytes * it_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                      "algorithmic_bytes_per_iteration": iter_bytes,
@@ -231,7 +236,7 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
         "kernels_ms_per_iteration_sum_of_spans": {k: v[1] / K for k, v in times.items() if v[0]},
         "trajectories_still_active": int(active), "cost_mean_after_window": cost,
     }
-    out["roofline"]["issue"] = issue_object("k_backward_wave<true>", "issue_config5.json")
+    out["roofline"]["issue"] = issue_object("k_backward_quad<true>", "issue_config5.json")
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(B, K, "synth16x8", 1, synth.SYNTH16_PARAMS, N, synth.synth16_batch, budget_s=4.0,
                                            max_per_core=2)
@@ -480,6 +485,7 @@ def main():
     stream_groups = s.groups()
     wave_mapping = s.problem.wave_mapping
     cost = gathered.cpu().numpy() if world > 1 and rank == 0 else s.scalar("cost")
+    sweeps = None if rehearsal else float(s.ints("bp_calls").mean())  # backward sweeps (lambda retries) per trajectory, last iteration
     s.close()
 
     if rank == 0:
@@ -512,8 +518,9 @@ def main():
             "config": {"workload": "%s batch=%d per GPU x %d GPU, 8-alpha line search, FULL_DDP=%d, "
                                    "first %d iterations after the initial roll-out" % ("CarParking" if car else "Synth16x8", B, world, fd, K),
                        "batch_per_gpu": B, "n_hor": n_hor, "n_x": nx, "n_u": nu, "full_ddp": fd,
-                       "mapping": ("one wavefront per trajectory" if wave_mapping else
+                       "mapping": ("wave mapping (16 lanes per trajectory in the backward step where the problem allows, else one wavefront)" if wave_mapping else
                                    "one lane per trajectory (64 trajectories per wavefront)"),
+                       "backward_sweeps_per_trajectory_in_last_iteration": sweeps,
                        "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split if args.ls_split is not None else "library default (4; 1 in the wave mapping)", "ls_keep": args.ls_keep if args.ls_keep is not None else "library default (2: roll-outs kept, accepted one relocated; 1 in the wave mapping)", "bw_split": args.bw_split, "resweep": args.resweep,
                        "stream_groups": stream_groups,
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},

@@ -1,13 +1,15 @@
-"""per-kernel sums of the counters of rocprofv3 --pmc passes: python pmc_kernels.py [--issue-json FILE STEPS] <dir> [<dir> ...]
+"""per-kernel sums of the counters of rocprofv3 --pmc passes: python pmc_kernels.py [--issue-json FILE STEPS [--sweep-steps X]] <dir> [<dir> ...]
 --issue-json FILE STEPS: also write, per kernel, the vector instructions a wavefront issues per time step (SQ_INSTS_VALU /
 SQ_WAVES / STEPS — STEPS = steps a wavefront of a sweep kernel walks, the horizon) and the fraction of a wavefront's cycles
 in which it issues a vector instruction (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), stamped with the digest of the sources
 (ddp-generator_amd/evidence.py); bench.py puts them into roofline.issue."""
 import csv, glob, json, os, sys, re, collections
 argv = sys.argv[1:]
-issue_json, steps = None, 1
+issue_json, steps, sweep_steps = None, 1, None
 if argv and argv[0] == "--issue-json":
     issue_json, steps, argv = argv[1], int(argv[2]), argv[3:]
+if argv and argv[0] == "--sweep-steps":  # trajectory steps the backward kernels of the run walked (B x N x sweeps per trajectory)
+    sweep_steps, argv = float(argv[1]), argv[2:]
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 for d in argv:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -31,6 +33,10 @@ if issue_json:
                   "active_valu_frac": c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"],
                   "wait_any_frac": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
                   "waves": c["SQ_WAVES"], "valu_insts_total": c.get("SQ_INSTS_VALU", 0.0)}
+        if sweep_steps and k.startswith("k_backward"):
+            # persistent wavefronts (a worker walks many trajectories): per step of a TRAJECTORY instead of per wavefront
+            out[k]["valu_insts_per_trajectory_step"] = c.get("SQ_INSTS_VALU", 0.0) / sweep_steps
+            out[k]["trajectory_steps"] = sweep_steps
     out["_steps"] = steps
     out["_source_sha"] = ev.source_sha()
     out["_counters"] = "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY (separate passes), summed over the run's dispatches of the kernel"

@@ -29,7 +29,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python3 tools/pmc_summary.py --config5-json $OUT/traffic_config5.json 2 $OUT/traffic_synth/FETCH_SIZE $OUT/traffic_synth/WRITE_SIZE > $OUT/traffic_synth.txt 2>&1
-grep -A3 "k_backward_wave\|k_derivs_wave" $OUT/traffic_synth.txt | head -40
+grep -A3 "k_backward_quad\|k_derivs_wave" $OUT/traffic_synth.txt | head -40
 echo "== timelines (kernel trace with time stamps)"
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_car -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-unfused > $OUT/trace_car.log 2>&1 || echo "trace (car) failed"
@@ -45,7 +45,12 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_ACTIVE_IN
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/sq_synth/$n -- python3 $R/bench.py --workload synth --steps 1 --warmup 0 --no-cpu-baseline --no-unfused > $OUT/sq_synth_$n.log 2>&1 || echo "sq $n failed"
 done
 cd $R
-python3 tools/pmc_kernels.py --issue-json $OUT/issue_config5.json 1000 $OUT/sq_synth > $OUT/pmc_config5_sq.txt
+# (trajectory steps the backward kernel walked in the counted run: 16 384 x 1 000 x the sweeps per trajectory its own line reports)
+SW=$(python3 -c "
+import json,sys
+d=json.loads([l for l in open('$OUT/sq_synth_SQ_WAVE_CYCLES.log') if l.startswith('{')][-1])
+print(16384*1000*d['config']['backward_sweeps_per_trajectory_in_last_iteration'])")
+python3 tools/pmc_kernels.py --issue-json $OUT/issue_config5.json 1000 --sweep-steps $SW $OUT/sq_synth > $OUT/pmc_config5_sq.txt
 cat $OUT/pmc_config5_sq.txt | cut -c1-400
 echo "== SQ counters, headline"
 cd /tmp
@@ -60,3 +65,9 @@ echo "== accepted step sizes"
 python3 tools/alpha_hist.py carparking > $OUT/alpha_hist_car.txt 2>&1
 python3 tools/alpha_hist.py synth16x8 > $OUT/alpha_hist_synth.txt 2>&1
 tail -1 $OUT/alpha_hist_car.txt; tail -2 $OUT/alpha_hist_synth.txt
+echo "== section profiles (cycle counters in the kernels; needs the -DILQG_PROFILE_SECTIONS build in ddp-generator_amd/lib_prof, see the scripts)"
+if [ -f $R/ddp-generator_amd/lib_prof/libilqg_synth16x8_fd1_hip.so ]; then
+  ILQG_LIBDIR=$R/ddp-generator_amd/lib_prof timeout -k 10 300 python3 tools/section_profile_quad.py > $OUT/sections_quad.txt 2>&1 || echo "section profile (quad) failed"
+  ILQG_LIBDIR=$R/ddp-generator_amd/lib_prof timeout -k 10 300 python3 tools/section_profile_derivs.py > $OUT/sections_derivs.txt 2>&1 || echo "section profile (derivs) failed"
+  tail -2 $OUT/sections_quad.txt; head -3 $OUT/sections_derivs.txt
+fi
