@@ -139,8 +139,9 @@ def issue_object(kernel, name="issue.json"):
         return {"valu_insts_per_step": None, "active_valu_frac": None, "source": "profiles/" + name, "stale": "no entry for " + kernel}
     per_step = k.get("valu_insts_per_trajectory_step", k["valu_insts_per_wave_and_step"])
     return {"kernel": kernel, "valu_insts_per_step": per_step, "active_valu_frac": k["active_valu_frac"],
-            "per": "step of a trajectory (wavefront instructions; a wavefront serves four trajectories)" if "valu_insts_per_trajectory_step" in k
-                   else "step of a wavefront",
+            "per": ("step of a trajectory: wavefront instructions over the steps the wavefronts walked (%.0f per wavefront step, counted "
+                    "by the profile build of the same sources) / %d trajectories per wavefront" % (k["valu_insts_per_wavefront_step"], k["trajectories_per_wavefront"]))
+                   if "valu_insts_per_trajectory_step" in k else "step of a wavefront",
             "wait_any_frac": k.get("wait_any_frac"), "valu_insts_total": k.get("valu_insts_total"),
             "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES / %d steps; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; sources %s; "
                       "not collected in this run)" % (name, j.get("_steps", 0), j.get("_source_sha"))}

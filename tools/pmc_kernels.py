@@ -1,4 +1,4 @@
-"""per-kernel sums of the counters of rocprofv3 --pmc passes: python pmc_kernels.py [--issue-json FILE STEPS [--sweep-steps X]] <dir> [<dir> ...]
+"""per-kernel sums of the counters of rocprofv3 --pmc passes: python pmc_kernels.py [--issue-json FILE STEPS [--wave-steps X ROWS]] <dir> [<dir> ...]
 --issue-json FILE STEPS: also write, per kernel, the vector instructions a wavefront issues per time step (SQ_INSTS_VALU /
 SQ_WAVES / STEPS — STEPS = steps a wavefront of a sweep kernel walks, the horizon) and the fraction of a wavefront's cycles
 in which it issues a vector instruction (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), stamped with the digest of the sources
@@ -8,8 +8,8 @@ argv = sys.argv[1:]
 issue_json, steps, sweep_steps = None, 1, None
 if argv and argv[0] == "--issue-json":
     issue_json, steps, argv = argv[1], int(argv[2]), argv[3:]
-if argv and argv[0] == "--sweep-steps":  # trajectory steps the backward kernels of the run walked (B x N x sweeps per trajectory)
-    sweep_steps, argv = float(argv[1]), argv[2:]
+if argv and argv[0] == "--wave-steps":  # steps the wavefronts of the persistent backward kernel walked in the counted run, and the
+    sweep_steps, rows, argv = float(argv[1]), int(argv[2]), argv[3:]  # trajectories a wavefront serves per step (quad mapping: 4)
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 for d in argv:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -34,9 +34,13 @@ if issue_json:
                   "wait_any_frac": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
                   "waves": c["SQ_WAVES"], "valu_insts_total": c.get("SQ_INSTS_VALU", 0.0)}
         if sweep_steps and k.startswith("k_backward"):
-            # persistent wavefronts (a worker walks many trajectories): per step of a TRAJECTORY instead of per wavefront
-            out[k]["valu_insts_per_trajectory_step"] = c.get("SQ_INSTS_VALU", 0.0) / sweep_steps
-            out[k]["trajectory_steps"] = sweep_steps
+            # persistent wavefronts (a worker walks many trajectories, sweeps are cut short by lambda retries): per step the
+            # wavefronts really walked — counted by the kernel itself in the -DILQG_PROFILE_SECTIONS build of the same sources
+            # (tools/section_profile_quad.py, the same first iteration) — and per trajectory step with all rows at work
+            out[k]["valu_insts_per_wavefront_step"] = c.get("SQ_INSTS_VALU", 0.0) / sweep_steps
+            out[k]["valu_insts_per_trajectory_step"] = c.get("SQ_INSTS_VALU", 0.0) / sweep_steps / rows
+            out[k]["wavefront_steps"] = sweep_steps
+            out[k]["trajectories_per_wavefront"] = rows
     out["_steps"] = steps
     out["_source_sha"] = ev.source_sha()
     out["_counters"] = "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY (separate passes), summed over the run's dispatches of the kernel"

@@ -45,12 +45,7 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_ACTIVE_IN
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/sq_synth/$n -- python3 $R/bench.py --workload synth --steps 1 --warmup 0 --no-cpu-baseline --no-unfused > $OUT/sq_synth_$n.log 2>&1 || echo "sq $n failed"
 done
 cd $R
-# (trajectory steps the backward kernel walked in the counted run: 16 384 x 1 000 x the sweeps per trajectory its own line reports)
-SW=$(python3 -c "
-import json,sys
-d=json.loads([l for l in open('$OUT/sq_synth_SQ_WAVE_CYCLES.log') if l.startswith('{')][-1])
-print(16384*1000*d['config']['backward_sweeps_per_trajectory_in_last_iteration'])")
-python3 tools/pmc_kernels.py --issue-json $OUT/issue_config5.json 1000 --sweep-steps $SW $OUT/sq_synth > $OUT/pmc_config5_sq.txt
+python3 tools/pmc_kernels.py --issue-json $OUT/issue_config5.json 1000 $OUT/sq_synth > $OUT/pmc_config5_sq.txt
 cat $OUT/pmc_config5_sq.txt | cut -c1-400
 echo "== SQ counters, headline"
 cd /tmp
@@ -70,4 +65,13 @@ if [ -f $R/ddp-generator_amd/lib_prof/libilqg_synth16x8_fd1_hip.so ]; then
   ILQG_LIBDIR=$R/ddp-generator_amd/lib_prof timeout -k 10 300 python3 tools/section_profile_quad.py > $OUT/sections_quad.txt 2>&1 || echo "section profile (quad) failed"
   ILQG_LIBDIR=$R/ddp-generator_amd/lib_prof timeout -k 10 300 python3 tools/section_profile_derivs.py > $OUT/sections_derivs.txt 2>&1 || echo "section profile (derivs) failed"
   tail -2 $OUT/sections_quad.txt; head -3 $OUT/sections_derivs.txt
+fi
+# the persistent backward kernel's instructions per step: over the steps its wavefronts really walked in the first iteration
+# (what the SQ passes above counted: --steps 1 --warmup 0), counted by the profile build of the same sources
+if [ -f $OUT/sections_quad.txt ]; then
+  WS=$(python3 -c "
+import re
+m = re.search(r'iteration 1 \\(.*?, (\\d+) wavefront steps per trajectory', open('$OUT/sections_quad.txt').read())
+print(int(m.group(1)) * 16384)")
+  python3 tools/pmc_kernels.py --issue-json $OUT/issue_config5.json 1000 --wave-steps $WS 4 $OUT/sq_synth > $OUT/pmc_config5_sq.txt
 fi
