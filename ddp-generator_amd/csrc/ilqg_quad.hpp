@@ -382,6 +382,8 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
             double(&gc)[3] = (i % 2) ? gb : ga;
             double(&gn)[3] = (i % 2) ? ga : gb;
             if constexpr(i + 1 < NX) fetch(std::integral_constant<int, i + 1>{}, nxt, gn);
+#ifdef ILQG_STRICT_FP
+            // the reference's two roundings: t->fxx[e] = coefficient * product, then d += Vx[i] * t->fxx[e]
 #pragma unroll
             for(int q = 0; q < NTX; q++) m[q] = cur[q] * gc[0];
 #pragma unroll
@@ -391,6 +393,18 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
             bc_vecs<i, NTC>(dxu, vx, m + NTX + NTU);
             bc_vecs<i, NTU>(duu, vx, m + NTX);
             bc_vecs<i, NTX>(dxx, vx, m);
+#else
+            // product build (FMA contraction anyway): d += coefficient * (Vx[i] * product) — three broadcasts per slice
+            // instead of one per entry, the entries plain multiply-adds: 28 instead of 44 vector instructions per slice
+            double w[3] = {0.0, 0.0, 0.0};
+            bc_vecs<i, 3>(w, vx, gc);
+#pragma unroll
+            for(int q = 0; q < NTC; q++) dxu[q] = __builtin_fma(cur[NTX + NTU + q], w[2], dxu[q]);
+#pragma unroll
+            for(int q = 0; q < NTU; q++) duu[q] = __builtin_fma(cur[NTX + q], w[1], duu[q]);
+#pragma unroll
+            for(int q = 0; q < NTX; q++) dxx[q] = __builtin_fma(cur[q], w[0], dxx[q]);
+#endif
         });
         using lds_pair_w = __attribute__((address_space(3))) dpair;
         lds_pair_w *const pd2 = (lds_pair_w *)(uintptr_t)(rb + c * 16);
@@ -428,12 +442,20 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
         double dsum = 0.0;
 #pragma unroll
         for(int s = 0; s < NX; s++) mac(dsum, fxc[s], t1[s]);  // fx[s, c] T1[s, c]
+#ifdef ILQG_STRICT_FP
 #pragma unroll
         for(int s = 0; s < NX; s++) bc_cols<NX>(a, t1[s], fxc[s]);  // + fx[s, c] T1[s, r]
+        constexpr double HALF = 0.5;
+#else
+        // (product build: fx'(Vxx fx) is symmetric but for rounding — the reference's second half sum, the same entry of
+        // the transpose, and the halving are left out; the FMA-free twin keeps the reference's arithmetic.  Likewise Quu
+        // and K'(Quu K) below: 450 of a wavefront step's 4 350 vector instructions)
+        constexpr double HALF = 1.0;
+#endif
         const LdsBase pd = lds_base(rb + (Q::dxx + bxx) * 8);
 #pragma unroll
         for(int r = 0; r < NX; r++) {
-            double v = cxx_c[r] + a[r] * 0.5;
+            double v = cxx_c[r] + a[r] * HALF;
             if(FULL && FACT) v += pd[r];
             qxx[r] = v;
         }
@@ -504,12 +526,17 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
         double dsum = 0.0;
 #pragma unroll
         for(int s = 0; s < NX; s++) mac(dsum, fuc[s], t2c[s]);
+#ifdef ILQG_STRICT_FP
 #pragma unroll
         for(int s = 0; s < NX; s++) bc_cols<NU>(a, t2c[s], fuc[s]);  // + fu[s, me] T2[s, i]
+        constexpr double HALF = 0.5;
+#else
+        constexpr double HALF = 1.0;
+#endif
         double col[NU];  // Quu[i, me], i < me
 #pragma unroll
         for(int i = 0; i < NU; i++) {
-            double v = cuu_c[i] + a[i] * 0.5;
+            double v = cuu_c[i] + a[i] * HALF;
             if(FULL && FACT) v += duu_c[i];
             col[i] = v;
         }
@@ -607,11 +634,16 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
             for(int s = 0; s < NU; s++) mac(dsum, kt[s], ba[s]);
             vd = vd + dsum;
         }
+#ifdef ILQG_STRICT_FP
 #pragma unroll
         for(int s = 0; s < NU; s++) bc_cols<NX>(a, ba[s], kt[s]);  // + K[s, c] (Quu K)[s, r]
+        constexpr double HALF = 0.5;
+#else
+        constexpr double HALF = 1.0;
+#endif
         double vv[NX];
 #pragma unroll
-        for(int r = 0; r < NX; r++) vv[r] = qxx[r] + a[r] * 0.5;
+        for(int r = 0; r < NX; r++) vv[r] = qxx[r] + a[r] * HALF;
         // the reference's loop nest touches packed entry (r, c) first as (i = r, j = c), then as (i = c, j = r); a
         // diagonal entry once, with the term doubled
 #pragma unroll

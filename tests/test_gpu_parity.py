@@ -741,7 +741,7 @@ def test_quad_mapping_equals_the_row_mapping(ilqg, monkeypatch, fd, strict):
     """The backward pass with 16 lanes per trajectory (ilqg_quad.hpp: four trajectories per wavefront, every 16-lane row
     at its own step, sweep and lambda) against the one-wavefront-per-trajectory row mapping (ILQG_NO_QUAD=1) on a ragged
     batch whose trajectories need different numbers of sweeps: gains, value changes, gradient norms, lambdas, sweep counts
-    and the solves that follow — the same bits in the FMA-free build, to rounding in the product build"""
+    and the solves that follow — the same bits in the FMA-free build, to the single-pass tolerance in the product build"""
     B, N, K = 37, 300, 4
     x0, u0 = syn_inputs(B, N, first=7)
     x0 = x0 * np.linspace(0.2, 3.0, B)[:, None]  # spread: some starts need lambda retries, some none
@@ -767,12 +767,16 @@ def test_quad_mapping_equals_the_row_mapping(ilqg, monkeypatch, fd, strict):
     row = run()
     calls = np.concatenate([o["calls"] for o in quad[:-1]])
     assert calls.min() == 1 and (fd == 0 or calls.max() > 1), np.bincount(calls)
-    for a, b in zip(quad, row):
+    for it, (a, b) in enumerate(zip(quad, row)):
         for k in a:
             if strict or k in ("calls", "rc"):
                 assert np.array_equal(a[k], b[k]), k
             else:
-                assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-12), (k, np.abs(a[k] - b[k]).max())
+                # product builds: the two mappings contract differently (FMA; the quad mapping's product build also takes
+                # ONE of the reference's two half sums of a symmetric product) — the single-pass bar of DESIGN §4 for the
+                # first pass, then the free-running iterations amplify the difference
+                tol = 1e-10 if it == 0 else 1e-7
+                assert np.all(np.abs(a[k] - b[k]) <= tol * np.maximum(1.0, np.abs(b[k]))), (it, k, np.abs(a[k] - b[k]).max())
 
 
 @pytest.mark.parametrize("strict", [True, False])
