@@ -615,35 +615,37 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
     // ---- Vx, Vxx with the unregularised Quu / Qxu (back_pass.c:219-241)
     {
         // Vx[c] = Qx[c] + K[:, c]'(Quu l) + K[:, c]'Qu + Qxu[c, :] l
+#ifdef ILQG_STRICT_FP
         double d = 0.0;
         bc_dot<NU>(d, bcl, kt);
         double vxn = qxl + d;
         bc_dot<NU>(vxn, qul, kt);
+#else
+        double vxn = qxl;  // (product build: K'(Quu l + Qu) in one pass)
+        const double bq = bcl + qul;
+        bc_dot<NU>(vxn, bq, kt);
+#endif
         bc_dot<NU>(vxn, ll, qxu);
 
         // Vxx[r, c], r < c, and the diagonal entry apart
+        double vd = qxx_d;
+        double vv[NX];
+#ifdef ILQG_STRICT_FP
         double a[NX];
 #pragma unroll
         for(int r = 0; r < NX; r++) a[r] = 0.0;
 #pragma unroll
         for(int s = 0; s < NU; s++) bc_cols<NX>(a, kt[s], ba[s]);  // K[s, r] (Quu K)[s, c], all r
-        double vd = qxx_d;
         {
             double dsum = 0.0;
 #pragma unroll
             for(int s = 0; s < NU; s++) mac(dsum, kt[s], ba[s]);
             vd = vd + dsum;
         }
-#ifdef ILQG_STRICT_FP
 #pragma unroll
         for(int s = 0; s < NU; s++) bc_cols<NX>(a, ba[s], kt[s]);  // + K[s, c] (Quu K)[s, r]
-        constexpr double HALF = 0.5;
-#else
-        constexpr double HALF = 1.0;
-#endif
-        double vv[NX];
 #pragma unroll
-        for(int r = 0; r < NX; r++) vv[r] = qxx[r] + a[r] * HALF;
+        for(int r = 0; r < NX; r++) vv[r] = qxx[r] + a[r] * 0.5;
         // the reference's loop nest touches packed entry (r, c) first as (i = r, j = c), then as (i = c, j = r); a
         // diagonal entry once, with the term doubled
 #pragma unroll
@@ -652,6 +654,21 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
         for(int q = 0; q < NU; q++) bc_cols<NX>(vv, qxu[q], kt[q]);  // K[q, c] Qxu[r, q]
 #pragma unroll
         for(int q = 0; q < NU; q++) mac(vd, kt[q], qxu[q] * 2.0);
+#else
+        // product build: K'(Quu K) + K'Qxu' + Qxu K = K'(Quu K + Qxu') + Qxu K — two passes over the inputs instead of
+        // the reference's four (the first half sum of the symmetric term alone, like Qxx and Quu)
+        double wq[NU];  // (Quu K + Qxu')[q, c]
+#pragma unroll
+        for(int q = 0; q < NU; q++) wq[q] = ba[q] + qxu[q];
+#pragma unroll
+        for(int r = 0; r < NX; r++) vv[r] = qxx[r];
+#pragma unroll
+        for(int q = 0; q < NU; q++) bc_cols<NX>(vv, kt[q], wq[q]);   // K[q, r] (Quu K + Qxu')[q, c]
+#pragma unroll
+        for(int q = 0; q < NU; q++) bc_cols<NX>(vv, qxu[q], kt[q]);  // Qxu[r, q] K[q, c]
+#pragma unroll
+        for(int q = 0; q < NU; q++) mac(vd, kt[q], wq[q] + qxu[q]);  // K[q, c] (Quu K)[q, c] + 2 K[q, c] Qxu[c, q]
+#endif
         // columns -> full columns: every lane lays down its column, the diagonal entry on top, and reads its row
         wave_sync();
         {
