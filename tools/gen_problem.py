@@ -468,7 +468,7 @@ class Emitter:
         """the entry is the last one of a piece of a run (see _record_runs): the next one is assigned behind its guard"""
         m = re.fullmatch(r"t->(\w+)\[(\d+)\]", lhs)
         place = self.record_offsets()
-        return bool(m and m.group(1) in place and (place[m.group(1)] + int(m.group(2)) + 1) % self.RUN_PIECE == 0)
+        return bool(m and m.group(1) in place and (place[m.group(1)] + int(m.group(2)) + 1) % self.RUN_MAX == 0)
 
     @staticmethod
     def _neighbours(l1, l2):
@@ -886,16 +886,13 @@ int calc_derivs(tOptSet *o) {
         return out
 
     # Runs of neighbouring record entries that bp_derivsL_first assigns one after the other (all of fx, fu, cx, cu of a
-    # typical problem) are written through ILQG_REC(member, index), in pieces of at most RUN_PIECE entries marked by
-    # ILQG_REC_PIECE / ILQG_REC_WRITE (see _record_runs; ILQG_REC_DONE: a piece at the end of a function).  By default that
-    # is the plain assignment t->member[index]= ... and nothing; a batched back-end whose lanes each own a record may
-    # collect a piece on chip and store it as whole cache lines.
-    RUN_MIN, RUN_PIECE = 8, 32
-    RECORD_MACROS = ("#ifndef ILQG_REC  /* a back-end may define these four before including this file */\n"
+    # typical problem) are written through ILQG_REC(member, index), each run closed by ILQG_REC_DONE(member, first, count)
+    # in pieces of at most RUN_MAX entries.  By default that is the plain assignment t->member[index]= ...; a batched
+    # back-end whose lanes each own a record may collect a run on chip and store it as whole cache lines.
+    RUN_MIN, RUN_MAX = 8, 64
+    RECORD_MACROS = ("#ifndef ILQG_REC  /* a back-end may define these two before including this file */\n"
                      "#define ILQG_REC(member, index) t->member[index]\n"
-                     "#define ILQG_REC_PIECE(member, first, count)  /* entries first .. first+count-1 have been assigned */\n"
-                     "#define ILQG_REC_WRITE(member, first, count, part)  /* a good place to store an eighth of that piece */\n"
-                     "#define ILQG_REC_DONE(member, first, count)  /* ... assigned, and nothing follows to hide its stores behind */\n"
+                     "#define ILQG_REC_DONE(member, first, count)  /* entries first .. first+count-1 have been assigned */\n"
                      "#endif\n")
 
     @staticmethod
@@ -940,13 +937,9 @@ int calc_derivs(tOptSet *o) {
 
     def _record_runs(self, text):
         """A run: entries assigned one after the other that are neighbours in the ELEMENT (fx[255] and fu[0] are), at
-        least RUN_MIN of them.  It is cut into pieces that end where the place in the element is a multiple of RUN_PIECE
-        (a back-end that writes a piece as whole cache lines meets every line once), each piece named by its first entry;
-        the count may reach into the next member.  ILQG_REC_PIECE(member, index, count) stands behind a piece's last
-        guard; the eight ILQG_REC_WRITE(member, index, count, part) of a piece are spread over the assignments of the NEXT
-        piece, one behind every fourth (a back-end that stores a piece from on-chip memory can issue an eighth of the
-        stores there: they travel while the arithmetic goes on); what is left of them stands at the next piece's end, in
-        front of a piece that would use the same half of a 2 x RUN_PIECE ring, and at the end of the function."""
+        least RUN_MIN of them.  It is closed in pieces that end where the place in the element is a multiple of RUN_MAX
+        (so a back-end that writes a piece as whole cache lines meets every line once), each piece named by its first
+        entry: ILQG_REC_DONE(member, index, count) — the count may reach into the next member."""
         lines = text.split("\n")
         place = self.record_offsets()
         seq = []  # (member, index) in the order of their assignments
@@ -964,62 +957,33 @@ int calc_derivs(tOptSet *o) {
                 a = i
                 while a <= j:
                     e = a
-                    while e < j and (at(seq[e]) + 1) % self.RUN_PIECE != 0:
+                    while e < j and (at(seq[e]) + 1) % self.RUN_MAX != 0:
                         e += 1
-                    if j - e < self.RUN_MIN and j - a + 1 <= self.RUN_PIECE:
-                        e = j  # (a few entries behind the boundary stay with the piece)
                     pieces.append(seq[a:e + 1])
                     a = e + 1
             i = j + 1
         staged = {e: pc for pc in map(tuple, pieces) for e in pc}
         self.direct_entries = getattr(self, "direct_entries", []) + [e for e in seq if e not in staged]
-        out, last_line, first_line = [], {}, {}
+        out, last_line = [], {}
         for n_, ln in enumerate(lines):
             def sub(mo):
                 key = (mo.group(1), int(mo.group(2)))
                 if key in staged:
-                    last_line[key] = n_
-                    first_line.setdefault(staged[key], n_)
+                    last_line[staged[key]] = n_
                     return "ILQG_REC(%s, %d)" % key
                 return mo.group(0)
             # (not inside the guard's message: it names the entry as the reference's files do)
             parts = re.split(r'("(?:[^"\\]|\\.)*")', ln)
             out.append("".join(q if q.startswith('"') else re.sub(r"t->(\w+)\[(\d+)\]", sub, q) for q in parts))
-        ends = {}  # line -> entries whose last mention it is
-        for e, n_ in last_line.items():
-            ends.setdefault(n_, []).append(e)
-        starts = {n_: pc for pc, n_ in first_line.items()}
-        name = lambda pc: "%s, %d, %d" % (pc[0][0], pc[0][1], len(pc))
-        PARTS = 8
-        res, pending, written, complete = [], None, 0, {}
-
-        def rest():
-            nonlocal written
-            while pending is not None and written < PARTS:
-                res.append("    ILQG_REC_WRITE(%s, %d)" % (name(pending), written))
-                written += 1
-
+        done = {}
+        for pc, n_ in last_line.items():
+            done.setdefault(n_, []).append(pc)
+        res = []
         for n_, ln in enumerate(out):
-            pc = starts.get(n_)
-            halves = lambda q: {(at(e) // self.RUN_PIECE) % 2 for e in q}
-            if pc is not None and pending is not None and halves(pc) & halves(pending):
-                rest()  # the new piece takes (part of) the half of the ring the pending one lies in
             res.append(ln)
-            for e in ends.get(n_, []):
-                pc = staged[e]
-                complete[pc] = complete.get(pc, 0) + 1
-                if pending is not None and pending != pc and complete[pc] % 4 == 0 and written < PARTS:
-                    res.append("    ILQG_REC_WRITE(%s, %d)" % (name(pending), written))
-                    written += 1
-                if complete[pc] == len(pc):
-                    rest()
-                    res.append("    ILQG_REC_PIECE(%s)" % name(pc))
-                    pending, written = pc, 0
-        tail = []
-        while res and res[-1].strip() == "":
-            tail.append(res.pop())
-        rest()
-        return "\n".join(res + tail)
+            for pc in sorted(done.get(n_, []), key=lambda r: at(r[0])):
+                res.append("    ILQG_REC_DONE(%s, %d, %d)" % (pc[0][0], pc[0][1], len(pc)))
+        return "\n".join(res)
 
     def time_varying_list(self, full):
         """the entries emit_derivatives() assigns in bp_derivsL, as X(member, index) ..."""
