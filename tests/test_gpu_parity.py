@@ -1131,6 +1131,27 @@ def test_results_do_not_depend_on_stream_groups(ilqg, synth):
         s.close()
 
 
+def test_wave_mapping_results_do_not_depend_on_stream_groups(ilqg):
+    """the same for the wave mapping (n = 16 problem): several contexts share the device's work buffer, the roll-out stream
+    and — for the kernels with scratch memory — that stream's queue (on_scratch_stream); ragged group sizes, a horizon
+    that lets wavefronts of the derivative kernel straddle trajectories"""
+    B, N, iters = 150, 40, 4
+    x0, u0 = syn_inputs(B, N)
+    ref = None
+    for groups in (1, 2, 3):
+        s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters + 1), groups=groups)
+        assert s.groups() == groups
+        s.init(x0, u0)
+        s.iterate(iters)
+        out = (s.scalar("cost"), s.scalar("lambda"), s.x(), s.u(), s.ints("alpha_idx"), s.ints("status"), s.ints("bp_calls"))
+        s.close()
+        if ref is None:
+            ref = out
+        else:
+            for a, r in zip(out, ref):
+                assert np.array_equal(a, r)
+
+
 def test_huge_angle_goes_through_the_library_sincos(ilqg, synth, oracle_built):
     """sin/cos of the generated callbacks are straight-line code for |x| < 8e5; beyond that the step is evaluated
     a second time through the device library (the `huge` hook).  A heading angle of 1e7 rad in ONE trajectory of
