@@ -137,7 +137,12 @@ def issue_object(kernel, name="issue.json"):
     k = j.get(kernel)
     if not k:
         return {"valu_insts_per_step": None, "active_valu_frac": None, "source": "profiles/" + name, "stale": "no entry for " + kernel}
-    per_step = k.get("valu_insts_per_trajectory_step", k["valu_insts_per_wave_and_step"])
+    if "valu_insts_per_trajectory_step" not in k and k.get("persistent"):
+        # a persistent kernel's wavefronts walk many trajectories and sweeps: instructions / (wavefronts x n_hor) means
+        # nothing; only the profile build's count of the steps walked (--wave-steps) makes a per-step figure
+        return {"kernel": kernel, "valu_insts_per_step": None, "active_valu_frac": k["active_valu_frac"], "wait_any_frac": k.get("wait_any_frac"),
+                "source": "profiles/" + name, "stale": "no step count of the persistent kernel in this file (tools/round_profile.sh, --wave-steps)"}
+    per_step = k.get("valu_insts_per_trajectory_step", k.get("valu_insts_per_wave_and_step"))
     return {"kernel": kernel, "valu_insts_per_step": per_step, "active_valu_frac": k["active_valu_frac"],
             "per": ("step of a trajectory: wavefront instructions over the steps the wavefronts walked (%.0f per wavefront step, counted "
                     "by the profile build of the same sources) / %d trajectories per wavefront" % (k["valu_insts_per_wavefront_step"], k["trajectories_per_wavefront"]))
@@ -168,12 +173,33 @@ def kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, iters, **op
     return t
 
 
-def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
-    """BASELINE config 5: synthetic n=16, m=8, N=1000, FULL_DDP=1, 16 384 trajectories (wave mapping: 16 lanes per trajectory)"""
+CONFIG5_VARIANTS = {
+    # problem library, committed PMC passes, issue figures, kernels, mapping
+    "factored": ("synth16x8", "traffic_config5.json", ("k_backward_quad<true>", "issue_config5.json"),
+                 "k_derivs_wave + k_backward_quad + roll-outs",
+                 "quad mapping: 16 lanes per trajectory in the backward step, four trajectories per wavefront, "
+                 "each 16-lane row a worker that takes trajectories from a queue (k_backward_quad); records carry "
+                 "the first-order derivatives and the 32 products the tensors are multiples of (factored tensor "
+                 "tables of the generated file), written as whole cache lines from LDS (k_derivs_wave), the "
+                 "backward step multiplies the tensors out"),
+    # the same problem emitted WITHOUT any additive hint or table (tools/gen_problem.py --plain): what a
+    # Maxima / gentran-written pair looks like to the kernels — every tensor entry stored in the record and read back
+    "stored": ("synth16x8_plain", "traffic_config5_stored.json", ("k_backward_wave<false>", "issue_config5_stored.json"),
+               "k_derivs_wave<false> + k_backward_wave<false> + roll-outs",
+               "row mapping: one wavefront per trajectory in the backward step (k_backward_wave), records are the "
+               "reference's trajEl_t with the tensors fxx / fuu / fxu stored by the generated bp_derivsL (47.9 KB per "
+               "step) and contracted from HBM (back_pass.c:95-131): the path of a generated pair without hints"),
+}
+
+
+def config5(ilqg, synth, local, K=3, W=1, with_cpu=True, variant="factored"):
+    """BASELINE config 5: synthetic n=16, m=8, N=1000, FULL_DDP=1, 16 384 trajectories (wave mapping: 16 lanes per trajectory).
+    variant "stored": the hint-free pair of the same problem (stored tensors)"""
     B, N, nx, nu = 16384, 1000, 16, 8
+    problem, traffic_file, (issue_kernel, issue_file), kernels_label, mapping = CONFIG5_VARIANTS[variant]
     alg = algorithmic_bytes(nx, nu, 1)
     x0, u0 = synth.synth16_batch(B, N)
-    s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, device=local, params=synth.SYNTH16_PARAMS,
+    s = ilqg.BatchSolver(problem, 1, batch=B, n_hor=N, device=local, params=synth.SYNTH16_PARAMS,
                          opts=dict(max_iter=K + W + 1))
     s.init(x0, u0)
     if W > 0:
@@ -197,14 +223,14 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
     flops = backpass_flops(nx, nu, 1) * N * B  # one sweep per iteration; lambda retries repeat (parts of) it
     # what an iteration really moves: PMC passes of `bench.py --workload synth` (tools/round_profile.sh), committed
     traffic, traffic_detail = None, None
-    tj, why = stamped("traffic_config5.json")
+    tj, why = stamped(traffic_file)
     if tj is None:
         traffic_detail = {"stale": why}
     else:
         traffic = tj["iteration"]["hbm_bytes"]
-        traffic_detail = {"source": "profiles/traffic_config5.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+        traffic_detail = {"source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                     "`bench.py --workload synth`, FETCH_SIZE x2 + WRITE_SIZE, every kernel of an iteration; sources "
-                                    "%s; not collected in this run)" % tj.get("_source_sha"),
+                                    "%s; not collected in this run)" % (traffic_file, tj.get("_source_sha")),
                           "hbm_GBs": traffic * it_s / 1e9, "hbm_frac_of_peak": traffic * it_s / 1e9 / HBM_PEAK_GBS,
                           "per_kernel": {k: {"hbm_bytes_per_iteration": v["hbm_bytes_per_launch"] * v["launches_per_iteration"]}
                                          for k, v in tj.items() if k not in ("iteration", "_source_sha")}}
@@ -213,20 +239,25 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
         "value": it_s, "unit": "iterations/s", "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "dtype": "f64",
         "config": {"workload": "Synth16x8 batch=16384, 8-alpha line search, FULL_DDP=1, first %d iterations after the "
                                "initial roll-out" % K,
-                   "mapping": "quad mapping: 16 lanes per trajectory in the backward step, four trajectories per wavefront, "
-                              "each 16-lane row a worker that takes trajectories from a queue (k_backward_quad); records carry "
-                              "the first-order derivatives and the 32 products the tensors are multiples of (factored tensor "
-                              "tables of the generated file), written as whole cache lines from LDS (k_derivs_wave), the "
-                              "backward step multiplies the tensors out",
+                   "problem_library": problem, "mapping": mapping,
                    "backward_sweeps_per_trajectory_in_last_iteration": sweeps},
-        "roofline": {"bound": "hbm", "kernel": "iteration (k_derivs_wave + k_backward_quad + roll-outs)",
-                     "achieved": iter_bytes * it_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": iter_bytes * it_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
+        # frac / achieved: what the iteration REALLY moves (PMC bytes of the committed passes x iterations/s) against the
+        # peak — a utilisation.  The contract's algorithmic figure (SURVEY 8(d)'s bytes with every tensor materialised) is
+        # an HBM-EQUIVALENT and sits beside it under its own name: the factored path never moves those bytes, so it may
+        # pass 1.
+        "roofline": {"bound": "hbm", "kernel": "iteration (%s)" % kernels_label,
+                     "achieved": (traffic * it_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (traffic * it_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "frac_kind": "HBM utilisation: PMC bytes per iteration (`traffic`) x iterations/s / peak" if traffic else
+                                  "null: no PMC traffic collected on these sources (traffic_detail.stale); see hbm_equivalent_frac",
+                     "traffic": traffic, "traffic_detail": traffic_detail,
+                     "hbm_equivalent_GBs": iter_bytes * it_s / 1e9, "hbm_equivalent_frac": iter_bytes * it_s / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_iteration": iter_bytes,
-                     "note": "SURVEY 8(d): 91 200 algorithmic bytes per step and trajectory with the tensors "
-                             "materialised (1.49 TB per iteration, ceiling 5.4 it/s); the factored path moves ~7 KB per "
-                             "step instead of 44 KB, the number is the HBM-equivalent rate.  Kernel launches of "
-                             "consecutive chunks overlap on two streams, so no per-launch figure is given.",
+                     "note": "hbm_equivalent_*: SURVEY 8(d)'s 91 200 algorithmic bytes per step and trajectory with the "
+                             "tensors materialised (1.49 TB per iteration, ceiling 5.4 it/s) x iterations/s — the contract's "
+                             "recipe; with factored tensors the path moves ~7 KB per step instead of 44 KB, so the equivalent "
+                             "is not a utilisation.  Kernel launches of consecutive chunks overlap on two streams, so no "
+                             "per-launch figure is given.",
                      "backward_fp64": {"algorithmic_TFLOPs": flops * it_s / 1e12, "peak": FP64_PEAK_TFLOPS,
                                        "frac": flops * it_s / 1e12 / FP64_PEAK_TFLOPS,
                                        "note": "reference back_pass arithmetic, one sweep per iteration, over the WHOLE "
@@ -237,7 +268,7 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True):
         "kernels_ms_per_iteration_sum_of_spans": {k: v[1] / K for k, v in times.items() if v[0]},
         "trajectories_still_active": int(active), "cost_mean_after_window": cost,
     }
-    out["roofline"]["issue"] = issue_object("k_backward_quad<true>", "issue_config5.json")
+    out["roofline"]["issue"] = issue_object(issue_kernel, issue_file)
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(B, K, "synth16x8", 1, synth.SYNTH16_PARAMS, N, synth.synth16_batch, budget_s=4.0,
                                            max_per_core=2)
@@ -427,6 +458,21 @@ def main():
         args.no_unfused = args.no_cpu_baseline = True  # (nothing of the product runs)
     if args.all_on_device is not None:
         local = args.all_on_device
+    device_note = None
+    if not rehearsal:
+        # LOCAL_RANK is the device ordinal only while the rank sees all GPUs of the node; a launcher that narrows
+        # HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank leaves ONE visible device, ordinal 0
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            raise SystemExit("bench.py: no GPU visible to rank %d (HIP_VISIBLE_DEVICES=%r)" % (rank, os.environ.get("HIP_VISIBLE_DEVICES")))
+        if local >= ndev:
+            if ndev == 1 and args.all_on_device is None:
+                device_note = "LOCAL_RANK %d with one visible device: the launcher gave this rank its own GPU, ordinal 0" % local
+                local = 0
+            else:
+                raise SystemExit("bench.py: rank %d has LOCAL_RANK / device %d but only %d device(s) are visible "
+                                 "(HIP_VISIBLE_DEVICES=%r): launch one rank per visible GPU, or give every rank exactly one"
+                                 % (rank, local, ndev, os.environ.get("HIP_VISIBLE_DEVICES")))
     host_collective = args.backend == "gloo" or rehearsal  # the collective's tensors live in host memory
     if world > 1:
         pkg.dist.init("gloo" if rehearsal else args.backend, rank, world, None if host_collective else torch.device("cuda", local))
@@ -523,7 +569,10 @@ def main():
                                    "one lane per trajectory (64 trajectories per wavefront)"),
                        "backward_sweeps_per_trajectory_in_last_iteration": sweeps,
                        "fuse_derivs": args.fuse_derivs, "ls_split": args.ls_split if args.ls_split is not None else "library default (4; 1 in the wave mapping)", "ls_keep": args.ls_keep if args.ls_keep is not None else "library default (2: roll-outs kept, accepted one relocated; 1 in the wave mapping)", "bw_split": args.bw_split, "resweep": args.resweep,
-                       "stream_groups": stream_groups,
+                       "stream_groups": stream_groups, "device_ordinal_of_rank_0": local,
+                       # switches of the environment the library reads when a context is made (comparison runs): none in a default run
+                       "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ILQG_") or k == "GPU_MAX_HW_QUEUES"},
+                       **({"device_note": device_note} if device_note else {}),
                        "parallelism": "batch sharded over %d GPU, one RCCL gather of costs" % world},
             # PRIMARY: the whole iteration against the HBM roofline, algorithmic bytes of SURVEY 8(d)
             "iteration_roofline": {"bound": "hbm", "algorithmic_bytes_per_iteration": iter_bytes,
@@ -537,7 +586,7 @@ def main():
             "cost_mean_after_window": float(cost.mean()),
         }
         secondary = world == 1 and not args.no_unfused and not wave_mapping and car
-        if world == 1 and not wave_mapping and car:
+        if not rehearsal and not wave_mapping and car:  # (at N > 1: rank 0's own launches, its shard of the batch)
             # The two dominant launches IN THE TIMED WINDOW (HIP events on the solver's streams around every launch of the
             # K timed iterations; the groups of trajectories overlap, a launch covers one group):
             #   hbm_equivalent  SURVEY 8(d)'s algorithmic bytes of the stages the launch replaces / its duration (the
@@ -593,6 +642,9 @@ def main():
                     "achieved": bw["hbm_equivalent"]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": bw["hbm_equivalent"]["frac_of_peak"],
                     "traffic": bw.get("pmc", {}).get("hbm_bytes_per_launch"),
+                    "frac_kind": "hbm_equivalent: ALGORITHMIC bytes of the launch / its duration / peak (the contract's recipe); "
+                                 "the launch's real HBM utilisation is hbm_utilisation_frac",
+                    "hbm_utilisation_frac": bw.get("pmc", {}).get("frac_of_peak"),
                     "limiter": "valu_issue (fp64 vector instruction issue of ONE wavefront per SIMD, and the divergence of the box QP)",
                     "issue": issue_object("k_backward<2>"),
                     "dominant_launch": bw, "second_launch": st1,
@@ -649,21 +701,26 @@ def main():
                     out["config5"] = config5(ilqg, synth, local, with_cpu=not args.no_cpu_baseline)
                 except Exception as e:
                     out["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                try:
+                    out["config5_stored"] = config5(ilqg, synth, local, K=2, W=1, with_cpu=False, variant="stored")
+                except Exception as e:
+                    out["config5_stored"] = {"error": "%s: %s" % (type(e).__name__, e)}
         elif not car:
             flops = backpass_flops(nx, nu, fd) * n_hor * B
             out["roofline"] = {"bound": "hbm", "kernel": "iteration", "achieved": iter_bytes * (K / dt) / world / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": iter_bytes * (K / dt) / world / 1e9 / HBM_PEAK_GBS,
                                "traffic": None, "backward_fp64_frac": flops * (K / dt) / world / 1e12 / FP64_PEAK_TFLOPS}
-        if "roofline" not in out:  # N > 1, or the secondary runs were switched off: the iteration-level figure
+        if "roofline" not in out:  # the protocol rehearsal, or kernel timing unavailable: the iteration-level figure
             out["roofline"] = {"bound": "hbm", "kernel": "iteration", "achieved": out["iteration_roofline"]["achieved_GBs"],
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["iteration_roofline"]["frac_of_peak"],
                                "traffic": None, "note": "per GPU; algorithmic bytes of SURVEY 8(d) per iteration x "
-                                                        "iterations/s.  The per-kernel figures are measured at N = 1."}
-        if world == 1 and not args.no_cpu_baseline:
+                                                        "iterations/s."}
+        if not args.no_cpu_baseline:  # rank 0, whatever the world size: the host's cores are the same
             out["cpu_baseline"] = cpu_baseline(B, K, problem, fd, params, n_hor,
                                                synth.car_batch if car else synth.synth16_batch)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # (rank 0 may still have been timing the CPU baseline)
         dist.destroy_process_group()
 
 

@@ -49,17 +49,46 @@ __host__ __device__ constexpr int sy(int i, int j) { return i > j ? ut(j, i) : u
 // ---------------------------------------------------------------------------
 // matMult.c
 // ---------------------------------------------------------------------------
-// base[c] += sum_r a[r] * b[r + c*NR]
-template <int NR, int NC>
+// Structural zeros of the step's record.  For CarParking 27 of the 55 entries of a record are identically 0 (fx: 7 of
+// 16, fu: 4 of 8, cxx: 8 of 10, all of cxu, ...; the generated header lists them, ILQG_STRUCTURAL_ZERO, beside the list
+// of the entries bp_derivsL writes).  IEEE arithmetic does not let the optimiser drop `acc + x * 0.0` even where it sees
+// the constant (x may be Inf or NaN, acc may be -0.0), so the dense loops of matMult.c spend a multiply-add on every one
+// of them.  A caller that knows the zeros (Z::at(i): entry i of the record, in RecLayout's numbering, is identically 0)
+// has those terms left out — decided at compile time once the loops are unrolled, never at run time.  With finite
+// operands the result is the reference's bit for bit but for the sign of a zero sum; an Inf or NaN in the OTHER factor no
+// longer reaches the sum through a structural zero (it still does through every other term).  The FMA-free twin
+// (ILQG_STRICT_FP, the bit-for-bit tests) and every caller without the list keep the dense form.
+// (Tried first: `if(__builtin_constant_p(b) && b == 0.0)` per term, which needs no list — the undecided llvm.is.constant
+// branches keep SROA from dissolving the step's arrays, 1 120 bytes of scratch per lane; `#pragma float_control` for the
+// no-signed-zeros / no-NaN flags — "not supported on this target".)
+struct NoZeros {
+    static constexpr bool at(int) { return false; }
+};
+// term a * b of a sum, where b is entry I of the record (I < 0: not a record entry)
+template <class Z>
+ILQG_DEV double mad(const double acc, const double a, const double b, const int I) {
+    if(I >= 0 && Z::at(I)) return acc;
+    return acc + a * b;
+}
+// base + v, where base started as entry I of the record
+template <class Z>
+ILQG_DEV double plus(const double base, const double v, const int I) {
+    if(I >= 0 && Z::at(I)) return v;
+    return base + v;
+}
+
+// base[c] += sum_r a[r] * b[r + c*NR]                 (BO: b is the record from entry BO on, or -1)
+template <int NR, int NC, class Z = NoZeros, int BO = -1>
 ILQG_DEV void add_mul_vec(double *base, const double *a, const double *b) {
 #pragma unroll
     for(int c = 0; c < NC; c++)
 #pragma unroll
-        for(int r = 0; r < NR; r++) base[c] += a[r] * b[r + c * NR];
+        for(int r = 0; r < NR; r++) base[c] = mad<Z>(base[c], a[r], b[r + c * NR], BO < 0 ? -1 : BO + r + c * NR);
 }
 
 // packed-upper base (NC x NC) += A' B A, B packed symmetric NR x NR, A is NR x NC
-template <int NR, int NC>
+// (AO: A is the record from entry AO on; SO: base started as the record's entries from SO on; -1: neither)
+template <int NR, int NC, class Z = NoZeros, int AO = -1, int SO = -1>
 ILQG_DEV void add_square_tri(double *base, const double *B, const double *A) {
     double ba[NR * NC];
 #pragma unroll
@@ -68,7 +97,7 @@ ILQG_DEV void add_square_tri(double *base, const double *B, const double *A) {
         for(int c = 0; c < NC; c++) {
             double acc = 0.0;
 #pragma unroll
-            for(int s = 0; s < NR; s++) acc += B[sy(r, s)] * A[s + c * NR];
+            for(int s = 0; s < NR; s++) acc = mad<Z>(acc, B[sy(r, s)], A[s + c * NR], AO < 0 ? -1 : AO + s + c * NR);
             ba[r + c * NR] = acc;
         }
 #pragma unroll
@@ -77,18 +106,18 @@ ILQG_DEV void add_square_tri(double *base, const double *B, const double *A) {
         for(int r = 0; r <= c; r++) {
             double acc = 0.0;
 #pragma unroll
-            for(int s = 0; s < NR; s++) acc += A[s + r * NR] * ba[s + c * NR];
+            for(int s = 0; s < NR; s++) acc = mad<Z>(acc, ba[s + c * NR], A[s + r * NR], AO < 0 ? -1 : AO + s + r * NR);
             if(r != c) {
 #pragma unroll
-                for(int s = 0; s < NR; s++) acc += A[s + c * NR] * ba[s + r * NR];
+                for(int s = 0; s < NR; s++) acc = mad<Z>(acc, ba[s + r * NR], A[s + c * NR], AO < 0 ? -1 : AO + s + c * NR);
                 acc *= 0.5;
             }
-            base[ut(r, c)] += acc;
+            base[ut(r, c)] = plus<Z>(base[ut(r, c)], acc, SO < 0 ? -1 : SO + ut(r, c));
         }
 }
 
 // full base (NCA x NCC) += A' B C, B packed symmetric NRA x NRA, A is NRA x NCA, C is NRA x NCC
-template <int NRA, int NCA, int NCC>
+template <int NRA, int NCA, int NCC, class Z = NoZeros, int AO = -1, int CO = -1, int SO = -1>
 ILQG_DEV void add_mul2_tri(double *base, const double *B, const double *A, const double *C) {
     double bc[NRA * NCC];
 #pragma unroll
@@ -97,7 +126,7 @@ ILQG_DEV void add_mul2_tri(double *base, const double *B, const double *A, const
         for(int q = 0; q < NCC; q++) {
             double acc = 0.0;
 #pragma unroll
-            for(int s = 0; s < NRA; s++) acc += B[sy(r, s)] * C[s + q * NRA];
+            for(int s = 0; s < NRA; s++) acc = mad<Z>(acc, B[sy(r, s)], C[s + q * NRA], CO < 0 ? -1 : CO + s + q * NRA);
             bc[r + q * NRA] = acc;
         }
 #pragma unroll
@@ -106,8 +135,8 @@ ILQG_DEV void add_mul2_tri(double *base, const double *B, const double *A, const
         for(int q = 0; q < NCC; q++) {
             double acc = 0.0;
 #pragma unroll
-            for(int s = 0; s < NRA; s++) acc += A[s + r * NRA] * bc[s + q * NRA];
-            base[r + q * NCA] += acc;
+            for(int s = 0; s < NRA; s++) acc = mad<Z>(acc, bc[s + q * NRA], A[s + r * NRA], AO < 0 ? -1 : AO + s + r * NRA);
+            base[r + q * NCA] = plus<Z>(base[r + q * NCA], acc, SO < 0 ? -1 : SO + r + q * NCA);
         }
 }
 
@@ -786,13 +815,16 @@ struct RecLayout {
     static constexpr int UHX = LHX + NXU;
     static constexpr int HOST_SIZE = UHX + NXU;              // what the host always exchanges
     static constexpr int SIZE = HX ? HOST_SIZE : FULL_END;   // what the device stores per step
+    // (by member name of trajEl_t, for lists X(member, index) of the generated header)
+    static constexpr int off_cx = CX, off_cxx = CXX, off_cu = CU, off_cuu = CUU, off_cxu = CXU, off_fx = FX, off_fu = FU, off_fxx = FXX,
+                         off_fuu = FUU, off_fxu = FXU;
 };
 
 // r: derivative record of this step (registers), uk: nominal control,
 // Vx/Vxx: value function of step k+1 in, of step k out, l: warm start in /
 // feed-forward out, K: feedback gains out (NU x NX column-major).
 // Returns the box-QP code (< 1 means the sweep must be abandoned: the outputs are then meaningless).
-template <int NX, int NU, bool FULL, bool HX>
+template <int NX, int NU, bool FULL, bool HX, class Z = NoZeros>
 ILQG_DEV int back_step(const double *r, const double *uk, double *Vx, double *Vxx, double *l, double *K,
                        const double lambda, const int regType, double &dV0, double &dV1, double &gsum,
                        Prof *pf = nullptr) {
@@ -804,47 +836,47 @@ ILQG_DEV int back_step(const double *r, const double *uk, double *Vx, double *Vx
     double Qu[NU], Qx[NX], Qxu[NXU], Quu[SUU], Qxx[SXX];
 #pragma unroll
     for(int i = 0; i < NU; i++) Qu[i] = cu[i];
-    add_mul_vec<NX, NU>(Qu, Vx, fu);
+    add_mul_vec<NX, NU, Z, R::FU>(Qu, Vx, fu);
 #pragma unroll
     for(int i = 0; i < NX; i++) Qx[i] = cx[i];
-    add_mul_vec<NX, NX>(Qx, Vx, fx);
+    add_mul_vec<NX, NX, Z, R::FX>(Qx, Vx, fx);
 
 #pragma unroll
     for(int i = 0; i < NXU; i++) Qxu[i] = cxu[i];
-    add_mul2_tri<NX, NX, NU>(Qxu, Vxx, fx, fu);
+    add_mul2_tri<NX, NX, NU, Z, R::FX, R::FU, R::CXU>(Qxu, Vxx, fx, fu);
     if(FULL) {
         const double *fxu = r + R::FXU;
 #pragma unroll
         for(int j = 0; j < NXU; j++) {
             double acc = 0.0;
 #pragma unroll
-            for(int i = 0; i < NX; i++) acc += Vx[i] * fxu[j + i * NXU];
+            for(int i = 0; i < NX; i++) acc = mad<Z>(acc, Vx[i], fxu[j + i * NXU], R::FXU + j + i * NXU);
             Qxu[j] += acc;
         }
     }
 #pragma unroll
     for(int i = 0; i < SUU; i++) Quu[i] = cuu[i];
-    add_square_tri<NX, NU>(Quu, Vxx, fu);
+    add_square_tri<NX, NU, Z, R::FU, R::CUU>(Quu, Vxx, fu);
     if(FULL) {
         const double *fuu = r + R::FUU;
 #pragma unroll
         for(int j = 0; j < SUU; j++) {
             double acc = 0.0;
 #pragma unroll
-            for(int i = 0; i < NX; i++) acc += Vx[i] * fuu[j + i * SUU];
+            for(int i = 0; i < NX; i++) acc = mad<Z>(acc, Vx[i], fuu[j + i * SUU], R::FUU + j + i * SUU);
             Quu[j] += acc;
         }
     }
 #pragma unroll
     for(int i = 0; i < SXX; i++) Qxx[i] = cxx[i];
-    add_square_tri<NX, NX>(Qxx, Vxx, fx);
+    add_square_tri<NX, NX, Z, R::FX, R::CXX>(Qxx, Vxx, fx);
     if(FULL) {
         const double *fxx = r + R::FXX;
 #pragma unroll
         for(int j = 0; j < SXX; j++) {
             double acc = 0.0;
 #pragma unroll
-            for(int i = 0; i < NX; i++) acc += Vx[i] * fxx[j + i * SXX];
+            for(int i = 0; i < NX; i++) acc = mad<Z>(acc, Vx[i], fxx[j + i * SXX], R::FXX + j + i * SXX);
             Qxx[j] += acc;
         }
     }

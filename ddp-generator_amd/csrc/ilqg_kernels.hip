@@ -749,4 +749,12 @@ __global__ void k_from_dev(const double *__restrict__ dev, double *__restrict__ 
 
 }  // namespace
 
+#ifndef ILQG_ONLY_KERNEL
 #include "ilqg_shim_impl.inc"
+#else
+// kernel experiments (tools/one_kernel.sh): the device code of ONE kernel, e.g.
+// -DILQG_ONLY_KERNEL='k_backward_quad<true>(DevPtrs, ilqg_dev_opts_t, int, int, int)' — no shim, nothing else instantiated
+namespace {
+template __global__ void ILQG_ONLY_KERNEL;
+}
+#endif

@@ -32,6 +32,13 @@
 #else
 #define ILQG_TIME_VARYING_FULL(X)
 #endif
+/* among the others: the entries that are identically 0 (what a dense back_pass multiplies by zero, matMult.c:3-72) */
+#define ILQG_STRUCTURAL_ZERO(X) 
+#if FULL_DDP
+#define ILQG_STRUCTURAL_ZERO_FULL(X) X(fxx, 0) X(fuu, 0) X(fxu, 0)
+#else
+#define ILQG_STRUCTURAL_ZERO_FULL(X)
+#endif
 
 typedef struct {
     double x[N_X];

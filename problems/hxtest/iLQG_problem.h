@@ -32,6 +32,13 @@
 #else
 #define ILQG_TIME_VARYING_FULL(X)
 #endif
+/* among the others: the entries that are identically 0 (what a dense back_pass multiplies by zero, matMult.c:3-72) */
+#define ILQG_STRUCTURAL_ZERO(X) X(fx, 6) X(fu, 0) X(fu, 2) X(fu, 3) X(fu, 4) X(cxx, 1) X(cxx, 4) X(cuu, 1) X(cxu, 0) X(cxu, 1) X(cxu, 2) X(cxu, 3) X(cxu, 4) X(cxu, 5)
+#if FULL_DDP
+#define ILQG_STRUCTURAL_ZERO_FULL(X) X(fxx, 0) X(fxx, 1) X(fxx, 2) X(fxx, 3) X(fxx, 4) X(fxx, 5) X(fxx, 7) X(fxx, 8) X(fxx, 10) X(fxx, 12) X(fxx, 14) X(fxx, 15) X(fxx, 16) X(fxx, 17) X(fuu, 0) X(fuu, 1) X(fuu, 2) X(fuu, 3) X(fuu, 4) X(fuu, 5) X(fuu, 6) X(fuu, 7) X(fuu, 8) X(fxu, 0) X(fxu, 1) X(fxu, 2) X(fxu, 3) X(fxu, 4) X(fxu, 5) X(fxu, 6) X(fxu, 7) X(fxu, 8) X(fxu, 9) X(fxu, 10) X(fxu, 11) X(fxu, 12) X(fxu, 13) X(fxu, 14) X(fxu, 15) X(fxu, 16) X(fxu, 17)
+#else
+#define ILQG_STRUCTURAL_ZERO_FULL(X)
+#endif
 
 typedef struct {
     double x[N_X];

@@ -78,3 +78,66 @@ def test_cpu_build_sees_plain_assignments():
     assert "#define ILQG_REC(member, index) t->member[index]" in src
     assert re.search(r"#define ILQG_REC_DONE\(member, first, count\)\s*/\*", src)
     assert "#define ILQG_BASIS(index) basis[index]" in src
+
+
+def _tri(n):
+    return n * (n + 1) // 2
+
+
+@pytest.mark.parametrize("problem,fd", [("carparking", 0), ("carparking", 1), ("hxtest", 1), ("brachi", 1), ("almix", 1), ("synth16x8", 0)])
+def test_structural_zero_list_against_evaluated_records(problem, fd):
+    """ILQG_STRUCTURAL_ZERO / _FULL (additive lists of the generated header: the record entries that are identically 0, which
+    the fused backward sweep of the lane mapping leaves out of its products, ilqg_device.hpp NoZeros): every listed entry
+    IS 0.0 in records the generated callbacks evaluate along a rolled-out trajectory (the CPU checker's calc_derivs, the
+    same function file), the lists and the time-varying lists do not overlap, and for CarParking they are the zeros SURVEY
+    Appendix A.4's model has (fx: 7 of 16, fu: 4 of 8, cxx: 8 of 10, all of cxu)"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import harness as H
+    head = open(os.path.join(ROOT, "problems", problem, "iLQG_problem.h")).read()
+    n, m = int(re.search(r"#define N_X (\d+)", head).group(1)), int(re.search(r"#define N_U (\d+)", head).group(1))
+
+    def entries(macro, full):
+        ms = re.findall(r"#define %s\(X\)(.*)" % macro, head)
+        txt = ms[0] if (full is None or len(ms) == 1) else ms[0 if full else 1]
+        return {(a, int(b)) for a, b in re.findall(r"X\((\w+), (\d+)\)", txt)}
+    zeros = entries("ILQG_STRUCTURAL_ZERO", None) | (entries("ILQG_STRUCTURAL_ZERO_FULL", True) if fd else set())
+    varying = entries("ILQG_TIME_VARYING", None) | (entries("ILQG_TIME_VARYING_FULL", True) if fd else set())
+    assert zeros and not (zeros & varying)
+    # the record as oracle/driver.c lays it out (RecLayout of ilqg_device.hpp: the same order)
+    off, at = 0, {}
+    for name, size in (("cx", n), ("cxx", _tri(n)), ("cu", m), ("cuu", _tri(m)), ("cxu", n * m), ("fx", n * n), ("fu", n * m),
+                       ("lower", m), ("upper", m)) + ((("fxx", n * _tri(n)), ("fuu", n * _tri(m)), ("fxu", n * n * m)) if fd else ()):
+        at[name] = off
+        off += size
+    path = H.lib_path("oracle", problem, fd)
+    if not os.path.exists(path):
+        pytest.skip("oracle library not built")
+    rng = np.random.default_rng(5)
+    if problem == "carparking":
+        N, params = 40, H.CAR_PARAMS
+        x0, u0 = np.array([1.0, 1.0, 4.7, 0.0]), 0.3 * rng.standard_normal((N, m))
+    elif problem == "hxtest":
+        N, params = 30, H.HX_PARAMS
+        (x0, u0) = H.hx_inputs(1)
+        x0, u0, N = x0[0], u0[0], u0.shape[1]
+    elif problem == "synth16x8":
+        N, params = 12, H.SYN_PARAMS
+        x0, u0 = H.syn_inputs(1, N)
+        x0, u0 = x0[0], u0[0]
+    elif problem == "brachi":
+        params, opts, x0, u0 = H.brachi_case(20)
+        N = u0.shape[0]
+    else:
+        params, opts, x0, u0 = H.almix_case()
+        N = u0.shape[0]
+    d = H.Driver(path, N, params, {})
+    assert d.init(x0, u0) == 1 and d.calc_derivs() == 1
+    rec, _ = d.derivs()
+    d.close()
+    for member, index in sorted(zeros):
+        col = rec[:, at[member] + index]
+        assert np.all(col == 0.0), (member, index, col[:3])
+    if problem == "carparking" and fd == 0:
+        count = lambda mem: sum(1 for a, _ in zeros if a == mem)
+        assert (count("fx"), count("fu"), count("cxx"), count("cxu")) == (7, 4, 8, 8)

@@ -1440,3 +1440,40 @@ def test_rejected_alpha_leaves_the_step_sizes_alone(ilqg, synth):
         s.close()
     for r in res[1:]:
         assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1])
+
+
+@pytest.mark.parametrize("problem,fd", [("carparking", 0), ("carparking", 1), ("hxtest", 1)])
+def test_products_without_the_structural_zeros_equal_the_dense_ones(ilqg, synth, problem, fd):
+    """Lane mapping, fused sweep: the product build leaves the terms of matMult.c's products whose record factor is
+    identically 0 out (ILQG_STRUCTURAL_ZERO of the generated header; ilqg_device.hpp NoZeros), the FMA-free twin multiplies
+    them out as the reference does.  With finite inputs the two differ by FMA contraction alone: gains, expected changes
+    and gradient norm of a sweep at the single-pass bar (1e-10), return codes equal — over a batch, for three consecutive
+    teacher-forced iterations (the twin's trajectory is handed to the product build before each sweep)."""
+    if problem == "carparking":
+        B, N, params = 192, 500, ilqg.CAR_PARAMS
+        x0, u0 = synth.car_batch(B, N)
+    else:
+        B, N, params = 96, HX_N, HX_PARAMS
+        x0, u0 = hx_inputs(B)
+    mk = lambda strict: ilqg.BatchSolver(problem, fd, batch=B, n_hor=N, params=params, opts=dict(max_iter=8), strict=strict)
+    a, b = mk(True), mk(False)
+    a.init(x0, u0)
+    b.init(x0, u0)
+    for it in range(3):
+        if it:
+            b.set_x(a.x())
+            b.set_u(a.u())
+            for k in ("cost", "lambda", "dlambda"):
+                b.set_scalar(k, a.scalar(k))
+        a.back_pass(fused=True)
+        b.back_pass(fused=True)
+        la, La = a.gains()
+        lb, Lb = b.gains()
+        assert np.array_equal(a.ints("bp_rc"), b.ints("bp_rc")) and np.array_equal(a.ints("bp_calls"), b.ints("bp_calls"))
+        assert close(lb, la) and close(Lb, La), (it, worst(lb, la), worst(Lb, La))
+        for k in ("dV0", "dV1", "g_norm", "lambda"):
+            assert close(b.scalar(k), a.scalar(k)), (it, k, worst(b.scalar(k), a.scalar(k)))
+        a.line_search()
+        a.update()
+    a.close()
+    b.close()

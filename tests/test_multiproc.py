@@ -2,7 +2,9 @@
 no exchange except the single gather of costs — the same helpers bench.py uses with RCCL.
 The per-shard work is done by the product when a GPU is present and by the CPU oracle otherwise (no GPU in the
 build container); what is under test is the sharding and the collective."""
+import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -109,9 +111,16 @@ def test_bench_main_with_two_ranks_on_one_gpu():
     """the same branch with the PRODUCT under it: two ranks (gloo, collective through host memory) share device 0, each
     advances its shard; the line is a real (small) measurement and the gathered costs are those of one 2 x 512 batch"""
     port = 29800 + (os.getpid() % 90)
-    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512", "--backend", "gloo", "--all-on-device", "0",
-                      "--no-cpu-baseline"], nproc=2, port=port)
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512", "--backend", "gloo", "--all-on-device", "0"],
+                     nproc=2, port=port)
     assert out["n_gpus"] == 2 and out["value"] > 0 and "rehearsal" not in out
+    # the line of an N > 1 run is complete: the CPU baseline (rank 0's host cores) and a per-kernel roofline of rank 0's
+    # own launches (its shard), not the iteration-level stand-in
+    assert out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] in ("reference", "port")
+    rf = out["roofline"]
+    assert rf["kernel"] == "k_backward[fused derivs]" and rf["bound"] == "hbm" and 0 < rf["frac"] < 1.5
+    assert rf["dominant_launch"]["launches"] >= 3 and rf["dominant_launch"]["trajectories_per_launch"] * out["config"]["stream_groups"] == 512
+    assert abs(rf["achieved"] - rf["dominant_launch"]["hbm_equivalent"]["GBs"]) < 1e-9 * rf["achieved"]
     assert abs(out["value"] - 2 * out["per_gpu_iterations_per_s"]) < 1e-9 * out["value"]  # whole job = 2 shards
     assert out["collective"]["gathered_on_rank_0"] == 1024 and out["trajectories_still_active"] == 512
     pkg = load_package()
@@ -122,6 +131,26 @@ def test_bench_main_with_two_ranks_on_one_gpu():
     want = float(s.scalar("cost").mean())
     s.close()
     assert abs(out["cost_mean_after_window"] - want) <= 1e-12 * abs(want)
+
+
+@pytest.mark.gpu
+def test_bench_guards_the_device_ordinal():
+    """LOCAL_RANK is a device ordinal only while the rank sees every GPU: with ONE visible device a rank's ordinal is 0
+    (a launcher that narrows HIP_VISIBLE_DEVICES per rank), and an ordinal beyond the visible devices otherwise is an
+    error that says so instead of a HIP failure somewhere inside"""
+    import torch
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ, LOCAL_RANK=str(ndev + 2), RANK="0", WORLD_SIZE="1")
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--batch", "256", "--no-unfused", "--no-cpu-baseline"]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    if ndev == 1:
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert out["config"]["device_ordinal_of_rank_0"] == 0 and "one visible device" in out["config"]["device_note"]
+    else:
+        assert r.returncode != 0 and "device(s) are visible" in r.stderr
+    r = subprocess.run(args + ["--all-on-device", str(ndev + 2)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "device(s) are visible" in r.stderr and "Traceback" not in r.stderr
 
 
 @pytest.mark.gpu

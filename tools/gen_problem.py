@@ -539,6 +539,13 @@ class Emitter:
 #else
 #define ILQG_TIME_VARYING_FULL(X)
 #endif
+/* among the others: the entries that are identically 0 (what a dense back_pass multiplies by zero, matMult.c:3-72) */
+#define ILQG_STRUCTURAL_ZERO(X) {self.time_varying_list(False, zeros=True)}
+#if FULL_DDP
+#define ILQG_STRUCTURAL_ZERO_FULL(X) {self.time_varying_list(True, zeros=True)}
+#else
+#define ILQG_STRUCTURAL_ZERO_FULL(X)
+#endif
 
 """
 
@@ -985,11 +992,12 @@ int calc_derivs(tOptSet *o) {
                 res.append("    ILQG_REC_DONE(%s, %d, %d)" % (pc[0][0], pc[0][1], len(pc)))
         return "\n".join(res)
 
-    def time_varying_list(self, full):
-        """the entries emit_derivatives() assigns in bp_derivsL, as X(member, index) ..."""
+    def time_varying_list(self, full, zeros=False):
+        """the entries emit_derivatives() assigns in bp_derivsL, as X(member, index) ...; zeros: instead, the entries
+        whose expression is identically 0"""
         if full:
             groups = [self.jaco2_items(nm, ten) for nm, ten in (("fxx", self.fxx), ("fuu", self.fuu), ("fxu", self.fxu))
-                      if not self.all_zero(ten)]
+                      if zeros or not self.all_zero(ten)]
         else:
             groups = [self.jaco_items("fx", self.fx), self.jaco_items("fu", self.fu), self.grad_items("cx", self.Lx),
                       self.hess_items("cxx", self.Lxx), self.grad_items("cu", self.Lu), self.hess_items("cuu", self.Luu),
@@ -997,7 +1005,7 @@ int calc_derivs(tOptSet *o) {
         out = []
         for items in groups:
             for lhs, e in items:
-                if self.is_time_var(e):
+                if (sp.sympify(e) == 0) if zeros else self.is_time_var(e):
                     m = re.fullmatch(r"t->(\w+)\[(\d+)\]", lhs)
                     out.append("X(%s, %s)" % (m.group(1), m.group(2)))
         return " ".join(out)

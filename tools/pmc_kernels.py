@@ -33,6 +33,12 @@ if issue_json:
                   "active_valu_frac": c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"],
                   "wait_any_frac": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
                   "waves": c["SQ_WAVES"], "valu_insts_total": c.get("SQ_INSTS_VALU", 0.0)}
+        # the wave mapping's backward kernels are PERSISTENT (wavefronts take trajectories from a queue and walk their sweeps,
+        # lambda retries included): instructions / (wavefronts x horizon) is not a per-step figure for them; only the step
+        # count of the profile build (--wave-steps) makes one, and bench.py reports none without it
+        if re.match(r"k_backward_(quad|wave)", k):
+            out[k]["persistent"] = True
+            del out[k]["valu_insts_per_wave_and_step"]
         if sweep_steps and k.startswith("k_backward"):
             # persistent wavefronts (a worker walks many trajectories, sweeps are cut short by lambda retries): per step the
             # wavefronts really walked — counted by the kernel itself in the -DILQG_PROFILE_SECTIONS build of the same sources
