@@ -33,6 +33,37 @@
 
 namespace ilqg {
 
+// ILQG_QUAD_LEAN (round 5; default 0): the step written for TWO wavefronts per SIMD — at most 256 registers, eight
+// wavefronts per workgroup.  Less is kept alive: a row without a step to do gets zeros for its value function instead of
+// keeping the old one through the step, the first-order entries of the record and cxx / cxu / cuu are requested where they
+// are used, the box QP's diagonal lies in LDS, the contraction may run with one register set — and, what decided it, the
+// sums Qxx / Qxu / Quu are PINNED in front of the box QP: the optimiser otherwise sinks these cheap additions to their
+// use behind it and keeps their three operands alive instead (430 -> 254 registers, no spills with the pins; 126 spilled
+// without).  The arithmetic is untouched: bit-identical to the default layout (test_quad_lean_layout_equals_the_default).
+// MEASURED (config 5, profiles/r5_quad_lean.txt): two co-resident wavefronts take 37 500 cycles per step against 26 400 for
+// one alone — 1.41x the throughput per SIMD while every row is busy — but a single wavefront's step takes 17 us instead
+// of 12.4 (every wait the other wavefront covers is exposed to the one that waits), and the kernel is NOT bound by
+// throughput at this batch size: the sweeps of a trajectory are a serial chain, the longest trajectories walk 4 000-5 000
+// steps (mean 1 800: lambda retries), a worker that takes one of them late finishes at start + 4 500 x 17 us.  106-109 ms
+// against 101-104 ms for the default; with 4 096 trajectories (one per row, pure chain) 62 against 42 ms.  Kept as a build
+// option (bits below; -DILQG_QUAD_LEAN=63 -> eight wavefronts per workgroup) and as the `_lean` library of the tests.
+#ifndef ILQG_QUAD_LEAN
+#define ILQG_QUAD_LEAN 0
+#endif
+// the measures one by one (bits of ILQG_QUAD_LEAN)
+#define ILQG_LEAN_ZERO ((ILQG_QUAD_LEAN & 1) != 0)    // a row without a step gets zeros for its value function
+#define ILQG_LEAN_FIRST ((ILQG_QUAD_LEAN & 2) != 0)   // first-order entries requested behind the contraction
+#define ILQG_LEAN_SINGLE ((ILQG_QUAD_LEAN & 4) != 0)  // one register set in the contraction
+#define ILQG_LEAN_DG ((ILQG_QUAD_LEAN & 8) != 0)      // the factor's diagonal in LDS
+#define ILQG_LEAN_LATE ((ILQG_QUAD_LEAN & 16) != 0)   // cxx / cxu / cuu requested where they are used
+#define ILQG_LEAN_HERE ((ILQG_QUAD_LEAN & 32) != 0)   // sums pinned in front of the box QP
+
+// "this value exists HERE": keeps the optimiser from sinking a cheap sum to its use behind the box QP — which keeps the
+// sum's operands alive instead (three values for one)
+ILQG_DEV void here(double &v) {
+    if(ILQG_LEAN_HERE) asm volatile("" : "+v"(v));
+}
+
 // acc += a * b with the contraction of the DPP forms: fused in the product build, two roundings in the strict one
 ILQG_DEV void mac(double &acc, const double a, const double b) {
 #ifdef ILQG_STRICT_FP
@@ -64,7 +95,7 @@ constexpr unsigned long long col_above(int r) {
 // ---------------------------------------------------------------------------
 template <int M>
 ILQG_DEV int box_qp_quad(const double (&Hrow)[M], const double g, const double lower, const double upper, double &x, const bool active,
-                         const unsigned inv_at, int &clamp_out, double (&invrow)[M]) {
+                         const unsigned inv_at, int &clamp_out, double (&invrow)[M], const unsigned dg_at = 0) {
     static_assert(M <= 16, "one 16-lane row holds all variables");
     constexpr int LD = M + 1;
     int lane = threadIdx.x & 63;
@@ -137,37 +168,67 @@ ILQG_DEV int box_qp_quad(const double (&Hrow)[M], const double g, const double l
             auto factor = [&](auto plain_c) {
                 constexpr bool PLAIN = decltype(plain_c)::value;
                 bool plain = true;
-                double dg[M], rdg[M];  // the factor's diagonal and its reciprocals (the same in every lane of the row)
+                // the factor's diagonal and its reciprocals (the same in every lane of the row).  Lean build: 2 M doubles of
+                // the row's LDS block instead of 4 M registers held through the inverse (every lane writes the same value)
+                double dg_r[ILQG_LEAN_DG ? 1 : M], rdg_r[ILQG_LEAN_DG ? 1 : M];
+                const LdsBase pdg = lds_base(dg_at);
+                auto put_dg = [&](auto jc, const double d, const double r) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr(ILQG_LEAN_DG) {
+                        pdg[2 * j] = d;
+                        pdg[2 * j + 1] = r;
+                    } else {
+                        dg_r[j] = d;
+                        rdg_r[j] = r;
+                    }
+                };
+                auto get_dg = [&](auto jc, double &d, double &r) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr(ILQG_LEAN_DG) {
+                        d = pdg.fetch(2 * j);
+                        r = pdg.fetch(2 * j + 1);
+                    } else {
+                        d = dg_r[j];
+                        r = rdg_r[j];
+                    }
+                };
                 static_for<0, M>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     double dot = 0.0;
                     bc_dotj<j, j>(dot, Ucol, Ucol);  // sum_{k < j} U[k, j] * U[k, me]
                     const double sv = Hm[j] - dot;
                     const double piv = bc_get<j>(sv);
+                    double dj, rj;
                     if constexpr(PLAIN) {
                         plain = plain && plain_range_lane(piv);
-                        dg[j] = sqrt_plain(piv);
-                        rdg[j] = rcp_plain(dg[j]);
+                        dj = sqrt_plain(piv);
+                        rj = rcp_plain(dj);
                     } else {
                         if(piv <= 0.0) pd = false;
-                        dg[j] = sqrt(piv);
-                        rdg[j] = 1.0 / dg[j];
+                        dj = sqrt(piv);
+                        rj = 1.0 / dj;
                     }
+                    put_dg(jc, dj, rj);
                     // (me == j) ? d : ((me > j) ? 1.0 / d * sv : 0.0)
-                    Ucol[j] = lane_pick<lanes_of<M>(j, 0)>(dg[j], lane_pick<lanes_of<M>(j, 1)>(rdg[j] * sv, 0.0));
+                    Ucol[j] = lane_pick<lanes_of<M>(j, 0)>(dj, lane_pick<lanes_of<M>(j, 1)>(rj * sv, 0.0));
                 });
+                if constexpr(ILQG_LEAN_DG) wave_sync();
                 // explicit inverse: lane l solves U'U y = e_l; y[k] for k >= l is row l of the inverse
                 static_for<0, M>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     double v = lane_unit<lanes_of<M>(k, 0)>();
                     bc_dotjn<k, k>(v, Ucol, y);  // v -= sum_{i < k} y[i] * U[i, k]    (y[i] = 0 for i < l: exact zeros)
-                    y[k] = PLAIN ? div_plain(v, dg[k], rdg[k]) : v / dg[k];
+                    double dk, rk;
+                    get_dg(kc, dk, rk);
+                    y[k] = PLAIN ? div_plain(v, dk, rk) : v / dk;
                 });
                 static_for<0, M>([&](auto kr) {
                     constexpr int k = M - 1 - decltype(kr)::value;
                     double v = y[k];
                     bc_dotn<M - 1 - k, k + 1>(v, Ucol[k], y + k + 1);  // v -= sum_{i > k} y[i] * U[k, i]
-                    y[k] = PLAIN ? div_plain(v, dg[k], rdg[k]) : v / dg[k];
+                    double dk, rk;
+                    get_dg(std::integral_constant<int, k>{}, dk, rk);
+                    y[k] = PLAIN ? div_plain(v, dk, rk) : v / dk;
                 });
                 return plain;
             };
@@ -291,13 +352,21 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
 
     // ---- the step's record
     double fxc[NX], fuc[NX];  // column cx_ of fx, column me of fu
+    double cxl, cul, lo_k, up_k, u_l;
+    auto load_first_order = [&]() {
 #pragma unroll
-    for(int s = 0; s < NX; s++) fxc[s] = ldd(R::fx + (unsigned)(s + cx_ * NX) * 8u);
+        for(int s = 0; s < NX; s++) fxc[s] = ldd(R::fx + (unsigned)(s + cx_ * NX) * 8u);
 #pragma unroll
-    for(int s = 0; s < NX; s++) fuc[s] = ldd(R::fu + (unsigned)(s + me * NX) * 8u);
-    const double cxl = ldd(R::cx + (unsigned)cx_ * 8u), cul = ldd(R::cu + (unsigned)me * 8u);
-    const double lo_k = ldd(R::lower + (unsigned)me * 8u), up_k = ldd(R::upper + (unsigned)me * 8u);
-    const double u_l = nom_u[me];
+        for(int s = 0; s < NX; s++) fuc[s] = ldd(R::fu + (unsigned)(s + me * NX) * 8u);
+        cxl = ldd(R::cx + (unsigned)cx_ * 8u);
+        cul = ldd(R::cu + (unsigned)me * 8u);
+        lo_k = ldd(R::lower + (unsigned)me * 8u);
+        up_k = ldd(R::upper + (unsigned)me * 8u);
+        u_l = nom_u[me];
+    };
+    // (lean build, two wavefronts per SIMD: the first-order entries are requested BEHIND the contraction — 37 doubles less
+    // alive through it; the other wavefront of the SIMD covers the wait)
+    if(!(ILQG_LEAN_FIRST && FULL && FACT)) load_first_order();
     const int bxx = cx_ * (cx_ + 1) / 2, buu = me * (me + 1) / 2;  // packed column starts: entry (r, c) = b + r, r <= c
     // (The vector ALU addresses 256 registers = 128 doubles; what a wavefront holds beyond that sits in accumulation
     // registers and costs a copy per use.  So every block below loads what it needs itself, right in front of its
@@ -374,14 +443,19 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
         // times their product — which waits for reads issued a whole stage ago, with the ones just issued still in flight
         // (the wait counter of LDS operations holds 15: a slice's 11 + 3 reads fit) — then the multiply-adds.
         double ca[PER], cb[PER], ga[3], gb[3], m[PER];
-        fetch(std::integral_constant<int, 0>{}, ca, ga);
+        if(!ILQG_LEAN_SINGLE) fetch(std::integral_constant<int, 0>{}, ca, ga);
         static_for<0, NX>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            double(&cur)[PER] = (i % 2) ? cb : ca;
+            double(&cur)[PER] = (i % 2 && !ILQG_LEAN_SINGLE) ? cb : ca;
             double(&nxt)[PER] = (i % 2) ? ca : cb;
-            double(&gc)[3] = (i % 2) ? gb : ga;
+            double(&gc)[3] = (i % 2 && !ILQG_LEAN_SINGLE) ? gb : ga;
             double(&gn)[3] = (i % 2) ? ga : gb;
-            if constexpr(i + 1 < NX) fetch(std::integral_constant<int, i + 1>{}, nxt, gn);
+            if constexpr(ILQG_LEAN_SINGLE) {
+                // (lean build: ONE register set — the slice's reads, then its arithmetic; the other wavefront of the SIMD
+                // issues meanwhile)
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(std::integral_constant<int, i>{}, ca, ga);
+            } else if constexpr(i + 1 < NX) fetch(std::integral_constant<int, i + 1>{}, nxt, gn);
 #ifdef ILQG_STRICT_FP
             // the reference's two roundings: t->fxx[e] = coefficient * product, then d += Vx[i] * t->fxx[e]
 #pragma unroll
@@ -415,6 +489,10 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
 #pragma unroll
         for(int q = 0; q < NTX; q += 2) pd2[(Q::dxx + 16 * q) / 2] = dpair{dxx[q], dxx[q + 1]};
         wave_sync();
+        if(ILQG_LEAN_FIRST) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_first_order();
+        }
     }
 
     if(pf) pf->probe(1);
@@ -430,10 +508,13 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
     double qxx[NX], qxx_d;
     __builtin_amdgcn_sched_barrier(0);
     {
-        double cxx_c[NX];  // cxx[r, cx_] (r <= cx_; rows beyond the diagonal: inside the array, unused)
+        double cxx_c[NX], cxx_d;  // cxx[r, cx_] (r <= cx_; rows beyond the diagonal: inside the array, unused)
+        auto load_cxx = [&]() {
 #pragma unroll
-        for(int r = 0; r < NX; r++) cxx_c[r] = ldd(R::cxx + (unsigned)(bxx + r) * 8u);
-        const double cxx_d = ldd(R::cxx + (unsigned)(bxx + cx_) * 8u);
+            for(int r = 0; r < NX; r++) cxx_c[r] = ldd(R::cxx + (unsigned)(bxx + r) * 8u);
+            cxx_d = ldd(R::cxx + (unsigned)(bxx + cx_) * 8u);
+        };
+        if(!ILQG_LEAN_LATE) load_cxx();  // (lean build: behind the products, where they are used)
         double a[NX];
 #pragma unroll
         for(int r = 0; r < NX; r++) a[r] = 0.0;
@@ -452,15 +533,21 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
         // and K'(Quu K) below: 450 of a wavefront step's 4 350 vector instructions)
         constexpr double HALF = 1.0;
 #endif
+        if(ILQG_LEAN_LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_cxx();
+        }
         const LdsBase pd = lds_base(rb + (Q::dxx + bxx) * 8);
 #pragma unroll
         for(int r = 0; r < NX; r++) {
             double v = cxx_c[r] + a[r] * HALF;
             if(FULL && FACT) v += pd[r];
+            here(v);
             qxx[r] = v;
         }
         qxx_d = cxx_d + dsum;
         if(FULL && FACT) qxx_d += pd[cx_];
+        here(qxx_d);
     }
     wave_sync();
 
@@ -470,8 +557,11 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
     __builtin_amdgcn_sched_barrier(0);
     {
         double cxu_r[NU];  // cxu[cx_, j]
+        auto load_cxu = [&]() {
 #pragma unroll
-        for(int j = 0; j < NU; j++) cxu_r[j] = ldd(R::cxu + (unsigned)(cx_ + j * NX) * 8u);
+            for(int j = 0; j < NU; j++) cxu_r[j] = ldd(R::cxu + (unsigned)(cx_ + j * NX) * 8u);
+        };
+        if(!ILQG_LEAN_LATE) load_cxu();
         double a[NU];
 #pragma unroll
         for(int j = 0; j < NU; j++) a[j] = 0.0;
@@ -479,11 +569,16 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
             constexpr int s = decltype(sc)::value;
             bc_rows<s, NU>(a, t2r, fxc[s]);  // T2[s, j] fx[s, r], all j
         });
+        if(ILQG_LEAN_LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_cxu();
+        }
         const LdsBase pd = lds_base(rb + (Q::dxu + cx_) * 8);
 #pragma unroll
         for(int j = 0; j < NU; j++) {
             double v = cxu_r[j] + a[j];
             if(FULL && FACT) v += pd[j * NX];
+            here(v);
             qxu[j] = v;
         }
     }
@@ -492,10 +587,13 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
     double quu[NU], hrow[NU];  // Quu[me, .], the regularised one
     __builtin_amdgcn_sched_barrier(0);
     {
-        double cuu_c[NU];  // cuu[i, me] (i <= me)
+        double cuu_c[NU], cuu_d;  // cuu[i, me] (i <= me)
+        auto load_cuu = [&]() {
 #pragma unroll
-        for(int i = 0; i < NU; i++) cuu_c[i] = ldd(R::cuu + (unsigned)(buu + i) * 8u);
-        const double cuu_d = ldd(R::cuu + (unsigned)(buu + me) * 8u);
+            for(int i = 0; i < NU; i++) cuu_c[i] = ldd(R::cuu + (unsigned)(buu + i) * 8u);
+            cuu_d = ldd(R::cuu + (unsigned)(buu + me) * 8u);
+        };
+        if(!ILQG_LEAN_LATE) load_cuu();
         double duu_c[NU], duu_d = 0.0;
         if(FULL && FACT) {
             const LdsBase pd = lds_base(rb + (Q::duu + buu) * 8);
@@ -533,15 +631,21 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
 #else
         constexpr double HALF = 1.0;
 #endif
+        if(ILQG_LEAN_LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_cuu();
+        }
         double col[NU];  // Quu[i, me], i < me
 #pragma unroll
         for(int i = 0; i < NU; i++) {
             double v = cuu_c[i] + a[i] * HALF;
             if(FULL && FACT) v += duu_c[i];
+            here(v);
             col[i] = v;
         }
         double qd = cuu_d + dsum;
         if(FULL && FACT) qd += duu_d;
+        here(qd);
         // every lane lays down its column (rows above the diagonal are good, the diagonal entry apart) and reads its row
         wave_sync();
         {
@@ -567,7 +671,7 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
     int mine;
     double ih[NU];  // invH[me, .]
     double lsol = lcur;
-    const int rc = box_qp_quad<NU>(hrow, qul, lo_k, up_k, lsol, live, rb + Q::inv * 8, mine, ih);
+    const int rc = box_qp_quad<NU>(hrow, qul, lo_k, up_k, lsol, live, rb + Q::inv * 8, mine, ih, rb + Q::basis * 8);
     const bool ok = live && rc >= 1;
     if(pf) pf->probe(5);
     __builtin_amdgcn_sched_barrier(0);
@@ -685,9 +789,9 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
             constexpr int r = decltype(rc_)::value;
             const double other = p[r * LDX];                                // Vxx[c, r] of column r: good for r >= c
             const double v = lane_pick<col_above(r)>(vv[r], other);       // (c > r) ? own : column r's
-            vxx[r] = ok ? v : vxx[r];
+            vxx[r] = ok ? v : (ILQG_LEAN_ZERO ? 0.0 : vxx[r]);
         });
-        vx = ok ? vxn : vx;
+        vx = ok ? vxn : (ILQG_LEAN_ZERO ? 0.0 : vx);
         wave_sync();
     }
     lcur = ok ? lsol : lcur;

@@ -49,8 +49,9 @@ def add_library_dir(path):
 def library_path(problem="carparking", full_ddp=0, strict=False):
     """strict=True: the -ffp-contract=off build (bit-for-bit CPU parity of the backward pass; tests only);
     strict="wave": the build of a small problem forced into the one-wavefront-per-trajectory mapping;
-    strict="elem": the n = 16 problem built with the one-output-element-per-lane backward step (FMA-free)"""
-    suffix = "_wave" if strict == "wave" else ("_elem" if strict == "elem" else ("_strict" if strict else ""))
+    strict="elem": the n = 16 problem built with the one-output-element-per-lane backward step (FMA-free);
+    strict="lean": the n = 16 problem's product build with the quad step laid out for two wavefronts per SIMD"""
+    suffix = "_" + strict if strict in ("wave", "elem", "lean") else ("_strict" if strict else "")
     name = "libilqg_%s_fd%d_hip%s.so" % (problem, int(full_ddp), suffix)
     for d in [LIBDIR] + _extra_libdirs:
         if os.path.exists(os.path.join(d, name)):

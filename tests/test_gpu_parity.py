@@ -1470,10 +1470,43 @@ def test_products_without_the_structural_zeros_equal_the_dense_ones(ilqg, synth,
         la, La = a.gains()
         lb, Lb = b.gains()
         assert np.array_equal(a.ints("bp_rc"), b.ints("bp_rc")) and np.array_equal(a.ints("bp_calls"), b.ints("bp_calls"))
-        assert close(lb, la) and close(Lb, La), (it, worst(lb, la), worst(Lb, La))
+        # (the feed-forward term is the box QP's solution: once inputs run on their limits — the later iterations — the
+        # iteration ends on a relative improvement of 1e-8 (boxQP.c:85), a last-bit difference of the two builds'
+        # contraction may end it one iteration apart: 1e-6 there, as between two CPU builds of the reference)
+        ltol = TOL if it == 0 else 1e-6
+        assert close(lb, la, ltol) and close(Lb, La), (it, worst(lb, la), worst(Lb, La))
         for k in ("dV0", "dV1", "g_norm", "lambda"):
-            assert close(b.scalar(k), a.scalar(k)), (it, k, worst(b.scalar(k), a.scalar(k)))
+            assert close(b.scalar(k), a.scalar(k), ltol), (it, k, worst(b.scalar(k), a.scalar(k)))
         a.line_search()
         a.update()
     a.close()
     b.close()
+
+
+def test_quad_lean_layout_equals_the_default(ilqg):
+    """The quad-mapped backward step laid out for two wavefronts per SIMD (ilqg_quad.hpp ILQG_QUAD_LEAN = 63: 254
+    registers, eight wavefronts per workgroup, values re-requested where they are used, the box QP's diagonal in LDS,
+    one register set in the contraction) changes WHEN values are loaded and where they wait, not what is computed: the
+    same product-build arithmetic, so gains, value changes, gradient norms, lambdas and sweep counts of a ragged batch
+    with lambda retries — and the solves that follow — equal the default layout's bit for bit."""
+    B, N, K = 75, 300, 4
+    x0, u0 = syn_inputs(B, N, first=11)
+    x0 = x0 * np.linspace(0.2, 3.0, B)[:, None]
+
+    def run(variant):
+        s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=K + 1, lambdaInit=1e-7), strict=variant)
+        s.init(x0, u0)
+        out = []
+        for it in range(K):
+            s.iterate(1)
+            l, L = s.gains()
+            out.append(dict(l=l.copy(), L=L.copy(), dV0=s.scalar("dV0").copy(), dV1=s.scalar("dV1").copy(), g=s.scalar("g_norm").copy(),
+                            lam=s.scalar("lambda").copy(), calls=s.ints("bp_calls").copy(), cost=s.scalar("cost").copy()))
+        s.close()
+        return out
+
+    a, b = run(False), run("lean")
+    assert np.concatenate([o["calls"] for o in a]).max() > 1
+    for it, (p, q) in enumerate(zip(a, b)):
+        for k in p:
+            assert np.array_equal(p[k], q[k]), (it, k)

@@ -1,0 +1,13 @@
+set -o pipefail
+O=gpurun_out/r5a; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/pytest.rc; tail -5 $O/pytest.log
+for i in 1 2; do
+ for v in lib lib_nofold; do
+  ILQG_LIBDIR=$PWD/ddp-generator_amd/$v timeout -k 10 200 python bench.py --no-unfused --no-cpu-baseline > $O/bench_${v}_$i.json 2> $O/bench_${v}_$i.err
+  python - $O/bench_${v}_$i.json $v <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[2], "%.2f it/s"%d["value"], {k:round(v,3) for k,v in d["kernels_ms_per_iteration_overlapping"].items() if v>0.05})
+PY
+ done
+done
+timeout -k 10 500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -c 600 $O/bench_default.json

@@ -7,9 +7,10 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 PROB=$1; FD=$2; SIG=$3; shift 3
 PD=$R/problems/$PROB; [ -d "$PD" ] || PD=$R/ddp-generator_amd/build/plain/$PROB
 BIG=""; case $PROB in synth16x8*|synth16p*) BIG="-DILQG_SINCOS_CALL -mllvm -disable-machine-licm";; esac
+FP="-ffp-contract=fast-honor-pragmas"; [ -n "$STRICT" ] && FP="-ffp-contract=off -DILQG_STRICT_FP=1"   # STRICT=1: the FMA-free twin
 OUT=$(mktemp /tmp/onek.XXXXXX.s)
 hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -Wno-writable-strings -Wno-extern-c-compat -Wno-unused-value \
-  -DHAVE_OCTAVE $BIG ${STRICT:+-ffp-contract=off -DILQG_STRICT_FP=1} ${STRICT:--ffp-contract=fast-honor-pragmas} -DFULL_DDP=$FD "-DILQG_ONLY_KERNEL=$SIG" "$@" \
+  -DHAVE_OCTAVE $BIG $FP -DFULL_DDP=$FD "-DILQG_ONLY_KERNEL=$SIG" "$@" \
   -I$R/include/mex_stub -I$R/include -I$R/ddp-generator_amd/csrc -I$PD -I$R/ddp-generator_amd/build/${PROB}_fd$FD \
   $R/ddp-generator_amd/csrc/ilqg_kernels.hip -o $OUT || exit 1
 cat $OUT
