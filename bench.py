@@ -316,6 +316,56 @@ def dropin_b1(ilqg, synth, iters=20):
                     "so one trajectory cannot use the GPU — compare cpu_baseline.single_core_ms_per_trajectory_iteration"}
 
 
+def full_solve(ilqg, synth, local, B=65536, n_hor=500, max_iter=500, compact=2048):
+    """The reference's product — a solve to convergence (iLQG.c:224-379) — for a batch of CarParking starts: solves/s with
+    and without retiring finished trajectories (option "compact": the live trajectories are gathered into smaller contexts,
+    ilqg_host.c ilqg_batch_solve), the iterations the starts need, and how many of the lanes the iterations ran over were
+    live.  The same starts, the same results bit for bit (asserted here on cost / status / iterations)."""
+    x0, u0 = synth.car_batch(B, n_hor)
+    out = {"metric": "iLQG solves/sec, %d CarParking starts (n=4,m=2,N=%d), max_iter %d" % (B, n_hor, max_iter), "unit": "solves/s",
+           "config": {"workload": "CarParking batch=%d randomised x0 (the benchmark's generator), u0 = 0.1 N(0,1), solved to the reference's "
+                                  "exit tests (iLQG.c:297-303, :331, :365-378), max_iter %d (testCar.m:19 has 200), default options" % (B, max_iter),
+                      "compact_min_trajectories": compact}}
+    ref = None
+    # (both contexts are made before either solve, so that both get fresh device memory and the same stream set-up order
+    # does not favour one: a context made after another one was released has been seen 50 % slower per iteration)
+    solvers = [(label, ilqg.BatchSolver("carparking", 0, batch=B, n_hor=n_hor, device=local, params=ilqg.CAR_PARAMS, opts=dict(max_iter=max_iter, compact=cmin)))
+               for label, cmin in (("plain", 0), ("compacted", compact))]
+    for label, s in solvers:
+        s.init(x0, u0)
+        s.sync()
+    for label, s in solvers:
+        t0 = time.perf_counter()
+        s.solve()
+        s.sync()
+        dt = time.perf_counter() - t0
+        it, act, slots, ncomp = s.solve_trace()
+        status, iters, cost = s.ints("status"), s.ints("iterations"), s.scalar("cost")
+        s.close()
+        steps = np.diff(np.concatenate([[0], it]))              # iterations each poll covered
+        before = np.concatenate([[B], act[:-1]])                  # live when those iterations started
+        o = {"seconds": dt, "value": B / dt, "iterations_run": int(it[-1]), "compactions": ncomp,
+             "slot_iterations": int((slots * steps).sum()), "live_lane_iterations_upper_bound": int((before * steps).sum()),
+             "lane_occupancy": float((before * steps).sum() / max(1, (slots * steps).sum())),
+             "occupancy_over_time": [{"iteration": int(a), "active": int(b), "slots": int(c)} for a, b, c in
+                                     list(zip(it, act, slots))[::max(1, len(it) // 16)]]}
+        if ref is None:
+            ref = (status, iters, cost)
+            q = np.percentile(iters, [5, 25, 50, 75, 95])
+            names = {1: "gradient test", 2: "cost test", 3: "max_iter", 4: "lambda > lambdaMax (backward pass)", 5: "lambda > lambdaMax (rejected step)",
+                     6: "NaN/Inf in derivatives", 7: "initial roll-out failed", 0: "still active"}
+            out["iterations_per_start"] = {"min": int(iters.min()), "p5": q[0], "p25": q[1], "median": q[2], "p75": q[3], "p95": q[4],
+                                           "max": int(iters.max()), "mean": float(iters.mean())}
+            out["exits"] = {names.get(int(k), str(k)): int(v) for k, v in zip(*np.unique(status, return_counts=True))}
+            out["cost_mean"] = float(cost.mean())
+        else:
+            o["identical_to_plain"] = bool(np.array_equal(status, ref[0]) and np.array_equal(iters, ref[1]) and np.array_equal(cost, ref[2]))
+        out[label] = o
+    out["value"] = out["compacted"]["value"]
+    out["speedup_from_compaction"] = out["compacted"]["value"] / out["plain"]["value"]
+    return out
+
+
 class ProtocolShard:
     """--rehearse-protocol: stands where the solver of a rank stands and does NO numerics — its "costs" are the global
     indices of the shard's trajectories.  What runs for real is everything around the solver in main(): the shard
@@ -429,6 +479,11 @@ def main():
                          "mapping: second stage beside the re-rolled winners); 0: second stage, then winner pass")
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary runs (kernels alone, config 5, drop-in)")
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--solve", action="store_true",
+                    help="full solves instead of the benchmark window: --batch CarParking starts solved to convergence (max_iter "
+                         "--max-iter), with and without retiring finished trajectories; prints its own JSON line")
+    ap.add_argument("--max-iter", type=int, default=500)
+    ap.add_argument("--compact", type=int, default=2048, help="--solve: smallest live set still gathered into a smaller context")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N > 1 without torch.distributed.run: ONE process drives the N GPUs through the C "
                          "interface ilqg_multi_* (hipSetDevice per shard, ncclCommInitAll, one ncclGather of the costs)")
@@ -453,6 +508,10 @@ def main():
     rank, local, world = pkg.dist.env_world()
     if args.single_process and world == 1 and args.gpus > 1:
         return single_process(args, ilqg, synth)
+    if args.solve:
+        assert world == 1 and args.workload == "car", "--solve: one GPU, CarParking"
+        print(json.dumps(full_solve(ilqg, synth, local, B=args.batch or 65536, n_hor=args.n_hor or 500, max_iter=args.max_iter, compact=args.compact)))
+        return
     rehearsal = args.rehearse_protocol
     if rehearsal:
         args.no_unfused = args.no_cpu_baseline = True  # (nothing of the product runs)
@@ -696,6 +755,10 @@ def main():
                 out["config2"] = config2(ilqg, synth, local)
             except Exception as e:
                 out["config2"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                out["full_solve"] = full_solve(ilqg, synth, local)
+            except Exception as e:
+                out["full_solve"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if not args.no_config5:
                 try:
                     out["config5"] = config5(ilqg, synth, local, with_cpu=not args.no_cpu_baseline)

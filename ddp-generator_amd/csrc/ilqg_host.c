@@ -46,6 +46,7 @@
  * process's four hardware queues and collapse to 118, with GPU_MAX_HW_QUEUES=8 they reach 159-171).  Trajectories are
  * independent, so results do not depend on the grouping. */
 #define ILQG_MAX_GROUPS 4
+#define ILQG_TRACE_MAX 4096
 struct ilqg_batch {
     ilqg_dev_t *dev[ILQG_MAX_GROUPS];
     int first[ILQG_MAX_GROUPS], count[ILQG_MAX_GROUPS];
@@ -57,6 +58,11 @@ struct ilqg_batch {
     double **p;                      /* owned copies of the problem parameters */
     char *p_given;                   /* which of them the caller has set */
     int params_pushed;
+    /* full solves: finished trajectories are retired (ilqg_batch_solve) */
+    int compact;                     /* 0: never; else the smallest number of live trajectories still worth a smaller context */
+    int trace_n;                     /* the last solve, poll by poll: iterations done, trajectories active, slots iterated */
+    int trace_it[ILQG_TRACE_MAX], trace_active[ILQG_TRACE_MAX], trace_slots[ILQG_TRACE_MAX];
+    int compactions;
     double *scratch;                 /* host arrays of the drop-in entry points, kept between calls */
     size_t scratch_doubles;
     char err[512];
@@ -395,6 +401,12 @@ int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value
         c->fuse_derivs = value[0] != 0.0;
         return 0;
     }
+    if(strcmp(name, "compact") == 0) {
+        if(n != 1) return fail_msg(c, err_scalar);
+        if(value[0] < 0.0) return fail_msg(c, err_pos);
+        c->compact = (int)value[0];
+        return 0;
+    }
     if(strcmp(name, "alpha") == 0) {
         /* the option set only borrows the array (iLQG.c:101): it is validated on the caller's values first, and only
          * an accepted set replaces the stored one */
@@ -500,16 +512,164 @@ int ilqg_batch_active(ilqg_batch_t *c, int *n) {
     return 0;
 }
 
-int ilqg_batch_solve(ilqg_batch_t *c) {
-    int it, active = 1;
-    if(push_config(c)) return 1;
-    /* poll the active count every few iterations: one small D2H copy */
-    for(it = 0; it < c->opt.max_iter && active; it += 4) {
-        int n = c->opt.max_iter - it < 4 ? c->opt.max_iter - it : 4;
-        if(iterate_groups(c, n)) return 1;
-        if(ilqg_batch_active(c, &active)) return 1;
+/* ---- full solves: retiring finished trajectories -----------------------------------------------------------------
+ * The reference's product is a solve to convergence (iLQG.c:224-379): a trajectory leaves the loop through the gradient
+ * test (:297-303), the cost test (:331), lambda > lambdaMax (:273, :356) or max_iter (:372).  In a lock-step batch the
+ * kernels skip a finished trajectory, but a wavefront with ONE live lane costs what a full one costs, and CarParking
+ * starts converge anywhere between 50 and 550 iterations: most lane-iterations of a solve's tail are idle lanes in
+ * resident wavefronts.  So, between iterations, once at most half of the slots being iterated are live, the live
+ * trajectories are gathered into a smaller context (ilqg_dev_move: current x / u, records, scalars, integers,
+ * multipliers, and the stored derivative records of the unfused path), iterated there, and written back into their own
+ * slots of the caller's batch when they are gathered again or the solve ends.  Every getter therefore reads the caller's
+ * batch as if nothing had moved; a trajectory's iterations depend on nothing but its own state, so every result is
+ * bit for bit that of the uncompacted solve (tests/test_gpu_solve.py).  Option "compact" = n > 0 switches it on:
+ * contexts of fewer than n trajectories are not made (below a few thousand trajectories an iteration costs the latency
+ * of its chains of n_hor steps whatever the size). */
+static double now_s(void) {
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+}
+static int group_of(const ilqg_batch_t *c, int b) {
+    int g;
+    for(g = c->groups - 1; g > 0; g--)
+        if(b >= c->first[g]) break;
+    return g;
+}
+/* state of trajectories src_idx[0..n) of `src` -> trajectories dst_idx[0..n) of `dst` (indices of the whole batches) */
+static int move_between(ilqg_batch_t *dst, ilqg_batch_t *src, int n, const int *dst_idx, const int *src_idx) {
+    int gd, gs, j, rc = 0;
+    int *to = (int *)malloc(sizeof(int) * (n > 0 ? n : 1)), *from = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    for(gd = 0; gd < dst->groups && !rc; gd++)
+        for(gs = 0; gs < src->groups && !rc; gs++) {
+            int m = 0;
+            for(j = 0; j < n; j++)
+                if(group_of(dst, dst_idx[j]) == gd && group_of(src, src_idx[j]) == gs) {
+                    to[m] = dst_idx[j] - dst->first[gd];
+                    from[m] = src_idx[j] - src->first[gs];
+                    m++;
+                }
+            if(m && ilqg_dev_move(dst->dev[gd], src->dev[gs], m, to, from, !src->fuse_derivs)) rc = fail(dst, "moving trajectories");
+        }
+    free(to);
+    free(from);
+    return rc;
+}
+/* a context of `n` trajectories with the options and parameters of c */
+static ilqg_batch_t *working_copy(ilqg_batch_t *c, int n) {
+    int i;
+    /* (MEASURED: four stream groups for the small contexts too — so that their chains of n_hor dependent steps overlap —
+     * changed nothing: an iteration of 3 738 trajectories takes the 5 ms an iteration of 65 536 takes, in one group or four) */
+    int dims[8], groups;
+    ilqg_batch_t *w;
+    ilqg_dev_dims(dims);
+    (void)dims;
+    groups = 0;  /* the library's choice for that size (ILQG_COMPACT_GROUPS: experiments) */
+    if(getenv("ILQG_COMPACT_GROUPS")) groups = atoi(getenv("ILQG_COMPACT_GROUPS"));
+    w = ilqg_batch_create_groups(c->device, n, c->N, groups);
+    if(!w) return NULL;
+    w->opt = c->opt;
+    memcpy(w->alpha_store, c->opt.alpha, sizeof(double) * c->opt.n_alpha);
+    w->opt.alpha = w->alpha_store;
+    w->resweep = c->resweep; w->fuse_derivs = c->fuse_derivs; w->ls_split = c->ls_split; w->ls_keep = c->ls_keep; w->bw_split = c->bw_split;
+    for(i = 0; i < n_params; i++) {
+        memcpy(w->p[i], c->p[i], sizeof(double) * param_len(c, i));
+        w->p_given[i] = c->p_given[i];
     }
-    return 0;
+    if(push_config(w)) {
+        snprintf(c->err, sizeof(c->err), "%s", w->err);
+        ilqg_batch_destroy(w);
+        return NULL;
+    }
+    return w;
+}
+
+int ilqg_batch_solve(ilqg_batch_t *c) {
+    int it, active = 1, rc = 0, j;
+    ilqg_batch_t *cur = c;  /* the context being iterated; map[j]: the trajectory of c in its slot j */
+    int *map = NULL, *status = NULL, *ident = NULL;
+    const int dbg = getenv("ILQG_SOLVE_DEBUG") != NULL;
+    double t_dbg = 0.0, t_poll = 0.0;
+    if(push_config(c)) return 1;
+    c->trace_n = 0;
+    t_poll = dbg ? now_s() : 0.0;
+    c->compactions = 0;
+    /* poll the active count every few iterations: one small D2H copy */
+    for(it = 0; it < c->opt.max_iter && active; ) {
+        int n = c->opt.max_iter - it < 4 ? c->opt.max_iter - it : 4;
+        if(iterate_groups(cur, n)) { rc = 1; break; }
+        it += n;
+        if(ilqg_batch_active(cur, &active)) { rc = 1; break; }
+        if(dbg && it % 40 == 0) {
+            fprintf(stderr, "ilqg solve: iteration %d, %d live of %d slots, %.2f ms per iteration\n", it, active, cur->B, 1e3 * (now_s() - t_poll) / 4);
+        }
+        t_poll = dbg ? now_s() : 0.0;
+        if(c->trace_n < ILQG_TRACE_MAX) {
+            c->trace_it[c->trace_n] = it;
+            c->trace_active[c->trace_n] = active;
+            c->trace_slots[c->trace_n] = cur->B;
+            c->trace_n++;
+        }
+        if(c->compact > 0 && active > 0 && it < c->opt.max_iter && 2 * active <= cur->B && active >= c->compact) {
+            ilqg_batch_t *w;
+            int *nmap, m = 0;
+            /* who is live (in cur's numbering), and where each lives in c */
+            status = (int *)realloc(status, sizeof(int) * cur->B);
+            if(each_read_int(cur, ILQG_I_STATUS, status, "status")) { rc = 1; break; }
+            if(cur != c) {  /* everything cur holds goes home first: its finished trajectories are results */
+                ident = (int *)realloc(ident, sizeof(int) * cur->B);
+                for(j = 0; j < cur->B; j++) ident[j] = j;
+                if(move_between(c, cur, cur->B, map, ident)) { rc = 1; break; }
+            }
+            nmap = (int *)malloc(sizeof(int) * active);
+            for(j = 0; j < cur->B && m < active; j++)
+                if(status[j] == ILQG_ST_ACTIVE) nmap[m++] = (cur == c) ? j : map[j];
+            t_dbg = dbg ? now_s() : 0.0;
+            w = working_copy(c, m);
+            if(!w) { free(nmap); rc = 1; break; }
+            if(dbg) fprintf(stderr, "ilqg solve: iteration %d, %d live of %d slots: new context %.1f ms", it, m, cur->B, 1e3 * (now_s() - t_dbg));
+            t_dbg = dbg ? now_s() : 0.0;
+            ident = (int *)realloc(ident, sizeof(int) * (m > cur->B ? m : cur->B));
+            for(j = 0; j < m; j++) ident[j] = j;
+            if(move_between(w, c, m, ident, nmap)) { snprintf(c->err, sizeof(c->err), "%s", w->err); ilqg_batch_destroy(w); free(nmap); rc = 1; break; }
+            if(dbg) fprintf(stderr, ", gather %.1f ms", 1e3 * (now_s() - t_dbg));
+            t_dbg = dbg ? now_s() : 0.0;
+            if(cur != c) ilqg_batch_destroy(cur);
+            if(dbg) fprintf(stderr, ", release %.1f ms\n", 1e3 * (now_s() - t_dbg));
+            free(map);
+            cur = w;
+            map = nmap;
+            c->compactions++;
+        }
+    }
+    if(cur != c) {
+        if(!rc) {
+            ident = (int *)realloc(ident, sizeof(int) * cur->B);
+            for(j = 0; j < cur->B; j++) ident[j] = j;
+            if(move_between(c, cur, cur->B, map, ident)) rc = 1;
+        } else {
+            snprintf(c->err, sizeof(c->err), "%s", cur->err);
+        }
+        ilqg_batch_destroy(cur);
+    }
+    free(map);
+    free(status);
+    free(ident);
+    return rc;
+}
+
+/* the last ilqg_batch_solve, poll by poll (every 4 iterations): iterations done so far, trajectories still active, slots the
+ * iterations ran over (the batch, or the smaller context the live trajectories had been gathered into); returns the number
+ * of polls (at most cap are written), *compactions = how often the live set was gathered */
+int ilqg_batch_solve_trace(ilqg_batch_t *c, int *iterations, int *active, int *slots, int cap, int *compactions) {
+    int i;
+    for(i = 0; i < c->trace_n && i < cap; i++) {
+        if(iterations) iterations[i] = c->trace_it[i];
+        if(active) active[i] = c->trace_active[i];
+        if(slots) slots[i] = c->trace_slots[i];
+    }
+    if(compactions) *compactions = c->compactions;
+    return c->trace_n;
 }
 
 int ilqg_batch_sync(ilqg_batch_t *c) {

@@ -167,6 +167,10 @@ int ilqg_dev_update(ilqg_dev_t *d);           /* accept/reject bookkeeping (iLQG
 int ilqg_dev_iterate(ilqg_dev_t *d, int n);   /* n lock-step iterations */
 int ilqg_dev_sync(ilqg_dev_t *d);
 int ilqg_dev_count_active(ilqg_dev_t *d, int *n_active); /* synchronises */
+/* solver state of trajectories from[0..count) of src -> trajectories to[0..count) of dst (same device and horizon): current
+ * x / u (they arrive in dst's arrays X / U), records, scalars, integers, multipliers; with_records: also the stored
+ * derivative records (contexts iterated with fuse_derivs = 0).  Synchronises both contexts. */
+int ilqg_dev_move(ilqg_dev_t *dst, ilqg_dev_t *src, int count, const int *to, const int *from, int with_records);
 
 /* builds with -DILQG_PROFILE_SECTIONS: cycles per section of the fused backward step, summed over wavefronts */
 int ilqg_dev_section_cycles(unsigned long long *out8);

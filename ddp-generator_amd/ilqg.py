@@ -234,6 +234,16 @@ class BatchSolver:
     def solve(self):
         self._ck(self.lib.ilqg_batch_solve(self.h))
 
+    def solve_trace(self):
+        """the last solve(), poll by poll: (iterations done, trajectories active, slots iterated over) arrays and the number
+        of times the active set was gathered into a smaller context (option "compact")"""
+        cap = 4096
+        it, act, slots = (np.zeros(cap, dtype=np.int32) for _ in range(3))
+        comp = C.c_int(0)
+        self.lib.ilqg_batch_solve_trace.argtypes = [C.c_void_p, _ip, _ip, _ip, C.c_int, C.POINTER(C.c_int)]
+        n = min(cap, self.lib.ilqg_batch_solve_trace(self.h, it, act, slots, cap, C.byref(comp)))
+        return it[:n].copy(), act[:n].copy(), slots[:n].copy(), comp.value
+
     def sync(self):
         self._ck(self.lib.ilqg_batch_sync(self.h))
 

@@ -83,6 +83,13 @@ const char *ilqg_batch_error(const ilqg_batch_t *c);
  *                 (derivatives of step k-1 on one, Riccati update of step k on the other, hand-over in
  *                 LDS) where the problem allows it (no multipliers, constant limits).  Same results;
  *                 measured no faster.
+ *   "compact"     default 0.  n > 0: ilqg_batch_solve retires finished trajectories — between iterations, once at most
+ *                 half of the slots it iterates over are still active (and at least n are), the active trajectories are
+ *                 gathered into a smaller context and iterated there; they return to their own slots of this batch when
+ *                 they are gathered again or the solve ends, so every getter reads this batch as before.  Same results
+ *                 bit for bit (a trajectory's iterations depend on nothing but its own state); a solve whose
+ *                 trajectories converge at very different iterations (CarParking: 50 to 550) does not run 64-lane
+ *                 wavefronts for one live lane.  Reference: the loop exits of iLQG.c:297-303, :331, :365-378.
  * Defaults = standard_parameters() (iLQG.c:57-78). */
 int ilqg_batch_set_option(ilqg_batch_t *c, const char *name, const double *value, int n);
 /* problem parameter by name, shared by all trajectories (iLQG_mex.c:70-84) */
@@ -104,6 +111,10 @@ int ilqg_batch_iterate(ilqg_batch_t *c, int n);
 int ilqg_batch_solve(ilqg_batch_t *c);
 int ilqg_batch_sync(ilqg_batch_t *c);
 int ilqg_batch_active(ilqg_batch_t *c, int *n_active);
+/* the last ilqg_batch_solve, poll by poll (it polls every 4 iterations): iterations done so far, trajectories still
+ * active, slots the iterations ran over (the batch, or the smaller context of option "compact"); returns the number of
+ * polls (at most cap entries are written; any pointer may be NULL), *compactions = how often the active set was gathered */
+int ilqg_batch_solve_trace(ilqg_batch_t *c, int *iterations, int *active, int *slots, int cap, int *compactions);
 
 /* single stages, for tests and for callers that interleave their own work */
 int ilqg_batch_calc_derivs(ilqg_batch_t *c);
