@@ -189,6 +189,11 @@ CONFIG5_VARIANTS = {
                "row mapping: one wavefront per trajectory in the backward step (k_backward_wave), records are the "
                "reference's trajEl_t with the tensors fxx / fuu / fxu stored by the generated bp_derivsL (47.9 KB per "
                "step) and contracted from HBM (back_pass.c:95-131): the path of a generated pair without hints"),
+    # the n = 16 problem with pairwise state products in the nonlinearity (problems/defs/synth16p.py): the generator's
+    # hints are there (roll-outs in parts) but the tensors do not factor — stored tensors again
+    "pair": ("synth16p", "traffic_config5_pair.json", ("k_backward_wave<false>", "issue_config5_pair.json"),
+             "k_derivs_wave<false> + k_backward_wave<false> + roll-outs in parts",
+             "row mapping, stored tensors (the second derivatives of f_i are not multiples of one product: no tables)"),
 }
 
 
@@ -199,7 +204,8 @@ def config5(ilqg, synth, local, K=3, W=1, with_cpu=True, variant="factored"):
     problem, traffic_file, (issue_kernel, issue_file), kernels_label, mapping = CONFIG5_VARIANTS[variant]
     alg = algorithmic_bytes(nx, nu, 1)
     x0, u0 = synth.synth16_batch(B, N)
-    s = ilqg.BatchSolver(problem, 1, batch=B, n_hor=N, device=local, params=synth.SYNTH16_PARAMS,
+    params = dict(synth.SYNTH16_PARAMS, e=[0.3]) if variant == "pair" else synth.SYNTH16_PARAMS
+    s = ilqg.BatchSolver(problem, 1, batch=B, n_hor=N, device=local, params=params,
                          opts=dict(max_iter=K + W + 1))
     s.init(x0, u0)
     if W > 0:
@@ -461,6 +467,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config5-variant", choices=("factored", "stored", "pair"), default=None,
+                    help="only BASELINE config 5 in one of its forms (the object `config5` of the default line), as its own JSON line")
     ap.add_argument("--workload", choices=("car", "synth"), default="car",
                     help="car: BASELINE metric (CarParking n=4,m=2,N=500, 65 536 per GPU); synth: BASELINE config 5 "
                          "(n=16,m=8,N=1000, FULL_DDP=1, 16 384 per GPU, one wavefront per trajectory) as the headline")
@@ -508,6 +516,9 @@ def main():
     rank, local, world = pkg.dist.env_world()
     if args.single_process and world == 1 and args.gpus > 1:
         return single_process(args, ilqg, synth)
+    if args.config5_variant:
+        print(json.dumps(config5(ilqg, synth, local, K=args.steps if args.steps != 20 else 3, W=min(args.warmup, 1), with_cpu=False, variant=args.config5_variant)))
+        return
     if args.solve:
         assert world == 1 and args.workload == "car", "--solve: one GPU, CarParking"
         print(json.dumps(full_solve(ilqg, synth, local, B=args.batch or 65536, n_hor=args.n_hor or 500, max_iter=args.max_iter, compact=args.compact)))

@@ -48,6 +48,9 @@ SYN_PARAMS = dict(h=[0.05], c=[0.8], px=[0.1], ru=[0.05] * 8, qx=[0.02 + 0.01 * 
 
 # the same with tight input limits, so that short-horizon test solves run on the limits
 SYN_PARAMS_TIGHT = dict(SYN_PARAMS, lim=[-0.25, 0.25])
+# problems/defs/synth16p.py: synth16x8 with pairwise state products in the nonlinearity (tensors not factorable)
+SYNP_PARAMS = dict(SYN_PARAMS, e=[0.3])
+SYNP_PARAMS_TIGHT = dict(SYN_PARAMS_TIGHT, e=[0.3])
 
 
 def syn_inputs(batch, n_hor, first=0, seed=20261003):

@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT as SYN_PARAMS, Driver, Kernels, almix_case, brachi_case,  # noqa: E402
+from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT as SYN_PARAMS, SYNP_PARAMS_TIGHT, Driver, Kernels, almix_case, brachi_case,  # noqa: E402
                             brachi_hli_case, hx_inputs, lib_path, syn_inputs)
 
 spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "ddp-generator_amd", "synth.py"))
@@ -338,13 +338,14 @@ def hx_goldens(fd):
           (fd, out["it3_bp_rc"], out["it3_ls_index"], int(np.count_nonzero(hxcols)), rcs, its))
 
 
-def synth_goldens(fd, N=32):
+def synth_goldens(fd, N=32, problem="synth16x8", SYN_PARAMS=SYN_PARAMS):
     """synthetic n=16, m=8 problem (BASELINE config 5) on a short horizon: single pass at the start and
-    after 3 iterations (inputs on their limits), line search, and full solves"""
+    after 3 iterations (inputs on their limits), line search, and full solves; problem "synth16p": the variant whose
+    tensors do not factor (problems/defs/synth16p.py), FULL_DDP = 1, a shorter horizon (the records carry the tensors)"""
     x0s, u0s = syn_inputs(4, N)
     out = dict(x0=x0s, u0=u0s, n_hor=N)
     for tag, pre in (("", 0), ("it3_", 3)):
-        d = Driver(lib_path("ref", "synth16x8", fd), N, SYN_PARAMS, dict(max_iter=max(pre, 1)))
+        d = Driver(lib_path("ref", problem, fd), N, SYN_PARAMS, dict(max_iter=max(pre, 1)))
         assert d.init(x0s[0], u0s[0]) == 1
         if pre:
             d.solve()
@@ -369,16 +370,16 @@ def synth_goldens(fd, N=32):
         d.close()
     rcs, its, costs, xs = [], [], [], []
     for b in range(len(x0s)):
-        d = Driver(lib_path("ref", "synth16x8", fd), N, SYN_PARAMS, dict(max_iter=100))
+        d = Driver(lib_path("ref", problem, fd), N, SYN_PARAMS, dict(max_iter=100))
         assert d.init(x0s[b], u0s[b]) == 1
         with quiet():
             rcs.append(d.solve())
         sc = d.scalars(); its.append(int(sc["iterations"])); costs.append(sc["cost"]); xs.append(d.traj(0)[0])
         d.close()
     out.update(solve_rc=np.array(rcs), solve_iterations=np.array(its), solve_cost=np.array(costs), solve_x=np.array(xs))
-    np.savez_compressed(os.path.join(HERE, "synth16x8_fd%d.npz" % fd), **out)
+    np.savez_compressed(os.path.join(HERE, "%s_fd%d.npz" % (problem, fd)), **out)
     clamped = int(np.sum(np.abs(np.abs(out["it3_u_nom"]) - 0.25) < 1e-12))
-    print("synth16x8 fd%d: rc %d/%d alpha idx %d/%d, inputs on a limit at it3: %d, solves %s iterations %s" %
+    print(problem + " fd%d: rc %d/%d alpha idx %d/%d, inputs on a limit at it3: %d, solves %s iterations %s" %
           (fd, out["bp_rc"], out["it3_bp_rc"], out["ls_index"], out["it3_ls_index"], clamped, rcs, its))
 
 
@@ -451,7 +452,7 @@ def almix_goldens():
 
 
 def main(argv):
-    """all fixtures, or only the named groups: brachi almix kernels car lockstep hx regtype2 synth"""
+    """all fixtures, or only the named groups: brachi almix kernels car lockstep hx regtype2 synth synthp"""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     groups = {
         "brachi": brachi_goldens,
@@ -462,6 +463,7 @@ def main(argv):
         "hx": lambda: [hx_goldens(fd) for fd in (0, 1)],
         "regtype2": regtype2_goldens,
         "synth": lambda: [synth_goldens(fd) for fd in (0, 1)],
+        "synthp": lambda: synth_goldens(1, N=12, problem="synth16p", SYN_PARAMS=SYNP_PARAMS_TIGHT),
     }
     for name in (argv or list(groups)):
         groups[name]()

@@ -11,7 +11,9 @@ import numpy as np
 import pytest
 
 from conftest import golden, load_package
-from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS, SYN_PARAMS_TIGHT, Driver, hx_inputs, lib_path, syn_inputs
+from oracle.harness import CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS, SYN_PARAMS_TIGHT, SYNP_PARAMS_TIGHT, Driver, hx_inputs, lib_path, syn_inputs
+
+SYN_TIGHT = SYN_PARAMS_TIGHT
 
 pytestmark = pytest.mark.gpu
 
@@ -689,12 +691,15 @@ def test_regtype2_golden(ilqg, fd):
 # ---------------------------------------------------------------------------
 # wave mapping (one wavefront per trajectory): n=16/m=8 synthetic problem, and CarParking forced into it
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["", "_plain"])
-@pytest.mark.parametrize("fd", [0, 1])
+@pytest.mark.parametrize("fd,variant", [(0, ""), (1, ""), (0, "_plain"), (1, "_plain"), (1, "p")])
 def test_wave_mapping_synthetic_golden(ilqg, fd, variant):
-    g = golden("synth16x8_fd%d.npz" % fd)
+    """variant "_plain": the same problem emitted without hints or tables; "p": synth16p, the n = 16 problem whose
+    tensors do not factor (pairwise state products in the nonlinearity) — both take the stored-tensor path"""
+    problem = "synth16p" if variant == "p" else "synth16x8" + variant
+    g = golden("%s_fd%d.npz" % ("synth16p" if variant == "p" else "synth16x8", fd))
     N = int(g["n_hor"])
-    s = ilqg.BatchSolver("synth16x8" + variant, fd, batch=1, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(ls_split=0))
+    SYN_PARAMS_TIGHT = SYNP_PARAMS_TIGHT if variant == "p" else SYN_TIGHT
+    s = ilqg.BatchSolver(problem, fd, batch=1, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(ls_split=0))
     assert s.problem.wave_mapping and (s.problem.nx, s.problem.nu) == (16, 8)
     s.init(g["x0"][:1], g["u0"][:1])
     assert close(s.scalar("cost")[0], g["cost"])
@@ -721,12 +726,12 @@ def test_wave_mapping_synthetic_golden(ilqg, fd, variant):
     # lock-step batch (ragged size) against the oracle, derivative records chunked through the work buffer
     B, iters = 5, 4
     x0, u0 = syn_inputs(B, N, first=40)
-    s = ilqg.BatchSolver("synth16x8" + variant, fd, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters))
+    s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters))
     s.init(x0, u0)
     s.iterate(iters)
     cost, x = s.scalar("cost"), s.x()
     for b in range(B):
-        d = Driver(lib_path("oracle", "synth16x8", fd), N, SYN_PARAMS_TIGHT, dict(max_iter=iters))
+        d = Driver(lib_path("oracle", "synth16p" if variant == "p" else "synth16x8", fd), N, SYN_PARAMS_TIGHT, dict(max_iter=iters))
         assert d.init(x0[b], u0[b]) == 1
         d.solve()
         assert close(cost[b], d.scalars()["cost"], 1e-9), (b, cost[b], d.scalars()["cost"])
@@ -1107,6 +1112,42 @@ def test_properties_at_config5_size(ilqg, synth, oracle_built):
     assert close(prev[b], d.scalars()["cost"], 1e-9), (prev[b], d.scalars()["cost"])
     assert np.abs(x_big[pick.index(b)] - d.traj(0)[0]).max() < 1e-7
     d.close()
+    # ALL eight against the CPU oracle, three iterations at the full horizon, teacher forced: before iteration i the
+    # product build (quad-mapped step: FMA contraction, one half sum of the symmetric products, the contraction's order,
+    # DESIGN 2.2) gets the oracle's state after i iterations and must reproduce the oracle's iteration i + 1 — the gains
+    # of its backward pass (the last sweep of the lambda retries) at the single-pass bar, the lambda they were made
+    # with and the accepted step size exactly, cost and trajectory to rounding (back_pass.c:163-241, line_search.c:37-75)
+    def oracle_after(bb, n_it):
+        dd = Driver(lib_path("oracle", "synth16x8", 1), N, SYN_PARAMS, dict(max_iter=max(n_it, 1)))
+        assert dd.init(x0[bb], u0[bb]) == 1
+        if n_it:
+            dd.solve()
+        sc, (xx, uu), (ll, LL), tr = dd.scalars(), dd.traj(0), dd.gains(), dd.trace()
+        dd.close()
+        return sc, xx, uu, ll, LL, tr
+    states = [[oracle_after(bb, i) for bb in pick] for i in range(4)]
+    small = ilqg.BatchSolver("synth16x8", 1, batch=len(pick), n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=50))
+    small.init(x0[pick], u0[pick])
+    worst_l = worst_L = 0.0
+    for i in range(3):
+        if i:
+            small.set_x(np.array([st[1] for st in states[i]]))
+            small.set_u(np.array([st[2] for st in states[i]]))
+            small.set_scalar("cost", np.array([st[0]["cost"] for st in states[i]]))
+            # (lambda / dlambda follow by themselves while the decisions agree — asserted below)
+        small.iterate(1)
+        l, L = small.gains()
+        cost, lam, aidx, xg = small.scalar("cost"), small.scalar("lambda"), small.ints("alpha_idx"), small.x()
+        for j, bb in enumerate(pick):
+            sc, xr, ur, lr, Lr, tr = states[i + 1][j]
+            assert aidx[j] == tr["alpha_idx"][i], (i, bb, aidx[j], tr["alpha_idx"][i])
+            assert close(lam[j], sc["lambda"], 1e-12), (i, bb)
+            assert close(l[j], lr) and close(L[j], Lr), (i, bb, worst(l[j], lr), worst(L[j], Lr))
+            worst_l, worst_L = max(worst_l, worst(l[j], lr)), max(worst_L, worst(L[j], Lr))
+            assert close(cost[j], sc["cost"], 1e-9), (i, bb, cost[j], sc["cost"])
+            assert np.abs(xg[j] - xr).max() < 1e-7, (i, bb)
+    small.close()
+    print("config 5, product build against the oracle over 3 x 8 trajectory-iterations: worst deviation of l %.2e, of L %.2e" % (worst_l, worst_L))
 
 
 def test_results_do_not_depend_on_stream_groups(ilqg, synth):

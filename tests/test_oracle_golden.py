@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver, Kernels, almix_case, brachi_case, brachi_hli_case,
+from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, SYNP_PARAMS_TIGHT, Driver, Kernels, almix_case, brachi_case, brachi_hli_case,
                             lib_path)
 
 
@@ -147,13 +147,15 @@ def check_hxtest(path, fd):
         d.close()
 
 
-@pytest.mark.parametrize("fd", [0, 1])
-def test_synthetic_16x8_problem(oracle_built, fd):
-    """n=16, m=8 with dense second derivatives (BASELINE config 5), short horizon"""
-    g = golden("synth16x8_fd%d.npz" % fd)
+@pytest.mark.parametrize("problem,fd", [("synth16x8", 0), ("synth16x8", 1), ("synth16p", 1)])
+def test_synthetic_16x8_problem(oracle_built, problem, fd):
+    """n=16, m=8 with dense second derivatives (BASELINE config 5), short horizon; synth16p: the variant with pairwise
+    state products in the nonlinearity, whose tensors do not factor (problems/defs/synth16p.py)"""
+    g = golden("%s_fd%d.npz" % (problem, fd))
     N = int(g["n_hor"])
+    params = SYNP_PARAMS_TIGHT if problem == "synth16p" else SYN_PARAMS_TIGHT
     for tag, pre in (("", 0), ("it3_", 3)):
-        d = Driver(lib_path("oracle", "synth16x8", fd), N, SYN_PARAMS_TIGHT, dict(max_iter=max(pre, 1)))
+        d = Driver(lib_path("oracle", problem, fd), N, params, dict(max_iter=max(pre, 1)))
         assert d.init(g["x0"][0], g["u0"][0]) == 1
         if pre:
             d.solve()
@@ -168,7 +170,7 @@ def test_synthetic_16x8_problem(oracle_built, fd):
         assert np.array_equal(d.traj(1)[0], g[tag + "x_cand"])
         d.close()
     b = 0
-    d = Driver(lib_path("oracle", "synth16x8", fd), N, SYN_PARAMS_TIGHT, dict(max_iter=100))
+    d = Driver(lib_path("oracle", problem, fd), N, params, dict(max_iter=100))
     assert d.init(g["x0"][b], g["u0"][b]) == 1
     assert d.solve() == g["solve_rc"][b] and d.scalars()["cost"] == g["solve_cost"][b]
     d.close()
