@@ -322,53 +322,67 @@ def dropin_b1(ilqg, synth, iters=20):
                     "so one trajectory cannot use the GPU — compare cpu_baseline.single_core_ms_per_trajectory_iteration"}
 
 
-def full_solve(ilqg, synth, local, B=65536, n_hor=500, max_iter=500, compact=2048):
+def solve_once(ilqg, synth, local, B, n_hor, max_iter, compact):
+    """one full solve of B CarParking starts in THIS process (see full_solve): seconds, trace, per-start results"""
+    x0, u0 = synth.car_batch(B, n_hor)
+    s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=n_hor, device=local, params=ilqg.CAR_PARAMS, opts=dict(max_iter=max_iter, compact=compact))
+    s.init(x0, u0)
+    s.sync()
+    t0 = time.perf_counter()
+    s.solve()
+    s.sync()
+    dt = time.perf_counter() - t0
+    it, act, slots, ncomp = s.solve_trace()
+    status, iters, cost = s.ints("status"), s.ints("iterations"), s.scalar("cost")
+    s.close()
+    import hashlib
+    digest = hashlib.sha256(status.tobytes() + iters.tobytes() + cost.tobytes()).hexdigest()[:16]
+    steps = np.diff(np.concatenate([[0], it]))              # iterations each poll covered
+    before = np.concatenate([[B], act[:-1]])                  # live when those iterations started
+    q = np.percentile(iters, [5, 25, 50, 75, 95])
+    names = {1: "gradient test", 2: "cost test", 3: "max_iter", 4: "lambda > lambdaMax (backward pass)", 5: "lambda > lambdaMax (rejected step)",
+             6: "NaN/Inf in derivatives", 7: "initial roll-out failed", 0: "still active"}
+    return {"seconds": dt, "value": B / dt, "iterations_run": int(it[-1]), "compactions": ncomp,
+            "slot_iterations": int((slots * steps).sum()), "live_lane_iterations_upper_bound": int((before * steps).sum()),
+            "lane_occupancy": float((before * steps).sum() / max(1, (slots * steps).sum())),
+            "occupancy_over_time": [{"iteration": int(a), "active": int(b), "slots": int(c)} for a, b, c in
+                                    list(zip(it, act, slots))[::max(1, len(it) // 16)]],
+            "results_digest": digest,
+            "iterations_per_start": {"min": int(iters.min()), "p5": q[0], "p25": q[1], "median": q[2], "p75": q[3], "p95": q[4],
+                                     "max": int(iters.max()), "mean": float(iters.mean())},
+            "exits": {names.get(int(k), str(k)): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
+            "cost_mean": float(cost.mean())}
+
+
+def full_solve(local, B=65536, n_hor=500, max_iter=500, compact=2048):
     """The reference's product — a solve to convergence (iLQG.c:224-379) — for a batch of CarParking starts: solves/s with
     and without retiring finished trajectories (option "compact": the live trajectories are gathered into smaller contexts,
     ilqg_host.c ilqg_batch_solve), the iterations the starts need, and how many of the lanes the iterations ran over were
-    live.  The same starts, the same results bit for bit (asserted here on cost / status / iterations)."""
-    x0, u0 = synth.car_batch(B, n_hor)
+    live.  The same starts, the same results bit for bit (digest of cost / status / iterations).  Each solve runs in a
+    process of its own: a context that shares the process with another one — or follows one that was released — has been
+    measured up to 50 % slower per iteration (the streams of all contexts share the process's four hardware queues)."""
+    import subprocess
     out = {"metric": "iLQG solves/sec, %d CarParking starts (n=4,m=2,N=%d), max_iter %d" % (B, n_hor, max_iter), "unit": "solves/s",
            "config": {"workload": "CarParking batch=%d randomised x0 (the benchmark's generator), u0 = 0.1 N(0,1), solved to the reference's "
                                   "exit tests (iLQG.c:297-303, :331, :365-378), max_iter %d (testCar.m:19 has 200), default options" % (B, max_iter),
                       "compact_min_trajectories": compact}}
-    ref = None
-    # (both contexts are made before either solve, so that both get fresh device memory and the same stream set-up order
-    # does not favour one: a context made after another one was released has been seen 50 % slower per iteration)
-    solvers = [(label, ilqg.BatchSolver("carparking", 0, batch=B, n_hor=n_hor, device=local, params=ilqg.CAR_PARAMS, opts=dict(max_iter=max_iter, compact=cmin)))
-               for label, cmin in (("plain", 0), ("compacted", compact))]
-    for label, s in solvers:
-        s.init(x0, u0)
-        s.sync()
-    for label, s in solvers:
-        t0 = time.perf_counter()
-        s.solve()
-        s.sync()
-        dt = time.perf_counter() - t0
-        it, act, slots, ncomp = s.solve_trace()
-        status, iters, cost = s.ints("status"), s.ints("iterations"), s.scalar("cost")
-        s.close()
-        steps = np.diff(np.concatenate([[0], it]))              # iterations each poll covered
-        before = np.concatenate([[B], act[:-1]])                  # live when those iterations started
-        o = {"seconds": dt, "value": B / dt, "iterations_run": int(it[-1]), "compactions": ncomp,
-             "slot_iterations": int((slots * steps).sum()), "live_lane_iterations_upper_bound": int((before * steps).sum()),
-             "lane_occupancy": float((before * steps).sum() / max(1, (slots * steps).sum())),
-             "occupancy_over_time": [{"iteration": int(a), "active": int(b), "slots": int(c)} for a, b, c in
-                                     list(zip(it, act, slots))[::max(1, len(it) // 16)]]}
-        if ref is None:
-            ref = (status, iters, cost)
-            q = np.percentile(iters, [5, 25, 50, 75, 95])
-            names = {1: "gradient test", 2: "cost test", 3: "max_iter", 4: "lambda > lambdaMax (backward pass)", 5: "lambda > lambdaMax (rejected step)",
-                     6: "NaN/Inf in derivatives", 7: "initial roll-out failed", 0: "still active"}
-            out["iterations_per_start"] = {"min": int(iters.min()), "p5": q[0], "p25": q[1], "median": q[2], "p75": q[3], "p95": q[4],
-                                           "max": int(iters.max()), "mean": float(iters.mean())}
-            out["exits"] = {names.get(int(k), str(k)): int(v) for k, v in zip(*np.unique(status, return_counts=True))}
-            out["cost_mean"] = float(cost.mean())
-        else:
-            o["identical_to_plain"] = bool(np.array_equal(status, ref[0]) and np.array_equal(iters, ref[1]) and np.array_equal(cost, ref[2]))
-        out[label] = o
+    for label, cmin in (("plain", 0), ("compacted", compact)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--solve-one", str(cmin), "--batch", str(B), "--n-hor", str(n_hor), "--max-iter", str(max_iter)]
+        env = dict(os.environ, ILQG_DEVICE_ORDINAL=str(local))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError("%s solve failed: %s" % (label, r.stderr[-500:]))
+        out[label] = json.loads(lines[-1])
+    for k in ("iterations_per_start", "exits", "cost_mean"):
+        out[k] = out["plain"].pop(k)
+        out["compacted"].pop(k)
+    out["compacted"]["identical_to_plain"] = out["compacted"]["results_digest"] == out["plain"]["results_digest"]
     out["value"] = out["compacted"]["value"]
     out["speedup_from_compaction"] = out["compacted"]["value"] / out["plain"]["value"]
+    out["note"] = ("retiring finished trajectories raises the share of live lanes among the lanes iterated (lane_occupancy) but hardly the "
+                   "rate: an iteration of a few thousand CarParking trajectories takes what an iteration of 65 536 takes — the chains of "
+                   "n_hor dependent steps of its backward sweep and two search stages, one wavefront per SIMD either way")
     return out
 
 
@@ -490,6 +504,7 @@ def main():
     ap.add_argument("--solve", action="store_true",
                     help="full solves instead of the benchmark window: --batch CarParking starts solved to convergence (max_iter "
                          "--max-iter), with and without retiring finished trajectories; prints its own JSON line")
+    ap.add_argument("--solve-one", type=int, default=None, help="(used by --solve) ONE full solve in this process with this `compact` setting")
     ap.add_argument("--max-iter", type=int, default=500)
     ap.add_argument("--compact", type=int, default=2048, help="--solve: smallest live set still gathered into a smaller context")
     ap.add_argument("--single-process", action="store_true",
@@ -519,9 +534,13 @@ def main():
     if args.config5_variant:
         print(json.dumps(config5(ilqg, synth, local, K=args.steps if args.steps != 20 else 3, W=min(args.warmup, 1), with_cpu=False, variant=args.config5_variant)))
         return
+    if args.solve_one is not None:
+        local = int(os.environ.get("ILQG_DEVICE_ORDINAL", local))
+        print(json.dumps(solve_once(ilqg, synth, local, args.batch or 65536, args.n_hor or 500, args.max_iter, args.solve_one)))
+        return
     if args.solve:
         assert world == 1 and args.workload == "car", "--solve: one GPU, CarParking"
-        print(json.dumps(full_solve(ilqg, synth, local, B=args.batch or 65536, n_hor=args.n_hor or 500, max_iter=args.max_iter, compact=args.compact)))
+        print(json.dumps(full_solve(local, B=args.batch or 65536, n_hor=args.n_hor or 500, max_iter=args.max_iter, compact=args.compact)))
         return
     rehearsal = args.rehearse_protocol
     if rehearsal:
@@ -767,7 +786,7 @@ def main():
             except Exception as e:
                 out["config2"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
-                out["full_solve"] = full_solve(ilqg, synth, local)
+                out["full_solve"] = full_solve(local)
             except Exception as e:
                 out["full_solve"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if not args.no_config5:

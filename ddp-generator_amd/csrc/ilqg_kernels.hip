@@ -375,6 +375,13 @@ extern "C" {
 // the file at build time (csrc/Makefile); ILQG_* names, the additive surface the kernels ask for, stay.
 #include "ilqg_problem_undefs.h"
 
+// Measured negative results that are kept tested — the fused backward pass on two wavefronts (k_backward_split), the
+// derivative record in parts (k_derivs_parts), the box QP's pattern tables (box_qp<M, true>) — are compiled into the
+// -DILQG_EXPERIMENTS=1 libraries only (csrc/Makefile EXP_LIBS, lib*_exp.so): the product libraries, and every
+// measure-change-measure loop on them, do not pay for their compilation.
+#ifndef ILQG_EXPERIMENTS
+#define ILQG_EXPERIMENTS 0
+#endif
 #include "ilqg_device.hpp"
 #include "ilqg_wave.hpp"
 #include "ilqg_row.hpp"
