@@ -354,6 +354,28 @@ def solve_once(ilqg, synth, local, B, n_hor, max_iter, compact):
             "cost_mean": float(cost.mean())}
 
 
+def solve_stream_once(ilqg, synth, local, B, n_hor, max_iter, total):
+    """`total` CarParking starts streamed through B resident slots (ilqg_batch_solve_stream) in THIS process: the starts
+    come from host memory (x0, u0 of every refill cross PCIe inside the timed region), cost / exit / iterations go back"""
+    x0, u0 = synth.car_batch(total, n_hor)
+    s = ilqg.BatchSolver("carparking", 0, batch=B, n_hor=n_hor, device=local, params=ilqg.CAR_PARAMS, opts=dict(max_iter=max_iter))
+    s.sync()
+    t0 = time.perf_counter()
+    r = s.solve_stream(x0, u0)
+    s.sync()
+    dt = time.perf_counter() - t0
+    it, act, slots, refills = s.solve_trace()
+    s.close()
+    import hashlib
+    digest_first_batch = hashlib.sha256(r["status"][:B].tobytes() + r["iterations"][:B].tobytes() + r["cost"][:B].tobytes()).hexdigest()[:16]
+    steps = np.diff(np.concatenate([[0], it]))
+    return {"seconds": dt, "value": total / dt, "starts": total, "resident_slots": B, "iterations_run": int(it[-1]), "refills": refills,
+            "lane_occupancy": float((act[1:] * steps[1:]).sum() / max(1, (slots[1:] * steps[1:]).sum())) if len(it) > 1 else None,
+            "results_digest_of_the_first_%d_starts" % B: digest_first_batch,
+            "iterations_mean": float(r["iterations"].mean()), "cost_mean": float(r["cost"].mean()),
+            "inputs": "host memory: x0 / u0 of every refill cross PCIe inside the timed region (%.2f GB in all)" % (u0.nbytes / 1e9)}
+
+
 def full_solve(local, B=65536, n_hor=500, max_iter=500, compact=2048):
     """The reference's product — a solve to convergence (iLQG.c:224-379) — for a batch of CarParking starts: solves/s with
     and without retiring finished trajectories (option "compact": the live trajectories are gathered into smaller contexts,
@@ -374,12 +396,21 @@ def full_solve(local, B=65536, n_hor=500, max_iter=500, compact=2048):
         if r.returncode != 0 or not lines:
             raise RuntimeError("%s solve failed: %s" % (label, r.stderr[-500:]))
         out[label] = json.loads(lines[-1])
+    # a stream of 3 x B starts through the B slots (ilqg_batch_solve_stream): finished slots are refilled
+    cmd = [sys.executable, os.path.abspath(__file__), "--solve-stream", str(3 * B), "--batch", str(B), "--n-hor", str(n_hor), "--max-iter", str(max_iter)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, ILQG_DEVICE_ORDINAL=str(local)))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    out["streamed"] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": r.stderr[-500:]}
+    if "value" in out["streamed"]:
+        out["streamed"]["first_batch_identical_to_plain"] = out["streamed"]["results_digest_of_the_first_%d_starts" % B] == out["plain"]["results_digest"]
     for k in ("iterations_per_start", "exits", "cost_mean"):
         out[k] = out["plain"].pop(k)
         out["compacted"].pop(k)
     out["compacted"]["identical_to_plain"] = out["compacted"]["results_digest"] == out["plain"]["results_digest"]
-    out["value"] = out["compacted"]["value"]
+    out["value"] = max(out["compacted"]["value"], out["streamed"].get("value", 0.0))
     out["speedup_from_compaction"] = out["compacted"]["value"] / out["plain"]["value"]
+    if "value" in out["streamed"]:
+        out["speedup_from_streaming"] = out["streamed"]["value"] / out["plain"]["value"]
     out["note"] = ("retiring finished trajectories raises the share of live lanes among the lanes iterated (lane_occupancy) but hardly the "
                    "rate: an iteration of a few thousand CarParking trajectories takes what an iteration of 65 536 takes — the chains of "
                    "n_hor dependent steps of its backward sweep and two search stages, one wavefront per SIMD either way")
@@ -505,6 +536,7 @@ def main():
                     help="full solves instead of the benchmark window: --batch CarParking starts solved to convergence (max_iter "
                          "--max-iter), with and without retiring finished trajectories; prints its own JSON line")
     ap.add_argument("--solve-one", type=int, default=None, help="(used by --solve) ONE full solve in this process with this `compact` setting")
+    ap.add_argument("--solve-stream", type=int, default=None, help="(used by --solve) that many starts streamed through --batch resident slots, in this process")
     ap.add_argument("--max-iter", type=int, default=500)
     ap.add_argument("--compact", type=int, default=2048, help="--solve: smallest live set still gathered into a smaller context")
     ap.add_argument("--single-process", action="store_true",
@@ -533,6 +565,10 @@ def main():
         return single_process(args, ilqg, synth)
     if args.config5_variant:
         print(json.dumps(config5(ilqg, synth, local, K=args.steps if args.steps != 20 else 3, W=min(args.warmup, 1), with_cpu=False, variant=args.config5_variant)))
+        return
+    if args.solve_stream is not None:
+        local = int(os.environ.get("ILQG_DEVICE_ORDINAL", local))
+        print(json.dumps(solve_stream_once(ilqg, synth, local, args.batch or 65536, args.n_hor or 500, args.max_iter, args.solve_stream)))
         return
     if args.solve_one is not None:
         local = int(os.environ.get("ILQG_DEVICE_ORDINAL", local))

@@ -659,6 +659,109 @@ int ilqg_batch_solve(ilqg_batch_t *c) {
     return rc;
 }
 
+/* ---- a STREAM of starts through the resident batch ------------------------------------------------------------------
+ * An iteration of the lane mapping costs what its chains of n_hor dependent steps cost, for 600 trajectories as for 65 536
+ * (one wavefront per SIMD either way): a solve's rate is decided by how many of the batch's slots hold a live trajectory.
+ * Here finished trajectories do not just leave — their slots are given to the next starts of the stream: every
+ * ILQG_STREAM_ROUND iterations the finished slots are harvested (cost, exit reason, iteration count; the trajectory if the
+ * caller wants it) and, once enough are free, refilled: the new starts are initialised in a small staging context
+ * (initial roll-out + solver entry state, exactly ilqg_batch_init) and moved into the free slots (ilqg_dev_move).  A
+ * trajectory's iterations depend on nothing but its own state, so every start gets the result a plain ilqg_batch_solve
+ * of a batch holding it would give, bit for bit (tests/test_gpu_solve.py). */
+#define ILQG_STREAM_ROUND 8
+#define ILQG_STREAM_STAGE 8192
+int ilqg_batch_solve_stream(ilqg_batch_t *c, int total, const double *x0, const double *u0, double *cost, int *status,
+                            int *iterations, double *x, double *u) {
+    int dims[8], NXd, NUd, B = c->B, N = c->N, j, rc = 0, next = 0, n_done = 0, it = 0, active = 0, n_free;
+    int *slot = NULL, *st = NULL, *its = NULL, *freel = NULL, *ident = NULL, *fin = NULL;
+    double *cst = NULL, *xs = NULL, *us = NULL, *hx = NULL, *hu = NULL;
+    ilqg_batch_t *stage = NULL;
+    const int S = B < ILQG_STREAM_STAGE ? B : ILQG_STREAM_STAGE;
+    if(total < 1) return fail_msg(c, "ilqg_batch_solve_stream: no starts");
+    if(push_config(c)) return 1;
+    ilqg_dev_dims(dims);
+    NXd = dims[0];
+    NUd = dims[1];
+    slot = (int *)malloc(sizeof(int) * B); st = (int *)malloc(sizeof(int) * B); its = (int *)malloc(sizeof(int) * B);
+    freel = (int *)malloc(sizeof(int) * B); ident = (int *)malloc(sizeof(int) * B); fin = (int *)malloc(sizeof(int) * B);
+    cst = (double *)malloc(sizeof(double) * B);
+    xs = (double *)calloc((size_t)S * NXd, sizeof(double));
+    us = (double *)calloc((size_t)S * N * NUd, sizeof(double));
+    for(j = 0; j < B; j++) { slot[j] = -1; st[j] = ILQG_ST_MAX_ITER; ident[j] = j; }
+    /* every slot is free and says so to the kernels */
+    if(each_write_int(c, ILQG_I_STATUS, st, "status")) { rc = 1; goto done; }
+    stage = working_copy(c, S);
+    if(!stage) { rc = 1; goto done; }
+    c->trace_n = 0;
+    c->compactions = 0;
+    for(;;) {
+        /* harvest what has finished */
+        if(each_read_int(c, ILQG_I_STATUS, st, "status")) { rc = 1; break; }
+        {
+            int m = 0;
+            active = 0;
+            for(j = 0; j < B; j++) {
+                if(slot[j] < 0) continue;
+                if(st[j] == ILQG_ST_ACTIVE) active++;
+                else fin[m++] = j;
+            }
+            if(m) {
+                if(each_read(c, ILQG_F_COST, cst, "cost") || each_read_int(c, ILQG_I_ITER, its, "iterations")) { rc = 1; break; }
+                if(x || u) {  /* the finished trajectories, through a context of their own */
+                    ilqg_batch_t *h = working_copy(c, m);
+                    if(!h) { rc = 1; break; }
+                    if(move_between(h, c, m, ident, fin)) { ilqg_batch_destroy(h); rc = 1; break; }
+                    hx = (double *)realloc(hx, sizeof(double) * (size_t)m * (N + 1) * NXd);
+                    hu = (double *)realloc(hu, sizeof(double) * (size_t)m * N * NUd);
+                    if((x && ilqg_batch_get_x(h, hx)) || (u && ilqg_batch_get_u(h, hu))) { snprintf(c->err, sizeof(c->err), "%s", h->err); ilqg_batch_destroy(h); rc = 1; break; }
+                    ilqg_batch_destroy(h);
+                }
+                for(j = 0; j < m; j++) {
+                    const int b = fin[j], s0 = slot[b];
+                    if(cost) cost[s0] = cst[b];
+                    if(status) status[s0] = st[b];
+                    if(iterations) iterations[s0] = its[b];
+                    if(x) memcpy(x + (size_t)s0 * (N + 1) * NXd, hx + (size_t)j * (N + 1) * NXd, sizeof(double) * (N + 1) * NXd);
+                    if(u) memcpy(u + (size_t)s0 * N * NUd, hu + (size_t)j * N * NUd, sizeof(double) * N * NUd);
+                    slot[b] = -1;
+                }
+                n_done += m;
+            }
+        }
+        if(c->trace_n < ILQG_TRACE_MAX) {
+            c->trace_it[c->trace_n] = it;
+            c->trace_active[c->trace_n] = active;
+            c->trace_slots[c->trace_n] = B;
+            c->trace_n++;
+        }
+        if(n_done >= total) break;
+        /* refill: once a sixteenth of the slots is free, or nothing is left to iterate */
+        n_free = 0;
+        for(j = 0; j < B; j++)
+            if(slot[j] < 0) freel[n_free++] = j;
+        while(next < total && n_free > 0 && (n_free >= B / 16 || active == 0 || total - next <= n_free)) {
+            int m = n_free < S ? n_free : S;
+            if(m > total - next) m = total - next;
+            memcpy(xs, x0 + (size_t)next * NXd, sizeof(double) * (size_t)m * NXd);
+            memcpy(us, u0 + (size_t)next * N * NUd, sizeof(double) * (size_t)m * N * NUd);
+            if(ilqg_batch_set_x0(stage, xs) || ilqg_batch_set_u(stage, us) || ilqg_batch_init(stage)) { snprintf(c->err, sizeof(c->err), "%s", stage->err); rc = 1; break; }
+            if(move_between(c, stage, m, freel + (n_free - m), ident)) { rc = 1; break; }
+            for(j = 0; j < m; j++) slot[freel[n_free - m + j]] = next + j;
+            next += m;
+            n_free -= m;
+            active += m;  /* (those whose initial roll-out failed are harvested at the next poll) */
+            c->compactions++;
+        }
+        if(rc) break;
+        if(iterate_groups(c, ILQG_STREAM_ROUND)) { rc = 1; break; }
+        it += ILQG_STREAM_ROUND;
+    }
+done:
+    if(stage) ilqg_batch_destroy(stage);
+    free(slot); free(st); free(its); free(freel); free(ident); free(fin); free(cst); free(xs); free(us); free(hx); free(hu);
+    return rc;
+}
+
 /* the last ilqg_batch_solve, poll by poll (every 4 iterations): iterations done so far, trajectories still active, slots the
  * iterations ran over (the batch, or the smaller context the live trajectories had been gathered into); returns the number
  * of polls (at most cap are written), *compactions = how often the live set was gathered */

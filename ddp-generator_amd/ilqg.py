@@ -236,6 +236,24 @@ class BatchSolver:
     def solve(self):
         self._ck(self.lib.ilqg_batch_solve(self.h))
 
+    def solve_stream(self, x0, u0, with_trajectories=False):
+        """a stream of len(x0) starts through this batch's slots (ilqg_batch_solve_stream): dict of cost, status, iterations
+        per start, and x / u if asked for"""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        total = x0.shape[0]
+        assert u0.shape == (total, self.N, self.problem.nu) and x0.shape == (total, self.problem.nx)
+        cost = np.zeros(total)
+        status, iters = np.zeros(total, dtype=np.int32), np.zeros(total, dtype=np.int32)
+        x = np.zeros((total, self.N + 1, self.problem.nx)) if with_trajectories else None
+        u = np.zeros((total, self.N, self.problem.nu)) if with_trajectories else None
+        vp = C.c_void_p
+        self.lib.ilqg_batch_solve_stream.argtypes = [vp, C.c_int, _dp, _dp, _dp, _ip, _ip, vp, vp]
+        self._ck(self.lib.ilqg_batch_solve_stream(self.h, total, x0, u0, cost, status, iters,
+                                                  x.ctypes.data_as(vp) if with_trajectories else None,
+                                                  u.ctypes.data_as(vp) if with_trajectories else None))
+        return dict(cost=cost, status=status, iterations=iters, x=x, u=u)
+
     def solve_trace(self):
         """the last solve(), poll by poll: (iterations done, trajectories active, slots iterated over) arrays and the number
         of times the active set was gathered into a smaller context (option "compact")"""

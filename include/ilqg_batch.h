@@ -111,6 +111,15 @@ int ilqg_batch_iterate(ilqg_batch_t *c, int n);
 int ilqg_batch_solve(ilqg_batch_t *c);
 int ilqg_batch_sync(ilqg_batch_t *c);
 int ilqg_batch_active(ilqg_batch_t *c, int *n_active);
+/* A STREAM of `total` starts solved through this batch's slots: finished trajectories are harvested every 8 iterations and
+ * their slots given to the next starts of the stream (initialised in a staging context as ilqg_batch_init does, then moved
+ * in), so that the slots stay full while starts remain.  x0 [total][N_X], u0 [total][n_hor][N_U] in; per start out: cost,
+ * status (exit reason, see below), iterations, and — if not NULL — x [total][n_hor+1][N_X], u [total][n_hor][N_U].
+ * Every start gets the result a plain ilqg_batch_solve of a batch holding it gives, bit for bit.  Options and parameters:
+ * those of c; what c held before is overwritten.  ilqg_batch_solve_trace reports the polls (its `compactions` counts the
+ * refills).  No reference counterpart (the reference solves one trajectory per call, iLQG.c:224). */
+int ilqg_batch_solve_stream(ilqg_batch_t *c, int total, const double *x0, const double *u0, double *cost, int *status,
+                            int *iterations, double *x, double *u);
 /* the last ilqg_batch_solve, poll by poll (it polls every 4 iterations): iterations done so far, trajectories still
  * active, slots the iterations ran over (the batch, or the smaller context of option "compact"); returns the number of
  * polls (at most cap entries are written; any pointer may be NULL), *compactions = how often the active set was gathered */
