@@ -82,17 +82,22 @@ def test_solve_product_build(ilqg, tag, problem, case):
     s.close()
 
 
-def test_batch_of_different_starts_against_the_oracle(ilqg, oracle_built):
+@pytest.mark.parametrize("compact", [0, 8])
+def test_batch_of_different_starts_against_the_oracle(ilqg, oracle_built, compact):
     """every trajectory carries its own multipliers and penalty weights: a batch that spans several wavefronts,
-    solved in lock step (strict build: bitwise) against one oracle solve per trajectory"""
+    solved in lock step (strict build: bitwise) against one oracle solve per trajectory.  compact = 8: the same with
+    finished trajectories retired — the live ones gathered into smaller contexts, multipliers, weights and stored
+    derivative records moving with them (ilqg_batch_solve, option "compact") — every one of the 150 solves still the
+    oracle's, bit for bit"""
     B, n = 150, 60
     params, opts, x0, u0 = brachi_hli_case(n)
     rng = np.random.default_rng(11)
     x0s = -10.0 ** rng.uniform(-16, -1, (B, 1))
     u0s = -np.ones((B, n, 1)) * rng.uniform(0.3, 2.0, (B, 1, 1)) + 0.05 * rng.standard_normal((B, n, 1))
-    s = ilqg.BatchSolver("brachi_hli", 0, batch=B, n_hor=n, params=params, opts=opts, strict=True)
+    s = ilqg.BatchSolver("brachi_hli", 0, batch=B, n_hor=n, params=params, opts=dict(opts, compact=compact), strict=True)
     s.init(x0s, u0s)
     s.solve()
+    assert (s.solve_trace()[3] >= 1) == (compact > 0)
     cost, iters, ok = s.scalar("cost"), s.ints("iterations"), s.success()
     x, (run, fin), wl, wf = s.x(), s.multipliers(), s.scalar("w_pen_l"), s.scalar("w_pen_f")
     s.close()

@@ -30,6 +30,17 @@ done
 cd $R
 python3 tools/pmc_summary.py --config5-json $OUT/traffic_config5.json 2 $OUT/traffic_synth/FETCH_SIZE $OUT/traffic_synth/WRITE_SIZE > $OUT/traffic_synth.txt 2>&1
 grep -A3 "k_backward_quad\|k_derivs_wave" $OUT/traffic_synth.txt | head -40
+echo "== PMC traffic, config 5 with stored tensors (the hint-free pair)"
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/traffic_stored/$c -- python3 $R/bench.py --config5-variant stored --steps 2 --warmup 0 > $OUT/traffic_stored_$c.log 2>&1 || echo "stored $c failed"
+done
+cd $R
+python3 tools/pmc_summary.py --config5-json $OUT/traffic_config5_stored.json 2 $OUT/traffic_stored/FETCH_SIZE $OUT/traffic_stored/WRITE_SIZE > $OUT/traffic_stored.txt 2>&1
+grep -A3 "k_backward_wave\|k_derivs_wave" $OUT/traffic_stored.txt | head -20
+echo "== full solves"
+timeout -k 10 600 python3 bench.py --solve > $OUT/bench_solve.json 2> $OUT/bench_solve.err || echo "solve bench failed"
+tail -c 400 $OUT/bench_solve.json; echo
 echo "== timelines (kernel trace with time stamps)"
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_car -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-unfused > $OUT/trace_car.log 2>&1 || echo "trace (car) failed"
