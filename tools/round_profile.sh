@@ -11,7 +11,7 @@ echo "== default bench"; python3 bench.py > $OUT/bench_default.json 2> $OUT/benc
 tail -c 300 $OUT/bench_default.json; echo
 cd /tmp
 echo "== kernel stats, headline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_car -- python3 $R/bench.py --no-cpu-baseline --no-config5 > $OUT/stats_car.log 2>&1 || echo "rocprofv3 stats (car) failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_car -- python3 $R/bench.py --no-cpu-baseline --no-unfused > $OUT/stats_car.log 2>&1 || echo "rocprofv3 stats (car) failed"
 echo "== kernel stats, config 5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_synth -- python3 $R/bench.py --workload synth --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats_synth.log 2>&1 || echo "rocprofv3 stats (synth) failed"
 cd $R
