@@ -51,6 +51,14 @@ SYN_PARAMS_TIGHT = dict(SYN_PARAMS, lim=[-0.25, 0.25])
 # problems/defs/synth16p.py: synth16x8 with pairwise state products in the nonlinearity (tensors not factorable)
 SYNP_PARAMS = dict(SYN_PARAMS, e=[0.3])
 SYNP_PARAMS_TIGHT = dict(SYN_PARAMS_TIGHT, e=[0.3])
+# problems/defs/synth10hx.py: n = 10, m = 3, factored tensors AND input limits that depend on the state
+SYN10_PARAMS = dict(h=[0.05], c=[0.8], px=[0.1], ru=[0.05] * 3, qx=[0.02 + 0.01 * i for i in range(10)],
+                    qf=[1.0 + 0.1 * i for i in range(10)], lim=[0.3])
+
+
+def syn10_inputs(batch, n_hor, seed=7):
+    rng = np.random.default_rng(seed)
+    return 0.8 * rng.uniform(-1, 1, (batch, 10)), 0.2 * rng.standard_normal((batch, n_hor, 3))
 
 
 def syn_inputs(batch, n_hor, first=0, seed=20261003):

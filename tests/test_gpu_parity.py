@@ -1573,3 +1573,48 @@ def test_quad_lean_layout_equals_the_default(ilqg):
     for it, (p, q) in enumerate(zip(a, b)):
         for k in p:
             assert np.array_equal(p[k], q[k]), (it, k)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_factored_records_with_state_dependent_limits(ilqg, oracle_built, strict):
+    """n > 8, FULL_DDP = 1 from the factored tensor tables, AND input limits that depend on the state (problems/defs/
+    synth10hx.py): limitsU() stores the limits' signs and gradients into the element, the row-mapped factored
+    backward step reads them from the record (ilqg_row.hpp, back_pass.c:186-199) — so k_derivs_wave's factored
+    instantiation must work on the record itself here, not on its private element.  Five lock-step iterations of a ragged
+    batch, teacher forced (before each iteration the batch gets the oracle's trajectories: an input that sits ON a limit
+    which moves with the state makes the box QP's clamp decision a matter of the last bit, and a free-running pair parts
+    ways there — trajectory 7 does in iteration 2), each against the oracle's next state: accepted step size and sweep count
+    equal, cost and trajectory to rounding; with limits active whose gradients are not zero."""
+    from oracle.harness import SYN10_PARAMS, syn10_inputs
+    B, N, iters = 21, 40, 5
+    x0, u0 = syn10_inputs(B, N)
+
+    def oracle_state(b, n_it):
+        d = Driver(lib_path("oracle", "synth10hx", 1), N, SYN10_PARAMS, dict(max_iter=max(n_it, 1)))
+        assert d.init(x0[b], u0[b]) == 1
+        if n_it:
+            d.solve()
+        sc, (xx, uu), tr = d.scalars(), d.traj(0), d.trace()
+        d.close()
+        return sc, xx, uu, tr
+    states = [[oracle_state(b, it) for b in range(B)] for it in range(iters + 1)]
+    s = ilqg.BatchSolver("synth10hx", 1, batch=B, n_hor=N, params=SYN10_PARAMS, opts=dict(max_iter=iters + 1), strict=strict)
+    assert s.problem.wave_mapping and (s.problem.nx, s.problem.nu) == (10, 3)
+    s.init(x0, u0)
+    on_state_limit = 0
+    for it in range(iters):
+        s.set_x(np.array([states[it][b][1] for b in range(B)]))
+        s.set_u(np.array([states[it][b][2] for b in range(B)]))
+        s.set_scalar("cost", np.array([states[it][b][0]["cost"] for b in range(B)]))
+        s.iterate(1)
+        cost, lam, aidx, calls, x, u = s.scalar("cost"), s.scalar("lambda"), s.ints("alpha_idx"), s.ints("bp_calls"), s.x(), s.u()
+        for b in range(B):
+            sc, xr, ur, tr = states[it + 1][b]
+            assert aidx[b] == tr["alpha_idx"][it] and calls[b] == tr["bp_calls"][it], (it, b)
+            assert close(lam[b], sc["lambda"], 1e-12), (it, b)
+            assert close(cost[b], sc["cost"], 1e-9), (it, b, cost[b], sc["cost"])
+            assert np.abs(x[b] - xr).max() < 1e-7 and np.abs(u[b] - ur).max() < 1e-7, (it, b)
+            # inputs sitting on a limit that moves with the state: u0 on lim + x1 / 2, u2 on -(lim + x0^2 / 5)
+            on_state_limit += int(np.sum(np.abs(ur[:, 0] - (0.3 + xr[:-1, 1] / 2)) < 1e-12) + np.sum(np.abs(ur[:, 2] + (0.3 + xr[:-1, 0] ** 2 / 5)) < 1e-12))
+    s.close()
+    assert on_state_limit > 100, on_state_limit
