@@ -152,6 +152,46 @@ def issue_object(kernel, name="issue.json"):
                       "not collected in this run)" % (name, j.get("_steps", 0), j.get("_source_sha"))}
 
 
+def live_traffic(workload_args, labels=True, timeout=240):
+    """HBM bytes per launch of the benchmark's kernels, collected NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE — separate
+    passes, the guide's gfx950 corrections: FETCH_SIZE x 2, both KiB) of a short run of this script in child processes, summarised by
+    tools/pmc_summary.py's rule.  Returns ({label: bytes per launch}, detail) or (None, why)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    out = tempfile.mkdtemp(prefix="ilqg_traffic_", dir="/tmp")
+    try:
+        dirs = []
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, c)
+            cmd = ["rocprofv3", "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "0", "--no-cpu-baseline", "--no-unfused", "--no-live-traffic"] + workload_args
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed: %s" % (c, (r.stderr or r.stdout)[-300:])
+            dirs.append(d)
+        tj = os.path.join(out, "traffic.json")
+        argv = sys.argv
+        try:
+            sys.argv = ["pmc_summary.py", "--traffic-json", tj] + dirs
+            import io, contextlib
+            with contextlib.redirect_stdout(io.StringIO()):
+                pmc_summary.main()
+        finally:
+            sys.argv = argv
+        j = json.load(open(tj))
+        return j, ("collected in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 0 "
+                   "--no-unfused` in child processes; FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes, mean per launch")
+    except Exception as e:  # the line must not depend on the profiler
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def with_split(opts, args):
     """the solver options of a run: the library's line-search split unless --ls-split asks for another"""
     if args.ls_split is not None:
@@ -532,6 +572,9 @@ def main():
                          "mapping: second stage beside the re-rolled winners); 0: second stage, then winner pass")
     ap.add_argument("--no-unfused", action="store_true", help="skip the secondary runs (kernels alone, config 5, drop-in)")
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not collect the PMC traffic of the headline's kernels in this run (two short rocprofv3 child runs); the "
+                         "committed, source-stamped profiles/traffic.json is quoted instead")
     ap.add_argument("--solve", action="store_true",
                     help="full solves instead of the benchmark window: --batch CarParking starts solved to convergence (max_iter "
                          "--max-iter), with and without retiring finished trajectories; prints its own JSON line")
@@ -724,6 +767,15 @@ def main():
             if tj is None or B != 65536:
                 tj = {}
                 traffic_stale = traffic_stale or "profiles/traffic.json is for 65 536 trajectories per GPU"
+            traffic_source = ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/collect_traffic.sh; "
+                              "per launch of one of the stream groups; sources %s; not collected in this run)" % tj.get("_source_sha"))
+            committed = dict(tj)
+            if secondary and not args.no_live_traffic and B == 65536:
+                live, how = live_traffic([])
+                if live:
+                    tj, traffic_stale, traffic_source = live, None, how
+                else:
+                    traffic_source += "; live collection failed: " + str(how)
             per_launch = B / max(1, stream_groups)
 
             def launch_object(name, alg_bytes_per_step, flops_per_step, moved_per_step):
@@ -742,9 +794,9 @@ def main():
                     pmc = tj[name]["hbm_bytes_per_launch"]
                     o["pmc"] = {"hbm_bytes_per_launch": pmc, "GBs": pmc / (avg_ms * 1e-3) / 1e9,
                                 "frac_of_peak": pmc / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                          "command, tools/collect_traffic.sh; per launch of one of the stream groups; sources "
-                                          "%s; not collected in this run)" % tj.get("_source_sha")}
+                                "source": traffic_source}
+                    if name in committed and committed is not tj:
+                        o["pmc"]["committed_profile_bytes_per_launch"] = committed[name]["hbm_bytes_per_launch"]
                 elif traffic_stale:
                     o["pmc"] = {"hbm_bytes_per_launch": None, "stale": traffic_stale}
                 if flops_per_step:
