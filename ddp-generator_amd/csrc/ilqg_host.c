@@ -38,6 +38,19 @@
 #endif
 #define FIN_SIZE (N_X + sizeofQxx)
 
+/* The reference's console output of the outer loop and the line search (its TRACE macros: iLQG.c:24-33 on by
+ * default, line_search.c:19-28 on by default; back_pass.c:26-34 and boxQP.c:33 off by default and not reproduced —
+ * their messages name a time step inside a device sweep).  Same switches, same defaults, same texts, through PRNT
+ * and under the same o->debug_level thresholds. */
+#ifndef DEBUG_ILQG
+#define DEBUG_ILQG 1
+#endif
+#ifndef DEBUG_FORWARDPASS
+#define DEBUG_FORWARDPASS 1
+#endif
+#define SAY_LOOP(level, args) do { if((DEBUG_ILQG) && o->debug_level >= (level)) PRNT args; } while(0)
+#define SAY_SEARCH(level, args) do { if((DEBUG_FORWARDPASS) && o->debug_level >= (level)) PRNT args; } while(0)
+
 /* The batch is held as up to ILQG_MAX_GROUPS independent device contexts ("groups") of consecutive trajectories,
  * each with its own HIP stream, advanced alternately.  Every kernel of an iteration is either a chain of n_hor
  * dependent time steps with one wavefront per 64 trajectories — too few wavefronts to keep a SIMD busy — or wide
@@ -1156,6 +1169,23 @@ int line_search(tOptSet *o, int iter) {
         forward_pass(cand, o, 0.0, &tmp, 1);
     }
     z = (expected > 0) ? dcost / expected : 0;
+    if(DEBUG_FORWARDPASS) {
+        /* what the reference says while it walks the step sizes one by one (line_search.c:44-66): the device has
+         * tried them all at once and kept every cost and finite-flag, so the same walk is replayed here */
+        double costs[ILQG_MAX_ALPHA];
+        int ok[ILQG_MAX_ALPHA], tried = accepted ? idx : o->n_alpha, i;
+        DEV_OK(ilqg_dev_io_begin(d), who);
+        DEV_OK(ilqg_dev_read(d, ILQG_F_ALPHA_COST, costs), who);
+        DEV_OK(ilqg_dev_read_int(d, ILQG_I_ALPHA_OK, ok), who);
+        DEV_OK(ilqg_dev_io_end(d), who);
+        for(i = 0; i < tried && i < o->n_alpha; i++) {
+            if(!ok[i])
+                SAY_SEARCH(2, ("line search: %-3d: prediction or objective failed with inf or nan\n", i + 1));
+            else if(!(-o->alpha[i] * (o->dV[0] + o->alpha[i] * o->dV[1]) > 0))
+                SAY_SEARCH(-1000, ("non-positive expected reduction: should not occur (dV[0]= %g, dV[1]= %g)\n", o->dV[0], o->dV[1]));
+        }
+        if(!accepted) SAY_SEARCH(2, ("max number of line searches reached\n"));
+    }
     if(o->log_linesearch != NULL) o->log_linesearch[iter] = idx;
     if(o->log_z != NULL) o->log_z[iter] = z;
     if(o->log_cost != NULL) o->log_cost[iter] = cnew;
@@ -1265,30 +1295,41 @@ int iLQG(tOptSet *o) {
 
     for(iter = 0; iter < o->max_iter; iter++) {
         if(fresh) {
-            if(!calc_derivs(o)) break;
+            if(!calc_derivs(o)) {
+                SAY_LOOP(-1000, ("Calculating derivatives failed.\n"));
+                break;
+            }
             fresh = 0;
         }
         for(done = 0; !done;) {
             if(!back_pass(o)) {
                 done = 1;
             } else {
+                SAY_LOOP(1, ("Back pass failed.\n"));
                 lambda_increase(o, &dlambda);
                 if(o->lambda > o->lambdaMax) break;
             }
         }
         if(o->g_norm < o->tolGrad && o->lambda < 1e-5) {
             lambda_decrease(o, &dlambda);
+            SAY_LOOP(1, ("\nSUCCESS: gradient norm < tolGrad\n"));
             break;
         }
         if(!done) break;
 
         stepped = line_search(o, iter);
         if(stepped) {
+            SAY_LOOP(1, ("iter: %-3d  cost: %-9.6g  reduction: %-9.3g  gradient: %-9.3g  z: %-5.3g log10(lam): %3.1f "
+                         "w_pen_l: %-9.3g w_pen_f: %-9.3g\n", iter + 1, o->cost, o->dcost, o->g_norm,
+                         o->dcost / o->expected, log10(o->lambda), o->w_pen_l, o->w_pen_f));
             lambda_decrease(o, &dlambda);
             makeCandidateNominal(o, 0);
             o->cost = o->new_cost;
             fresh = 1;
-            if(o->dcost < o->tolFun) break;
+            if(o->dcost < o->tolFun) {
+                SAY_LOOP(1, ("\nSUCCESS: cost change < tolFun\n"));
+                break;
+            }
             update_multipliers(o, 0);
             forward_pass(o->nominal, o, 0.0, &o->cost, 1);
         } else {
@@ -1298,11 +1339,26 @@ int iLQG(tOptSet *o) {
                 o->w_pen_f = min(o->w_pen_max_f, o->w_pen_f * o->w_pen_fact2);
                 forward_pass(o->nominal, o, 0.0, &o->cost, 1);
             }
-            if(o->lambda > o->lambdaMax) break;
+            /* (the second label reads w_pen_l in the reference too, iLQG.c:353) */
+            SAY_LOOP(1, ("iter: %-3d  REJECTED    expected: %-11.3g    actual: %-11.3g    log10lam: %3.1f "
+                         "w_pen_l: %-9.3g w_pen_l: %-9.3g\n", iter + 1, o->expected, o->dcost, log10(o->lambda),
+                         o->w_pen_l, o->w_pen_f));
+            if(o->lambda > o->lambdaMax) {
+                SAY_LOOP(1, ("\nEXIT: lambda > lambdaMax\n"));
+                break;
+            }
         }
     }
     o->iterations = iter;
-    return (done && iter < o->max_iter) ? 1 : 0;
+    if(!done) {
+        SAY_LOOP(1, ("\nEXIT: no descent direction found.\n"));
+        return 0;
+    }
+    if(iter >= o->max_iter) {
+        SAY_LOOP(1, ("\nEXIT: Maximum iterations reached.\n"));
+        return 0;
+    }
+    return 1;
 }
 
 /* =========================================================================

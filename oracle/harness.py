@@ -101,6 +101,42 @@ def almix_case(batch=None, seed=3):
     return params, opts, x0, 0.1 * rng.standard_normal((batch, n, 2))
 
 
+CONSOLE_CASES = [("carparking", 0), ("carparking", 1), ("almix", 0)]
+
+
+def console_case(problem, fd):
+    """(n_hor, params, opts, x0, u0) of the solves whose console output is a fixture (tests/golden/trace_*.txt)"""
+    if problem == "carparking":
+        rng = np.random.default_rng(11)
+        # FULL_DDP = 1 from a small lambda: failed backward sweeps.  Few iterations: a free-running product solve
+        # leaves the reference's after about a dozen (last-bit decisions, DESIGN.md section 4)
+        opts = dict(max_iter=16, lambdaInit=0.01) if fd else dict(max_iter=12)
+        return CAR_N, CAR_PARAMS, opts, np.array(CAR_X0), 0.1 * rng.standard_normal((CAR_N, 2))
+    if problem == "almix":  # its first iteration is rejected, and the weights move
+        params, opts, x0, u0 = almix_case()
+        return len(u0), params, dict(opts, max_iter=25), x0, u0
+    raise ValueError(problem)
+
+
+def console_of(library, problem, fd, debug_level=2):
+    """what iLQG() of `library` (a driver build: reference, oracle or the product's drop-in) prints while it solves
+    console_case(problem, fd) at the reference's default debug_level (iLQG.c:71; the driver itself starts quiet) — run
+    in a child process, its stdout captured"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from oracle.harness import Driver, console_case\n"
+            "n, params, opts, x0, u0 = console_case(%r, %d)\n"
+            "opts = dict(opts, debug_level=%r)\n"
+            "d = Driver(%r, n, params, opts)\n"
+            "assert d.init(x0, u0) == 1\n"
+            "rc = d.solve()\n"
+            "import ctypes; ctypes.CDLL(None).fflush(None)\n"
+            "print('rc', rc, flush=True)\n"
+            "d.close()\n" % (os.path.dirname(HERE), problem, fd, debug_level, library))
+    return subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True, timeout=600).stdout
+
+
 def lib_path(kind, problem="carparking", full_ddp=0):
     """kind: 'ref' (reference sources), 'oracle' (CPU restatement), 'ref_fma' (reference sources built with FMA
     contraction, CarParking FULL_DDP=0 only), 'pure' (the reference's cholesky.c / matMult.c / printMat.c alone: no MEX

@@ -26,8 +26,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from oracle.harness import (CAR_PARAMS, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT as SYN_PARAMS, SYNP_PARAMS_TIGHT, Driver, Kernels, almix_case, brachi_case,  # noqa: E402
-                            brachi_hli_case, hx_inputs, lib_path, syn_inputs)
+from oracle.harness import (CAR_PARAMS, CONSOLE_CASES, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT as SYN_PARAMS, SYNP_PARAMS_TIGHT, Driver, Kernels, almix_case, brachi_case,  # noqa: E402
+                            brachi_hli_case, console_of, hx_inputs, lib_path, syn_inputs)
 
 spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "ddp-generator_amd", "synth.py"))
 synth = importlib.util.module_from_spec(spec)
@@ -451,8 +451,19 @@ def almix_goldens():
     np.savez_compressed(os.path.join(HERE, "almix.npz"), **out)
 
 
+def console_goldens():
+    """the iteration lines the reference prints with its default console switches (iLQG.c:24-33, :269-374;
+    line_search.c:19-28, :48-66): oracle/_ref/libref_<problem>_fd<n>_trace.so solving oracle.harness.console_case(problem, fd)"""
+    for problem, fd in CONSOLE_CASES:
+        text = console_of(os.path.join(ROOT, "oracle", "_ref", "libref_%s_fd%d_trace.so" % (problem, fd)), problem, fd)
+        with open(os.path.join(HERE, "trace_%s_fd%d.txt" % (problem, fd)), "w") as f:
+            f.write(text)
+        print("console %s fd%d: %d lines, %d failed sweeps, %d rejected; last: %s" % (
+            problem, fd, len(text.splitlines()), text.count("Back pass failed"), text.count("REJECTED"), text.splitlines()[-2:]))
+
+
 def main(argv):
-    """all fixtures, or only the named groups: brachi almix kernels car lockstep hx regtype2 synth synthp"""
+    """all fixtures, or only the named groups: brachi almix kernels car lockstep hx regtype2 synth synthp console"""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     groups = {
         "brachi": brachi_goldens,
@@ -464,6 +475,7 @@ def main(argv):
         "regtype2": regtype2_goldens,
         "synth": lambda: [synth_goldens(fd) for fd in (0, 1)],
         "synthp": lambda: synth_goldens(1, N=12, problem="synth16p", SYN_PARAMS=SYNP_PARAMS_TIGHT),
+        "console": console_goldens,
     }
     for name in (argv or list(groups)):
         groups[name]()

@@ -14,8 +14,8 @@ import os
 import numpy as np
 import pytest
 
-from oracle.harness import (CAR_N, CAR_PARAMS, CAR_X0, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver, almix_case,
-                            brachi_case, brachi_hli_case, hx_inputs, lib_path, syn_inputs)
+from oracle.harness import (CAR_N, CAR_PARAMS, CAR_X0, CONSOLE_CASES, HX_N, HX_PARAMS, SYN_PARAMS_TIGHT, Driver,
+                            almix_case, brachi_case, brachi_hli_case, console_of, hx_inputs, lib_path, syn_inputs)
 
 pytestmark = pytest.mark.gpu
 
@@ -157,3 +157,34 @@ def test_dropin_solve_matches_the_oracle(built, problem, fd):
     assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], (a[:3], b[:3])
     assert close(b[3], a[3], 1e-8), (a[3], b[3])
     assert np.abs(a[4][0] - b[4][0]).max() < 1e-4 and np.abs(a[4][1] - b[4][1]).max() < 1e-4  # full-solve tolerance
+
+
+def _same_console(got, want):
+    """line by line: the same words, and the same numbers to the three digits most of them are printed with"""
+    got, want = got.splitlines(), want.splitlines()
+    assert len(got) == len(want), (len(got), len(want), got[-3:], want[-3:])
+    for n, (a, b) in enumerate(zip(got, want)):
+        ta, tb = a.split(), b.split()
+        assert len(ta) == len(tb), (n, a, b)
+        for x, y in zip(ta, tb):
+            try:
+                fx, fy = float(x), float(y)
+            except ValueError:
+                assert x == y, (n, a, b)
+                continue
+            assert fx == fy or abs(fx - fy) <= 1.1e-2 * max(abs(fx), abs(fy)), (n, a, b)
+
+
+@pytest.mark.parametrize("problem,fd", CONSOLE_CASES)
+def test_dropin_console_output_is_the_references(built, problem, fd):
+    """iLQG() of the product prints what the reference prints with its default console switches (iLQG.c:24-33 and
+    :269-374: failed sweeps, the iteration line, the rejected line, the four exits; line_search.c:48-66) — compared with
+    tests/golden/trace_*.txt, the output of the reference's own sources (tests/golden/make_goldens.py console)"""
+    hip = os.path.join(os.path.dirname(lib_path("oracle")), "libdrv_%s_fd%d_hip.so" % (problem, fd))
+    with open(os.path.join(os.path.dirname(__file__), "golden", "trace_%s_fd%d.txt" % (problem, fd))) as f:
+        want = f.read()
+    assert want.count("iter:") >= 10
+    _same_console(console_of(hip, problem, fd), want)
+    # debug_level 0 silences everything the reference puts under a threshold
+    quiet = console_of(hip, problem, fd, debug_level=0)
+    assert [ln for ln in quiet.splitlines() if ln and not ln.startswith("non-positive")] == [want.splitlines()[-1]], quiet

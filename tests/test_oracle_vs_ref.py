@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import load_package, ref_available
-from oracle.harness import CAR_PARAMS, Driver, Kernels, lib_path
+from oracle.harness import CAR_PARAMS, CONSOLE_CASES, Driver, Kernels, console_of, lib_path
 
 pytestmark = pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (no reference sources here)")
 
@@ -73,3 +73,15 @@ def test_dense_helpers_match_the_reference_built_without_any_stand_in(oracle_bui
         assert np.array_equal(Kp.add_square_tri(b_xx, V, fx, n, n), Ko.add_square_tri(b_xx, V, fx, n, n))
         assert np.array_equal(Kp.add_mul2_tri(b_xu, V, fx, n, n, fu, n, m), Ko.add_mul2_tri(b_xu, V, fx, n, n, fu, n, m))
 
+
+
+@pytest.mark.parametrize("problem,fd", CONSOLE_CASES)
+def test_console_fixture_is_what_the_reference_prints(oracle_built, problem, fd):
+    """tests/golden/trace_*.txt (the iteration lines the product's iLQG() is compared with on the GPU,
+    tests/test_gpu_dropin.py) are the reference's own console output with its default switches"""
+    import os
+    lib = os.path.join(os.path.dirname(lib_path("ref")), "libref_%s_fd%d_trace.so" % (problem, fd))
+    if not os.path.exists(lib):
+        pytest.skip("trace build of the reference not present")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "trace_%s_fd%d.txt" % (problem, fd))) as f:
+        assert console_of(lib, problem, fd) == f.read()
