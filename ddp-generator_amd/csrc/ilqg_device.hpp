@@ -25,6 +25,35 @@ namespace ilqg {
 #ifdef ILQG_PROFILE_SECTIONS
 __device__ unsigned long long ilqg_prof_cycles[8];  // summed over wavefronts: see tools/section_profile.py
 #endif
+// Where and when every wavefront of the backward and search kernels ran (builds with -DILQG_WAVE_PLACES only;
+// tools/experiments/wave_places.py): HW_ID (SIMD, CU, shader array, engine), XCC_ID and the constant 100 MHz clock at entry and exit.
+#ifdef ILQG_WAVE_PLACES
+constexpr unsigned PLACES_MAX = 1u << 19;
+__device__ unsigned long long ilqg_places[PLACES_MAX][3];
+__device__ unsigned ilqg_places_n;
+#endif
+struct Place {
+    unsigned slot;
+    ILQG_DEV explicit Place(int kind) {
+        slot = ~0u;
+#ifdef ILQG_WAVE_PLACES
+        if(threadIdx.x % 64 == 0) {
+            slot = atomicAdd(&ilqg_places_n, 1u);
+            if(slot < PLACES_MAX) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                ilqg_places[slot][0] = ((unsigned long long)kind << 40) | ((unsigned long long)(xcc & 15u) << 32) | hw;
+                ilqg_places[slot][1] = wall_clock64();
+            }
+        }
+#endif
+    }
+    ILQG_DEV ~Place() {
+#ifdef ILQG_WAVE_PLACES
+        if(slot < PLACES_MAX) ilqg_places[slot][2] = wall_clock64();
+#endif
+    }
+};
+
 struct Prof {
     long long last, acc[8];
     long long wave_steps;  // quad mapping: steps of the wavefront
