@@ -33,7 +33,8 @@ def _solve(ilqg, problem, fd, x0, u0, n_hor, params, opts, compact, **kw):
     return out
 
 
-@pytest.mark.parametrize("problem,fd,groups", [("carparking", 0, 0), ("carparking", 1, 2), ("hxtest", 0, 0)])
+@pytest.mark.parametrize("problem,fd,groups", [("carparking", 0, 0), ("carparking", 1, 2), ("hxtest", 0, 0), ("synth16x8", 1, 0),
+                                               ("synth16x8", 0, 0)])
 def test_compacted_solve_equals_the_uncompacted_one(ilqg, problem, fd, groups):
     """CarParking starts converge at very different iterations: with "compact" the solve gathers the live trajectories
     several times (the trace shows the slots shrinking) and every result — trajectory, gains, cost, lambda, exit reason,
@@ -42,15 +43,19 @@ def test_compacted_solve_equals_the_uncompacted_one(ilqg, problem, fd, groups):
     if problem == "carparking":
         B, N, params, opts = 700, 500, ilqg.CAR_PARAMS, dict(max_iter=400)
         x0, u0 = pkg.synth.car_batch(B, N)
+    elif problem == "synth16x8":  # the wave mapping (quad / row kernels, records private to the context)
+        from oracle.harness import SYN_PARAMS_TIGHT, syn_inputs
+        B, N, params, opts = 200, 60, SYN_PARAMS_TIGHT, dict(max_iter=200)
+        x0, u0 = syn_inputs(B, N)
     else:
         from oracle.harness import HX_N, HX_PARAMS, hx_inputs
         B, N, params, opts = 300, HX_N, HX_PARAMS, dict(max_iter=60)
         x0, u0 = hx_inputs(B)
     kw = dict(groups=groups) if groups else {}
     plain = _solve(ilqg, problem, fd, x0, u0, N, params, opts, 0, **kw)
-    comp = _solve(ilqg, problem, fd, x0, u0, N, params, opts, 16, **kw)
+    comp = _solve(ilqg, problem, fd, x0, u0, N, params, opts, 8 if problem == "synth16x8" else 16, **kw)
     it, act, slots, n_comp = comp["trace"]
-    assert n_comp >= (2 if problem == "carparking" else 1) and slots[0] == B and slots[-1] < B // 2, (n_comp, slots)
+    assert n_comp >= (1 if problem == "hxtest" else 2) and slots[0] == B and slots[-1] < B // 2, (n_comp, slots)
     assert np.all(act <= slots) and plain["trace"][3] == 0 and np.all(plain["trace"][2] == B)
     st = plain["status"]
     # they do finish, and at different iterations
@@ -103,7 +108,7 @@ def test_compacted_solve_against_the_oracle(ilqg):
     assert checked >= 3, checked  # (of the 60 earliest finishers)
 
 
-@pytest.mark.parametrize("problem,fd", [("carparking", 0), ("hxtest", 1)])
+@pytest.mark.parametrize("problem,fd", [("carparking", 0), ("hxtest", 1), ("synth16x8", 1)])
 def test_stream_of_starts_equals_plain_solves(ilqg, problem, fd):
     """ilqg_batch_solve_stream: 3.3 batches' worth of starts through the slots of one batch — finished trajectories harvested,
     their slots refilled from a staging context — against plain solves of the same starts in batches of their own: cost,
@@ -114,6 +119,11 @@ def test_stream_of_starts_equals_plain_solves(ilqg, problem, fd):
         B, N, params, opts = 192, 500, ilqg.CAR_PARAMS, dict(max_iter=150)
         total = 640
         x0, u0 = pkg.synth.car_batch(total, N)
+    elif problem == "synth16x8":
+        from oracle.harness import SYN_PARAMS_TIGHT, syn_inputs
+        B, N, params, opts = 64, 40, SYN_PARAMS_TIGHT, dict(max_iter=120)
+        total = 210
+        x0, u0 = syn_inputs(total, N)
     else:
         from oracle.harness import HX_N, HX_PARAMS, hx_inputs
         B, N, params, opts = 128, HX_N, HX_PARAMS, dict(max_iter=60)
