@@ -469,6 +469,15 @@ struct DevPtrs {
     trajEl_t *work;      // wave mapping: derivative records of one chunk of trajectories, [chunk][N], work_stride apart
     size_t work_stride;  //   sizeof(trajEl_t), or less for factored records (see FACT_STRIDE)
     int *queue;          // wave mapping: next trajectory of the chunk to be taken by a wavefront of the backward kernel
+    // quad mapping with speculative retries (k_backward_quad<FACT, true>; null otherwise), per launch:
+    unsigned *spec_word; //   [B] attempts handed out (low 16 bits) | attempts running (high 16 bits)
+    unsigned *spec_best; //   [B] smallest attempt that ended with a result (0xffffffff: none yet)
+    unsigned *spec_done; //   [B] 1 once the trajectory's result has been written
+    unsigned *spec_out;  //   [B][SPEC_ATTEMPTS] how attempt j ended: 0 unknown, else kind | direct << 2 | row << 3
+    int *spec_row_b;     //   [rows] the trajectory a row works on (-1: none)
+    double *spec_res;    //   [rows][8] what a row's attempt with a result leaves: lambda, dlambda, dV0, dV1, g_norm, status, bp_rc, sweeps
+    double *spec_gains;  //   [rows][N][NU + NXU] gains of a row's attempt that does not write the trajectory's records
+    int spec_rows;
     double *nom;         // packed trajectory records, see nomp()
     double **p;
     int B, Bp, N;

@@ -175,6 +175,8 @@ int ilqg_dev_move(ilqg_dev_t *dst, ilqg_dev_t *src, int count, const int *to, co
 /* builds with -DILQG_PROFILE_SECTIONS: cycles per section of the fused backward step, summed over wavefronts */
 int ilqg_dev_section_cycles(unsigned long long *out8);
 int ilqg_dev_derivs_cycles(unsigned long long *out32);
+/* quad mapping with speculative retries (ILQG_QUAD_SPEC=1): the protocol's words after the last backward launch (measurement) */
+int ilqg_dev_spec_words(unsigned *out, size_t max_words, size_t *count);
 /* builds with -DILQG_WAVE_PLACES: where and when the wavefronts of the backward and search kernels ran (3 words per entry) */
 int ilqg_dev_wave_places(unsigned long long *out, int max_entries, int *count);
 
