@@ -1575,6 +1575,47 @@ def test_quad_lean_layout_equals_the_default(ilqg):
             assert np.array_equal(p[k], q[k]), (it, k)
 
 
+@pytest.mark.parametrize("problem,fd,strict", [("synth16x8", 1, False), ("synth16x8", 1, True), ("synth16x8", 0, False), ("synth16p", 0, False)])
+def test_speculative_retries_equal_the_sequential_sweeps(ilqg, monkeypatch, problem, fd, strict):
+    """k_backward_quad with speculative retries (the default; k_wave_backward.inc SPEC): rows whose queue is used up run other
+    trajectories' NEXT attempts (lambda_j replayed from the trajectory's lambda, iLQG.c:271-274) into buffers of their own,
+    and the first attempt with a result whose predecessors all failed is what is written — the sequential loop's result
+    (iLQG.c:261-283).  Batches much smaller than the kernel's 4 096 rows, so that every trajectory with a retry has
+    helpers: gains, value changes, gradient norm, lambda, dlambda, status, sweep count and the trajectories of the
+    iterations that follow equal those of ILQG_QUAD_SPEC=0 bit for bit; lambdaInit small enough for up to six sweeps."""
+    from oracle.harness import SYNP_PARAMS_TIGHT
+    params = SYNP_PARAMS_TIGHT if problem == "synth16p" else SYN_PARAMS
+    seen = []
+    for B, N, K in ((37, 40, 6), (300, 60, 5)):
+        x0, u0 = syn_inputs(B, N, first=3)
+        x0 = x0 * np.linspace(0.3, 2.5, B)[:, None]
+
+        def run(spec):
+            monkeypatch.setenv("ILQG_QUAD_SPEC", "1" if spec else "0")
+            s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=N, params=params, opts=dict(max_iter=K + 1, lambdaInit=1e-7), strict=strict)
+            s.init(x0, u0)
+            out = []
+            for it in range(K):
+                s.iterate(1)
+                l, L = s.gains()
+                out.append(dict(l=l.copy(), L=L.copy(), x=s.x().copy(), u=s.u().copy(), cost=s.scalar("cost").copy()))
+                for k in ("dV0", "dV1", "g_norm", "lambda", "dlambda"):
+                    out[-1][k] = s.scalar(k).copy()
+                for k in ("status", "bp_calls", "bp_rc", "alpha_idx"):
+                    out[-1][k] = s.ints(k).copy()
+            s.close()
+            return out
+
+        a, b = run(False), run(True)
+        for it, (p, q) in enumerate(zip(a, b)):
+            for k in p:
+                assert np.array_equal(p[k], q[k]), (B, it, k)
+        seen.append(np.concatenate([o["bp_calls"] for o in a]))
+    calls = np.concatenate(seen)
+    if fd:  # (without the tensors Quu is positive definite: one sweep each, the kernel's other instantiation all the same)
+        assert calls.max() >= 3 and (calls > 1).mean() > 0.1, (calls.max(), (calls > 1).mean())
+
+
 @pytest.mark.parametrize("strict", [True, False])
 def test_factored_records_with_state_dependent_limits(ilqg, oracle_built, strict):
     """n > 8, FULL_DDP = 1 from the factored tensor tables, AND input limits that depend on the state (problems/defs/
