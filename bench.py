@@ -135,6 +135,10 @@ def issue_object(kernel, name="issue.json"):
     if j is None:
         return {"valu_insts_per_step": None, "active_valu_frac": None, "source": None, "stale": why}
     k = j.get(kernel)
+    if not k:  # (a kernel template that has gained a parameter: "k_backward_quad<true>" also means "k_backward_quad<true, true>")
+        alt = [n for n in j if isinstance(j[n], dict) and n.startswith(kernel[:-1] + ",")]
+        if len(alt) == 1:
+            kernel, k = alt[0], j[alt[0]]
     if not k:
         return {"valu_insts_per_step": None, "active_valu_frac": None, "source": "profiles/" + name, "stale": "no entry for " + kernel}
     if "valu_insts_per_trajectory_step" not in k and k.get("persistent"):
