@@ -19,16 +19,20 @@ single RCCL gather of the per-trajectory costs at the end of the timed window
 (weak scaling: 65 536 trajectories per GPU).  PyTorch is used only for process
 rendezvous, the RCCL collective and device synchronisation.
 
-Prints ONE JSON line (rank 0):
+Prints ONE compact JSON line (rank 0; < 6 KB, nothing else reaches stdout) and writes the full report to
+bench_detail.json beside this file (and to gpurun_out/ where that exists):
   value / ms_per_step   the timed window (three groups of trajectories on three streams)
+  roofline              the dominant kernel's launches IN the timed window (HIP events on the solver's streams): SURVEY
+                        8(d)'s algorithmic bytes of the stages it replaces / its average duration against 8 TB/s, the PMC
+                        traffic per launch (collected in this run by two short rocprofv3 child runs), its real HBM
+                        utilisation, the limiter and the issue counters of the committed SQ passes
   iteration_roofline    the whole iteration against the HBM roofline with SURVEY 8(d)'s algorithmic bytes
-  roofline              the dominant kernel, timed ALONE (one group, nothing else on the GPU): it evaluates the
-                        derivatives in registers and is bound by fp64 vector issue, so it is priced in flop/s
-  unfused_kernels       the two HBM-bound kernels it replaces, each alone, against the HBM roofline
-  config5               BASELINE config 5 (synthetic n=16, m=8, N=1000, FULL_DDP=1, 16 384 trajectories)
-  dropin_b1             BASELINE config 1 through the drop-in iLQG() (one trajectory, hot path on the GPU)
   cpu_baseline          the CPU checker (the reference's own sources when oracle/_ref was shipped) on a bounded
                         sample of the same workload on this box's host cores
+  config5, config5_stored, config2, dropin_b1
+                        the other BASELINE configs, each measured in a fresh child process (`--object NAME`), reduced
+                        to value / ms_per_step / fractions; the full objects are in bench_detail.json
+  --full                adds full solves to convergence, the dominant kernel alone and the unfused kernel pair
 """
 import argparse
 import json
@@ -508,7 +512,7 @@ class ProtocolShard:
         pass
 
 
-def single_process(args, ilqg, synth):
+def single_process(args, ilqg, synth, guard):
     """N GPUs of the node driven by ONE process through ilqg_multi_* (the C counterpart of the torchrun path);
     --devices 0,0,...: the shards on the listed devices (equal ids: loop-back rehearsal on one GPU)"""
     G, K, W = args.gpus, args.steps, args.warmup
@@ -533,7 +537,7 @@ def single_process(args, ilqg, synth):
     active = m.active()
     m.close()
     iter_bytes = algorithmic_bytes(4, 2, 0)["iteration"] * n_hor * per
-    print(json.dumps({
+    out = {
         "metric": "iLQG iterations/sec, 65k-batch CarParking (n=4,m=2,N=500)", "value": G * K / dt,
         "unit": "iterations/s", "value_definition": "iterations of a %d-trajectory batch per second, all shards: %d x %d iterations / time" % (per, G, K),
         "per_gpu_iterations_per_s": K / dt,
@@ -548,7 +552,168 @@ def single_process(args, ilqg, synth):
         "roofline": {"bound": "hbm", "kernel": "iteration", "achieved": iter_bytes * (K / dt) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": iter_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "note": "per GPU; algorithmic bytes of SURVEY 8(d)"},
-        "trajectories_still_active": int(active), "cost_mean_after_window": float(cost.mean())}))
+        "trajectories_still_active": int(active), "cost_mean_after_window": float(cost.mean())}
+    out["detail"] = write_detail(out)
+    guard.emit(json.dumps(out))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Output: ONE compact JSON line on stdout (what the driver parses: < 6 KB, tests/test_multiproc.py asserts it), the full
+# report in bench_detail.json beside this file (and under gpurun_out/ where that exists).  Everything else that would
+# reach stdout — console lines of C libraries, of child processes — is kept off it: fd 1 points at bench_detail.log while
+# the benchmark runs and is put back for the one line.
+
+LINE_CAP = 6000
+
+
+class StdoutGuard:
+    """fd 1 -> a log file for the duration of the run (C printf of the checker libraries included); emit() writes the
+    one line to the real stdout"""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.real = os.dup(1)
+        log = None
+        for d in (ROOT, "/tmp"):
+            try:
+                log = os.open(os.path.join(d, "bench_detail.log"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                break
+            except OSError:
+                continue
+        if log is None:
+            log = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(log, 1)
+        os.close(log)
+
+    def emit(self, line):
+        sys.stdout.flush()
+        os.dup2(self.real, 1)
+        os.write(1, (line + "\n").encode())
+
+
+def write_detail(out):
+    """the full report: bench_detail.json beside bench.py, and in gpurun_out/ so that it comes back from a GPU box"""
+    paths = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f, indent=1)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            pass
+    return written
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out, detail_path):
+    """the line the driver parses, cut down from the full report `out` (the contract's keys, the dominant kernel's
+    roofline, the CPU baseline, the other configs as value / ms_per_step / fractions); never longer than LINE_CAP"""
+    c = out.get("config", {})
+    line = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "rehearsal", "gathered_costs_in_order", "per_gpu_iterations_per_s",
+                 "trajectories_still_active", "cost_mean_after_window")
+    line["config"] = _pick(c, "workload", "mapping", "batch_per_gpu", "n_hor", "full_ddp", "stream_groups", "parallelism", "device_ordinal_of_rank_0", "device_note")
+    if out.get("collective"):
+        line["collective"] = out["collective"]
+    rf = out.get("roofline", {})
+    r = _pick(rf, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm_utilisation_frac", "limiter")
+    dl = rf.get("dominant_launch") or {}
+    r.update({k: dl[k] for k in ("avg_launch_ms", "launches", "trajectories_per_launch") if k in dl})
+    if "hbm_equivalent" in dl:
+        r["algorithmic_bytes_per_launch"] = dl["hbm_equivalent"]["algorithmic_bytes_per_launch"]
+    if "valu_fp64" in dl:
+        r["valu_fp64_frac"] = dl["valu_fp64"]["frac_of_peak"]
+    if dl.get("pmc", {}).get("source"):
+        r["traffic_source"] = "live" if dl["pmc"]["source"].startswith("collected in this run") else "profiles/traffic.json"
+    iss = rf.get("issue") or {}
+    r.update({k: iss[k] for k in ("valu_insts_per_step", "active_valu_frac") if iss.get(k) is not None})
+    if rf.get("alone"):
+        r["alone_avg_launch_ms"] = rf["alone"]["avg_launch_ms"]
+    line["roofline"] = r
+    ir = out.get("iteration_roofline")
+    if ir:
+        line["iteration_roofline"] = {"achieved": ir["achieved_GBs"], "frac": ir["frac_of_peak"], "unit": "GB/s",
+                                      "algorithmic_bytes_per_iteration": ir["algorithmic_bytes_per_iteration"]}
+    if out.get("cpu_baseline"):
+        line["cpu_baseline"] = out["cpu_baseline"]
+    for name in ("config5", "config5_stored"):
+        o = out.get(name)
+        if not o:
+            continue
+        if "error" in o:
+            line[name] = {"error": str(o["error"])[:160]}
+            continue
+        orf = o.get("roofline", {})
+        line[name] = {"value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "frac": orf.get("frac"),
+                      "hbm_equivalent_frac": orf.get("hbm_equivalent_frac"), "traffic": orf.get("traffic"),
+                      "active_valu_frac": (orf.get("issue") or {}).get("active_valu_frac")}
+        if o.get("cpu_baseline"):
+            line[name]["cpu_baseline_value"] = o["cpu_baseline"]["value"]
+    o = out.get("config2")
+    if o:
+        line["config2"] = {"error": str(o["error"])[:160]} if "error" in o else \
+            {k: o[k]["value"] for k in ("lane_mapping", "wave_mapping") if k in o}
+    o = out.get("dropin_b1")
+    if o:
+        line["dropin_b1"] = _pick(o, "ms_per_iteration", "iterations") if "error" not in o else {"error": str(o["error"])[:160]}
+    o = out.get("full_solve")
+    if o:
+        line["full_solve"] = _pick(o, "value", "unit", "speedup_from_compaction", "speedup_from_streaming") if "error" not in o \
+            else {"error": str(o["error"])[:160]}
+    line["detail"] = detail_path
+    # the cap holds whatever a run put into the report: optional objects go first, the contract's keys never
+    for k in ("full_solve", "dropin_b1", "config2", "collective", "iteration_roofline", "config5_stored", "config5"):
+        if len(json.dumps(line)) < LINE_CAP:
+            break
+        line.pop(k, None)
+    s = json.dumps(line)
+    assert len(s) < LINE_CAP, len(s)
+    return s
+
+
+def run_object(name, local, extra=(), timeout=900):
+    """a secondary object of the report measured in a FRESH child process (`bench.py --object NAME`, started with
+    subprocess — never an exec of this GPU-initialised process): its own HIP context and hardware queues, its buffers
+    allocated into an empty device, so that its numbers do not depend on what ran before it in this process"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--object", name] + [str(a) for a in extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, ILQG_DEVICE_ORDINAL=str(local)))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "child `--object %s` rc %d: %s" % (name, r.returncode, (r.stderr or r.stdout)[-300:])}
+    return json.loads(lines[-1])
+
+
+def child_object(args):
+    """`--object NAME`: one secondary object in this (fresh) process, as one JSON line"""
+    import __graft_entry__ as g
+    g.load_package()
+    from ddp_generator_amd import ilqg, synth
+    local = int(os.environ.get("ILQG_DEVICE_ORDINAL", "0"))
+    name = args.object
+    guard = StdoutGuard()
+    if name in ("config5", "config5_stored", "config5_pair"):
+        variant = {"config5": "factored", "config5_stored": "stored", "config5_pair": "pair"}[name]
+        o = config5(ilqg, synth, local, K=args.steps, W=args.warmup, with_cpu=not args.no_cpu_baseline, variant=variant)
+    elif name == "config2":
+        o = config2(ilqg, synth, local, K=args.steps, W=args.warmup)
+    elif name == "dropin_b1":
+        o = dropin_b1(ilqg, synth)
+    elif name in ("alone", "unfused"):
+        B, n_hor = args.batch or 65536, args.n_hor or 500
+        x0, u0 = synth.car_batch(B, n_hor)
+        t = kernel_alone(ilqg, "carparking", 0, B, n_hor, ilqg.CAR_PARAMS, x0, u0, local, args.steps,
+                         **with_split(dict(fuse_derivs=1 if name == "alone" else 0), args))
+        o = {k: [v[0], v[1]] for k, v in t.items()}
+    else:
+        raise SystemExit("bench.py: unknown --object %r" % name)
+    guard.emit(json.dumps(o))
 
 
 def main():
@@ -597,33 +762,44 @@ def main():
     ap.add_argument("--rehearse-protocol", action="store_true",
                     help="no solver, no GPU: the ranks run the sharding / barrier / gather / JSON protocol around a stand-in "
                          "(ProtocolShard); the line is marked `rehearsal` and measures nothing")
+    ap.add_argument("--object", default=None,
+                    help="(used by the default run) ONE secondary object of the report — config5, config5_stored, config5_pair, "
+                         "config2, dropin_b1, alone, unfused — measured in this fresh process, as one JSON line")
+    ap.add_argument("--full", action="store_true",
+                    help="also the long secondary objects: full solves to convergence (plain / compacted / streamed), the "
+                         "dominant kernel alone, the two kernels of the unfused path (all go to bench_detail.json)")
     ap.add_argument("--groups", type=int, default=0,
                     help="independent sets of trajectories advanced on separate HIP streams (0: library default)")
     args = ap.parse_args()
+    if args.object:  # a child of the default run: no torch, no process group
+        if args.steps == 20 and args.object.startswith("config5"):
+            args.steps, args.warmup = (2 if args.object != "config5" else 3), 1
+        return child_object(args)
 
     import torch
     import torch.distributed as dist
     import __graft_entry__ as g
     pkg = g.load_package()
     from ddp_generator_amd import ilqg, synth
+    guard = StdoutGuard()
 
     rank, local, world = pkg.dist.env_world()
     if args.single_process and world == 1 and args.gpus > 1:
-        return single_process(args, ilqg, synth)
+        return single_process(args, ilqg, synth, guard)
     if args.config5_variant:
-        print(json.dumps(config5(ilqg, synth, local, K=args.steps if args.steps != 20 else 3, W=min(args.warmup, 1), with_cpu=False, variant=args.config5_variant)))
+        guard.emit(json.dumps(config5(ilqg, synth, local, K=args.steps if args.steps != 20 else 3, W=min(args.warmup, 1), with_cpu=False, variant=args.config5_variant)))
         return
     if args.solve_stream is not None:
         local = int(os.environ.get("ILQG_DEVICE_ORDINAL", local))
-        print(json.dumps(solve_stream_once(ilqg, synth, local, args.batch or 65536, args.n_hor or 500, args.max_iter, args.solve_stream)))
+        guard.emit(json.dumps(solve_stream_once(ilqg, synth, local, args.batch or 65536, args.n_hor or 500, args.max_iter, args.solve_stream)))
         return
     if args.solve_one is not None:
         local = int(os.environ.get("ILQG_DEVICE_ORDINAL", local))
-        print(json.dumps(solve_once(ilqg, synth, local, args.batch or 65536, args.n_hor or 500, args.max_iter, args.solve_one)))
+        guard.emit(json.dumps(solve_once(ilqg, synth, local, args.batch or 65536, args.n_hor or 500, args.max_iter, args.solve_one)))
         return
     if args.solve:
         assert world == 1 and args.workload == "car", "--solve: one GPU, CarParking"
-        print(json.dumps(full_solve(local, B=args.batch or 65536, n_hor=args.n_hor or 500, max_iter=args.max_iter, compact=args.compact)))
+        guard.emit(json.dumps(full_solve(local, B=args.batch or 65536, n_hor=args.n_hor or 500, max_iter=args.max_iter, compact=args.compact)))
         return
     rehearsal = args.rehearse_protocol
     if rehearsal:
@@ -841,55 +1017,48 @@ def main():
                             "as ONE group and nothing else on the GPU, over the same %d iterations."
                             % (backpass_flops(nx, nu, fd), stream_groups, K)}
         if secondary:
-            # the dominant kernel ALONE: one group of trajectories, so a launch covers the whole batch and shares the
-            # GPU with nothing; the SAME K iterations as the headline window (the kernel grows with the iterations)
-            iters1 = K
-            t1 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, iters1, **with_split(dict(fuse_derivs=1), args))
-            name = "k_backward[fused derivs]"
-            n_launch, total_ms = t1[name]
-            avg_ms = total_ms / n_launch
-            flops_launch = backpass_flops(nx, nu, fd) * n_hor * B
-            out["roofline"]["alone"] = {
-                "avg_launch_ms": avg_ms, "launches": n_launch, "stream_groups": 1, "trajectories_per_launch": B,
-                "valu_fp64_TFLOPs": flops_launch / (avg_ms * 1e-3) / 1e12,
-                "valu_fp64_frac": flops_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                "hbm_equivalent_GBs": (alg["k_derivs"] + alg["k_backward"]) * n_hor * B / (avg_ms * 1e-3) / 1e9,
-                "note": "one wavefront per SIMD (65 536 lanes): a chain of dependent fp64 instructions, see DESIGN.md; "
-                        "hbm_equivalent above the 8 TB/s peak means the fused kernel beats what the unfused pair could reach"}
-            out["kernels_ms_per_iteration_alone"] = {k: v[1] / iters1 for k, v in t1.items() if v[0]}
-            # the HBM-bound kernels of the unfused path, each alone
-            t2 = kernel_alone(ilqg, problem, fd, B, n_hor, params, x0, u0, local, 5, **with_split(dict(fuse_derivs=0), args))
-            unfused = {}
-            for kname in ("k_derivs", "k_backward"):
-                n, ms = t2[kname]
-                if n:
-                    b_alg = alg[kname] * n_hor * B
-                    unfused[kname] = {"bound": "hbm", "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": b_alg,
-                                      "achieved_GBs": b_alg / (ms / n * 1e-3) / 1e9,
-                                      "frac_of_peak": b_alg / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, "stream_groups": 1}
-            out["unfused_kernels"] = unfused
-            # the secondary objects must not cost the headline line: a failure is reported in place
-            try:
-                out["dropin_b1"] = dropin_b1(ilqg, synth)
-            except Exception as e:
-                out["dropin_b1"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            try:
-                out["config2"] = config2(ilqg, synth, local)
-            except Exception as e:
-                out["config2"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            try:
-                out["full_solve"] = full_solve(local)
-            except Exception as e:
-                out["full_solve"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # Every secondary object is measured in a fresh child process (run_object): its own HIP context and queues,
+            # its buffers allocated into an empty device — this process has released the solver and holds only torch's
+            # context.  A failure is reported in place and never costs the headline.
+            if args.full:
+                # the dominant kernel ALONE: one group of trajectories, so a launch covers the whole batch and shares the
+                # GPU with nothing; the SAME K iterations as the headline window (the kernel grows with the iterations)
+                t1 = run_object("alone", local, ["--steps", K, "--batch", B, "--n-hor", n_hor] + (["--ls-split", args.ls_split] if args.ls_split is not None else []))
+                name = "k_backward[fused derivs]"
+                if "error" not in t1 and t1.get(name, [0])[0] and "roofline" in out:
+                    n_launch, total_ms = t1[name]
+                    avg_ms = total_ms / n_launch
+                    flops_launch = backpass_flops(nx, nu, fd) * n_hor * B
+                    out["roofline"]["alone"] = {
+                        "avg_launch_ms": avg_ms, "launches": n_launch, "stream_groups": 1, "trajectories_per_launch": B,
+                        "valu_fp64_TFLOPs": flops_launch / (avg_ms * 1e-3) / 1e12,
+                        "valu_fp64_frac": flops_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                        "hbm_equivalent_GBs": (alg["k_derivs"] + alg["k_backward"]) * n_hor * B / (avg_ms * 1e-3) / 1e9,
+                        "note": "one wavefront per SIMD (65 536 lanes): a chain of dependent fp64 instructions, see DESIGN.md; "
+                                "hbm_equivalent above the 8 TB/s peak means the fused kernel beats what the unfused pair could reach"}
+                    out["kernels_ms_per_iteration_alone"] = {k: v[1] / K for k, v in t1.items() if v[0]}
+                elif "error" in t1:
+                    out["kernels_ms_per_iteration_alone"] = t1
+                # the HBM-bound kernels of the unfused path, each alone
+                t2 = run_object("unfused", local, ["--steps", 5, "--batch", B, "--n-hor", n_hor] + (["--ls-split", args.ls_split] if args.ls_split is not None else []))
+                unfused = {}
+                for kname in ("k_derivs", "k_backward"):
+                    n, ms = t2.get(kname, (0, 0.0)) if "error" not in t2 else (0, 0.0)
+                    if n:
+                        b_alg = alg[kname] * n_hor * B
+                        unfused[kname] = {"bound": "hbm", "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": b_alg,
+                                          "achieved_GBs": b_alg / (ms / n * 1e-3) / 1e9,
+                                          "frac_of_peak": b_alg / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, "stream_groups": 1}
+                out["unfused_kernels"] = unfused if "error" not in t2 else t2
+                try:
+                    out["full_solve"] = full_solve(local)
+                except Exception as e:
+                    out["full_solve"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["dropin_b1"] = run_object("dropin_b1", local)
+            out["config2"] = run_object("config2", local, ["--steps", 20, "--warmup", 2])
             if not args.no_config5:
-                try:
-                    out["config5"] = config5(ilqg, synth, local, with_cpu=not args.no_cpu_baseline)
-                except Exception as e:
-                    out["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
-                try:
-                    out["config5_stored"] = config5(ilqg, synth, local, K=2, W=1, with_cpu=False, variant="stored")
-                except Exception as e:
-                    out["config5_stored"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["config5"] = run_object("config5", local, ["--steps", 3, "--warmup", 1] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
+                out["config5_stored"] = run_object("config5_stored", local, ["--steps", 2, "--warmup", 1, "--no-cpu-baseline"])
         elif not car:
             flops = backpass_flops(nx, nu, fd) * n_hor * B
             out["roofline"] = {"bound": "hbm", "kernel": "iteration", "achieved": iter_bytes * (K / dt) / world / 1e9,
@@ -903,7 +1072,7 @@ def main():
         if not args.no_cpu_baseline:  # rank 0, whatever the world size: the host's cores are the same
             out["cpu_baseline"] = cpu_baseline(B, K, problem, fd, params, n_hor,
                                                synth.car_batch if car else synth.synth16_batch)
-        print(json.dumps(out), flush=True)
+        guard.emit(compact_line(out, write_detail(out)))
     if world > 1:
         dist.barrier()  # (rank 0 may still have been timing the CPU baseline)
         dist.destroy_process_group()

@@ -90,7 +90,11 @@ def _run_bench(argv, nproc=0, port=0):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0
-    return json.loads(lines[0])
+    assert r.stdout.strip() == lines[0], r.stdout[-2000:]  # and nothing else on stdout (console lines of the C checkers)
+    assert len(lines[0]) < 6000, len(lines[0])  # what the driver parses; the full report is bench_detail.json
+    out = json.loads(lines[0])
+    assert out["detail"] == "bench_detail.json" and os.path.exists(os.path.join(ROOT, out["detail"]))
+    return out
 
 
 def test_bench_main_with_two_ranks_protocol_rehearsal():
@@ -119,8 +123,11 @@ def test_bench_main_with_two_ranks_on_one_gpu():
     assert out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] in ("reference", "port")
     rf = out["roofline"]
     assert rf["kernel"] == "k_backward[fused derivs]" and rf["bound"] == "hbm" and 0 < rf["frac"] < 1.5
-    assert rf["dominant_launch"]["launches"] >= 3 and rf["dominant_launch"]["trajectories_per_launch"] * out["config"]["stream_groups"] == 512
-    assert abs(rf["achieved"] - rf["dominant_launch"]["hbm_equivalent"]["GBs"]) < 1e-9 * rf["achieved"]
+    assert rf["launches"] >= 3 and rf["trajectories_per_launch"] * out["config"]["stream_groups"] == 512
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-9 * rf["achieved"]
+    import json
+    detail = json.load(open(os.path.join(ROOT, out["detail"])))  # the full report carries the line's figures and more
+    assert detail["value"] == out["value"] and detail["roofline"]["dominant_launch"]["launches"] == rf["launches"]
     assert abs(out["value"] - 2 * out["per_gpu_iterations_per_s"]) < 1e-9 * out["value"]  # whole job = 2 shards
     assert out["collective"]["gathered_on_rank_0"] == 1024 and out["trajectories_still_active"] == 512
     pkg = load_package()
