@@ -1616,6 +1616,53 @@ def test_speculative_retries_equal_the_sequential_sweeps(ilqg, monkeypatch, prob
         assert calls.max() >= 3 and (calls > 1).mean() > 0.1, (calls.max(), (calls > 1).mean())
 
 
+@pytest.mark.parametrize("opts,what", [(dict(lambdaFactor=1.2), "long"), (dict(lambdaMax=1e-4), "short")])
+def test_speculative_retries_under_other_lambda_schedules(ilqg, monkeypatch, opts, what):
+    """The lambda schedule is the user's (lambdaFactor, lambdaMin, lambdaMax: setOptParam); the speculative kernel numbers a
+    trajectory's sweeps 0..15.  "long": lambdaFactor = 1.2 allows more than 16 sweeps per call — the host takes
+    the sequential loop then (ilqg_shim_impl.inc spec_sweeps_at_most) and nothing is lost.  "short": lambdaMax so small
+    that trajectories run out of schedule (exit "no descent", iLQG.c:273-274) while rows speculate on them — status, lambda,
+    dlambda, sweep counts and everything of the trajectories that go on equal ILQG_QUAD_SPEC=0 bit for bit; the gains of
+    a trajectory that LEFT with "no descent" are those of partial sweeps in either path (nothing reads them) and are not
+    compared."""
+    B, N, K = 300, 60, 5
+    x0, u0 = syn_inputs(B, N, first=3)
+    x0 = x0 * np.linspace(0.3, 2.5, B)[:, None]
+
+    def run(spec):
+        monkeypatch.setenv("ILQG_QUAD_SPEC", "1" if spec else "0")
+        s = ilqg.BatchSolver("synth16x8", 1, batch=B, n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=K + 1, lambdaInit=1e-7, **opts))
+        s.init(x0, u0)
+        out = []
+        for it in range(K):
+            s.iterate(1)
+            l, L = s.gains()
+            out.append(dict(l=l.copy(), L=L.copy(), x=s.x().copy(), u=s.u().copy(), cost=s.scalar("cost").copy()))
+            for k in ("dV0", "dV1", "g_norm", "lambda", "dlambda"):
+                out[-1][k] = s.scalar(k).copy()
+            for k in ("status", "bp_calls", "bp_rc", "alpha_idx"):
+                out[-1][k] = s.ints(k).copy()
+        s.close()
+        return out
+
+    a, b = run(False), run(True)
+    NO_DESCENT = 4
+    for it, (p, q) in enumerate(zip(a, b)):
+        assert np.array_equal(p["status"], q["status"]), it
+        live = p["status"] != NO_DESCENT
+        for k in p:
+            if k in ("l", "L"):
+                assert np.array_equal(p[k][live], q[k][live]), (it, k)
+            else:
+                assert np.array_equal(p[k], q[k]), (it, k)
+    calls = np.concatenate([o["bp_calls"] for o in a])
+    status = a[-1]["status"]
+    if what == "short":
+        assert (status == NO_DESCENT).sum() >= 3 and (status != NO_DESCENT).sum() >= 3, np.bincount(status)
+    else:
+        assert calls.max() >= 4, calls.max()
+
+
 @pytest.mark.parametrize("strict", [True, False])
 def test_factored_records_with_state_dependent_limits(ilqg, oracle_built, strict):
     """n > 8, FULL_DDP = 1 from the factored tensor tables, AND input limits that depend on the state (problems/defs/
