@@ -605,6 +605,7 @@ int ilqg_batch_solve(ilqg_batch_t *c) {
     const int dbg = getenv("ILQG_SOLVE_DEBUG") != NULL;
     double t_dbg = 0.0, t_poll = 0.0;
     if(push_config(c)) return 1;
+    c->err[0] = 0;
     c->trace_n = 0;
     t_poll = dbg ? now_s() : 0.0;
     c->compactions = 0;
@@ -615,7 +616,7 @@ int ilqg_batch_solve(ilqg_batch_t *c) {
         it += n;
         if(ilqg_batch_active(cur, &active)) { rc = 1; break; }
         if(dbg && it % 40 == 0) {
-            fprintf(stderr, "ilqg solve: iteration %d, %d live of %d slots, %.2f ms per iteration\n", it, active, cur->B, 1e3 * (now_s() - t_poll) / 4);
+            fprintf(stderr, "ilqg solve: iteration %d, %d live of %d slots, %.2f ms per iteration\n", it, active, cur->B, 1e3 * (now_s() - t_poll) / n);
         }
         t_poll = dbg ? now_s() : 0.0;
         if(c->trace_n < ILQG_TRACE_MAX) {
@@ -661,7 +662,7 @@ int ilqg_batch_solve(ilqg_batch_t *c) {
             ident = (int *)realloc(ident, sizeof(int) * cur->B);
             for(j = 0; j < cur->B; j++) ident[j] = j;
             if(move_between(c, cur, cur->B, map, ident)) rc = 1;
-        } else {
+        } else if(!c->err[0]) {  /* (a failure already recorded in c — a move, a new context — stays; else the iterated context's) */
             snprintf(c->err, sizeof(c->err), "%s", cur->err);
         }
         ilqg_batch_destroy(cur);
@@ -1123,6 +1124,7 @@ int line_search(tOptSet *o, int iter) {
     double *x = dropin_scratch(c, 2 * n_x + 3 * n_u + n_L, who);
     double *u = x + n_x, *l = u + n_u, *L = l + n_u, *xc = L + n_L, *uc = xc + n_x;
     int k, accepted = 0, idx = 0, zero = 0;
+    int ok[ILQG_MAX_ALPHA];  /* finite-flag of every step size's roll-out (the replay of the reference's console walk below) */
     double cnew = 0.0, dcost = 0.0, expected = 0.0, z, tmp;
 
     pack_xu(o->nominal, N, x, u);
@@ -1156,6 +1158,7 @@ int line_search(tOptSet *o, int iter) {
     DEV_OK(ilqg_dev_read(d, ILQG_F_EXPECTED, &expected), who);
     DEV_OK(ilqg_dev_read(d, ILQG_F_X, xc), who);  /* the stored winner; unchanged nominal if nothing was accepted */
     DEV_OK(ilqg_dev_read(d, ILQG_F_U, uc), who);
+    if(DEBUG_FORWARDPASS) DEV_OK(ilqg_dev_read_int(d, ILQG_I_ALPHA_OK, ok), who);  /* (same batch: no second round trip) */
     DEV_OK(ilqg_dev_io_end(d), who);
     if(accepted) {
         traj_t *cand = o->candidates[0];
@@ -1172,12 +1175,7 @@ int line_search(tOptSet *o, int iter) {
     if(DEBUG_FORWARDPASS) {
         /* what the reference says while it walks the step sizes one by one (line_search.c:44-66): the device has
          * tried them all at once and kept every cost and finite-flag, so the same walk is replayed here */
-        double costs[ILQG_MAX_ALPHA];
-        int ok[ILQG_MAX_ALPHA], tried = accepted ? idx : o->n_alpha, i;
-        DEV_OK(ilqg_dev_io_begin(d), who);
-        DEV_OK(ilqg_dev_read(d, ILQG_F_ALPHA_COST, costs), who);
-        DEV_OK(ilqg_dev_read_int(d, ILQG_I_ALPHA_OK, ok), who);
-        DEV_OK(ilqg_dev_io_end(d), who);
+        int tried = accepted ? idx : o->n_alpha, i;
         for(i = 0; i < tried && i < o->n_alpha; i++) {
             if(!ok[i])
                 SAY_SEARCH(2, ("line search: %-3d: prediction or objective failed with inf or nan\n", i + 1));

@@ -37,6 +37,31 @@
 // NaN/Inf guards in generated code still `return 0`; their printing is dropped on the device
 #define PRNT(...) ((void)0)
 
+// Whether the callbacks of this pair work on a private element with proxies for the derivative arrays (ILQG_DEV_EL; what that
+// is: further down, in front of the function file)
+#include "ilqg_record_dev.h"  // ILQG_DEV_RECORDS; member and assignment lists of this pair (build directory)
+#ifndef ILQG_DEV_ELEMENT      // (-DILQG_DEV_ELEMENT=0: the callbacks on the record itself, as before — comparison)
+#define ILQG_DEV_ELEMENT 1
+#endif
+#if ILQG_DEV_RECORDS && ILQG_DEV_ELEMENT
+// the header once under other names: the record's LAYOUT (what lies in HBM, what the host sees)
+#define trajEl_t trajEl_layout_t
+#define traj_t traj_layout_t
+#include "iLQG_problem.h"
+#undef trajEl_t
+#undef traj_t
+#if (N_X > 8) || (defined(ILQG_WAVE_MAP) && ILQG_WAVE_MAP)
+#define ILQG_DEV_EL 1
+#else
+#define ILQG_DEV_EL 0  // lane mapping: the element is a handful of registers anyway
+typedef trajEl_layout_t trajEl_t;
+typedef traj_layout_t traj_t;
+#endif
+#else
+#define ILQG_DEV_EL 0
+#endif
+
+
 // ---------------------------------------------------------------------------
 // Hooks of the generated code on the device.
 //
@@ -259,7 +284,11 @@ __device__ __attribute__((noinline, const)) static ilqg_sc ilqg_sincos_call(doub
 // A file without the macros (Maxima-generated) stores directly as before.
 // ---------------------------------------------------------------------------
 #ifndef ILQG_DERIVS_BLOCK
+#if ILQG_DEV_EL
+#define ILQG_DERIVS_BLOCK 64  // one wavefront per workgroup of k_derivs_wave: its ring (ilqgdev) is 33 KB of dynamic LDS
+#else
 #define ILQG_DERIVS_BLOCK 256
+#endif
 #endif
 #define ILQG_STAGE_LD 65  // doubles between the slots of a lane (64 lanes + 1: the write-out reads a column, lane l slot first + l)
 __shared__ double ilqg_stage[(ILQG_DERIVS_BLOCK / 64) * 64 * ILQG_STAGE_LD];
@@ -334,6 +363,177 @@ __device__ __forceinline__ static void ilqg_stage_flush(double **p, unsigned fir
     asm volatile("" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------
+// The element the callbacks work on (wave mapping, generated pairs WITHOUT staging macros — a Maxima / gentran pair, or
+// tools/gen_problem.py --plain): not the record.  A record of the n = 16 problem is 47.9 KB, 47 KB of it the derivative
+// arrays cx .. fxu; the callbacks get a `trajEl_t *t` and store `t->fxx[17]= ...`.  With t = the record in HBM every such
+// store touches 64 records with 8 bytes each (k_derivs_wave was bound by the L2's request rate: 64 requests per store
+// instruction, profiles/r5_stored_path.txt); with t = a private copy of the struct a lane needs 47.9 KB of scratch memory,
+// 3 MB per wavefront, and the dispatcher then runs a few dozen wavefronts at a time (the roll-outs of such pairs).
+// So on these builds the callbacks are compiled against `trajEl_dev_t`: the members of trajEl_t in the header's order
+// (tools/gen_record_dev.py reads them at build time), the derivative arrays replaced by PROXIES without storage.  An
+// assignment to a proxy's entry puts the value into a ring of 64 slots per lane in LDS (slot = the entry's place in the
+// record modulo 64, lane-fastest), and the assignment that completes a run of neighbouring entries — a compile-time
+// table made from the ORDER in which init_running / bp_derivsL assign, same script — has the wavefront write the run out:
+// one store instruction per record, 512 contiguous bytes (ilqg_stage_flush's scheme, for a function file that knows
+// nothing of it).  A kernel that wants none of this (roll-outs: init_running for the constant auxiliaries) sets the
+// wavefront's mode to "discard".  The function file itself is compiled as it stands.
+// ---------------------------------------------------------------------------
+#if ILQG_DEV_EL
+namespace ilqgdev {
+constexpr int LD = 65;  // doubles between the slots of a lane (64 lanes + 1: the write-out reads a column)
+constexpr int ENTRIES = (int)(sizeof(trajEl_layout_t) / sizeof(double));
+enum { DISCARD = 0, TOGETHER = 1, ALONE = 2 };
+// STATIC LDS, in every kernel that runs callbacks which assign derivative entries (k_derivs_wave; the roll-outs and
+// k_multipliers through init_running): the ring [64 slots][LD] of the workgroup's ONE wavefront, the records its lanes
+// write to, and what the end of a run does.  Static, so that a slot's address is one per-lane register (made of threadIdx
+// alone, no load) plus an immediate offset: an assignment is one ds_write_b64.  (Dynamic LDS with the mode looked up per
+// assignment was tried first: 10-13 minutes of compilation for the n = 16 pair against 37 s.)  Kernels that discard still
+// fill the ring — 33 KB of LDS per wavefront, which costs these kernels nothing: at 230-300 registers they run one
+// wavefront per SIMD, four per CU.
+constexpr int WAVES = 1;  // wavefronts per workgroup of the kernels that run these callbacks (asserted where they are defined)
+__shared__ double ring_lds[WAVES * 64 * LD];
+__shared__ unsigned long long record_lds[WAVES * 64];
+__shared__ int mode_lds[WAVES];
+__device__ __forceinline__ double *ring() { return ring_lds; }
+__device__ __forceinline__ unsigned long long *records() { return record_lds; }
+__device__ __forceinline__ int mode() { return __builtin_amdgcn_readfirstlane(mode_lds[0]); }
+__device__ __forceinline__ void set_mode(int m) { mode_lds[0] = m; }
+__device__ __forceinline__ void set_record(void *rec) { record_lds[threadIdx.x & 63] = (unsigned long long)rec; }
+__device__ __forceinline__ double &slot(unsigned e) { return ring_lds[(e & 63u) * LD + (threadIdx.x & 63)]; }
+
+// entries [first, first + count) of the lanes' records, from the ring to HBM (count <= 64, one aligned window of 64)
+#ifndef ILQG_DEV_FLUSH_INLINE
+#define ILQG_DEV_FLUSH_INLINE 1
+#endif
+#if ILQG_DEV_FLUSH_INLINE
+#define ILQG_DEV_FLUSH_ATTR __device__ __forceinline__
+#else
+#define ILQG_DEV_FLUSH_ATTR __device__ __attribute__((noinline))
+#endif
+ILQG_DEV_FLUSH_ATTR void flush(int m, unsigned first, int count) {
+    typedef __attribute__((address_space(1))) double gdouble;
+    asm volatile("" ::: "memory");
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long tb = records()[lane];
+    if(m == ALONE) {
+        double *const out = reinterpret_cast<double *>(tb) + first;
+#pragma unroll 1
+        for(int i = 0; i < count; i++) out[i] = slot(first + i);
+    } else {
+        const unsigned lo = (unsigned)tb, hi = (unsigned)(tb >> 32);
+        const double *const rg = ring();
+        // (two records per store instruction, 16 bytes per lane, was measured for whole windows: 340 against 260 ms per
+        // iteration of config 5 — two 512-byte segments per instruction are slower than one)
+        if(count > 32) {
+            // one record per store instruction: lane l its entry first + l; the record's address is wave-uniform
+            const double *const col = rg + ((first + lane) & 63u) * LD;
+            for(int s0 = 0; s0 < 64; s0 += 8) {
+                double v[8];
+#pragma unroll
+                for(int j = 0; j < 8; j++) v[j] = col[s0 + j];
+#pragma unroll
+                for(int j = 0; j < 8; j++) {
+                    const unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, s0 + j) << 32) |
+                                                    (unsigned)__builtin_amdgcn_readlane((int)lo, s0 + j);
+                    if((int)lane < count) reinterpret_cast<gdouble *>(base)[first + lane] = v[j];
+                }
+            }
+        } else {
+            // short runs: 64 / W records per store instruction, W = 8, 16 or 32 lanes each
+            const int W = count > 16 ? 32 : (count > 8 ? 16 : 8), G = 64 / W;
+            const unsigned e = lane & (W - 1), g = lane / W;
+            const double *const col = rg + ((first + e) & 63u) * LD;
+            for(int s0 = 0; s0 < 64; s0 += G) {
+                const int s = s0 + (int)g;
+                const unsigned long long base = ((unsigned long long)(unsigned)__shfl((int)hi, s) << 32) | (unsigned)__shfl((int)lo, s);
+                const double v = col[s];
+                if((int)e < count) reinterpret_cast<gdouble *>(base)[first + e] = v;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+// the assignment order of the function file -> "this entry ends the run [first, first + count)"
+struct Run {
+    unsigned short first, count;
+};
+struct RunTable {
+    Run r[ENTRIES];
+    int collisions;
+};
+#define ILQG_DEV_E(member, index) (unsigned short)(offsetof(trajEl_layout_t, member) / sizeof(double) + (index)),
+constexpr unsigned short seq_init[] = {ILQG_DEV_SEQ_INIT(ILQG_DEV_E) 0xffff};
+constexpr unsigned short seq_derivs[] = {ILQG_DEV_SEQ_DERIVS(ILQG_DEV_E) 0xffff};
+#undef ILQG_DEV_E
+constexpr void add_runs(RunTable &t, const unsigned short *seq, int n) {
+    int first = 0;  // position in seq where the current run began
+    for(int j = 0; j < n; j++) {
+        const bool last = j + 1 == n || seq[j + 1] != seq[j] + 1 || (seq[j + 1] & 63) == 0;
+        if(last) {
+            if(t.r[seq[j]].count) t.collisions++;
+            t.r[seq[j]].first = seq[first];
+            t.r[seq[j]].count = (unsigned short)(j + 1 - first);
+            first = j + 1;
+        }
+    }
+}
+constexpr RunTable make_runs() {
+    RunTable t{};
+    add_runs(t, seq_init, (int)(sizeof(seq_init) / sizeof(seq_init[0])) - 1);
+    add_runs(t, seq_derivs, (int)(sizeof(seq_derivs) / sizeof(seq_derivs[0])) - 1);
+    return t;
+}
+__device__ constexpr RunTable runs = make_runs();
+static_assert(runs.collisions == 0, "an entry ends a run of init_running and one of bp_derivsL");
+
+template <unsigned OFF>
+struct Ref {
+    int i;
+    __device__ __forceinline__ void operator=(double v) const {
+        const unsigned e = OFF + (unsigned)i;
+        slot(e) = v;
+        const Run r = runs.r[e];
+        if(r.count) {  // (a compile-time condition wherever the index is a literal)
+            const int m = mode();
+            if(m != DISCARD) flush(m, r.first, r.count);
+        }
+    }
+    __device__ __forceinline__ operator double() const { return slot(OFF + (unsigned)i); }
+};
+template <unsigned OFF, int N>
+struct Arr {
+    __device__ __forceinline__ Ref<OFF> operator[](int i) const { return Ref<OFF>{i}; }
+};
+// memset(t->fxx, 0, sizeof(double) * ...) of init_running (iLQG_func.tem:338-342): the member's entries, one by one
+template <unsigned OFF, int N>
+__device__ __forceinline__ void *dev_memset(const Arr<OFF, N> &a, int, size_t) {
+#pragma unroll 1
+    for(int i = 0; i < N; i++) a[i] = 0.0;
+    return nullptr;
+}
+__device__ __forceinline__ void *dev_memset(void *d, int v, size_t n) { return __builtin_memset(d, v, n); }
+}  // namespace ilqgdev
+
+struct trajEl_dev_t {
+#define ILQG_DEV_SCALAR(name) double name;
+#define ILQG_DEV_ARRAY(name, count) double name[count];
+#define ILQG_DEV_PROXY(name, count) ilqgdev::Arr<(unsigned)(offsetof(trajEl_layout_t, name) / sizeof(double)), (count)> name;
+    ILQG_DEV_MEMBERS(ILQG_DEV_SCALAR, ILQG_DEV_ARRAY, ILQG_DEV_PROXY)
+#undef ILQG_DEV_SCALAR
+#undef ILQG_DEV_ARRAY
+#undef ILQG_DEV_PROXY
+};
+typedef struct {
+    trajEl_dev_t *t;
+    trajFin_t f;
+} traj_dev_t;
+#define trajEl_t trajEl_dev_t
+#define traj_t traj_dev_t
+#define memset(d, v, n) ilqgdev::dev_memset(d, v, n)
+#endif
+
 extern "C" {
 #pragma clang attribute push(__attribute__((device)), apply_to = function)
 #pragma clang attribute push(__attribute__((internal_linkage)), apply_to = variable(is_global))
@@ -369,6 +569,18 @@ extern "C" {
 }
 #undef sin
 #undef cos
+// el_t: what the kernels hand the callbacks as `trajEl_t *`; trajEl_t: the record in HBM (the header's struct) either way
+#if ILQG_DEV_EL
+#undef trajEl_t
+#undef traj_t
+#undef memset
+typedef trajEl_dev_t el_t;
+typedef traj_dev_t eltraj_t;
+typedef trajEl_layout_t trajEl_t;
+#else
+typedef trajEl_t el_t;
+typedef traj_t eltraj_t;
+#endif
 // The function file's own macros end here: the reference's template leaves `mcond`, `sec`, `csc` and one `aux_<name>` /
 // `daux_<name>` / `mu_<kind>_<i>` per auxiliary and multiplier defined to the end of the translation unit
 // (iLQG_func.tem:5-30), which on the host is the end of the file and here would be the kernels.  The list is made from

@@ -34,6 +34,7 @@ def worst(a, b):
 def ilqg():
     import __graft_entry__ as g
     g.build()
+    g.build_variants()  # (the `_exp`, `_lean`, `_elem` libraries some tests of this module load)
     from ddp_generator_amd import ilqg as m
     if m.Problem("carparking", 0).device_count() < 1:
         pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")

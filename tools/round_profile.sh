@@ -7,8 +7,10 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out/evidence
 mkdir -p $OUT
 cd $R
-echo "== default bench"; python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { echo "bench failed"; tail -5 $OUT/bench_default.err; exit 1; }
-tail -c 300 $OUT/bench_default.json; echo
+echo "== default bench (the driver's command; the line, and the full report bench_detail.json)"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err || { echo "bench failed"; tail -5 $OUT/bench_default.err; exit 1; }
+cp bench_detail.json $OUT/bench_default_detail.json
+wc -c $OUT/bench_default.json; tail -c 300 $OUT/bench_default.json; echo
 cd /tmp
 echo "== kernel stats, headline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_car -- python3 $R/bench.py --no-cpu-baseline --no-unfused > $OUT/stats_car.log 2>&1 || echo "rocprofv3 stats (car) failed"
@@ -38,6 +40,21 @@ done
 cd $R
 python3 tools/pmc_summary.py --config5-json $OUT/traffic_config5_stored.json 2 $OUT/traffic_stored/FETCH_SIZE $OUT/traffic_stored/WRITE_SIZE > $OUT/traffic_stored.txt 2>&1
 grep -A3 "k_backward_wave\|k_derivs_wave" $OUT/traffic_stored.txt | head -20
+echo "== SQ counters, config 5 with stored tensors"
+cd /tmp
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
+  n=$(echo $c | cut -d" " -f1)
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/sq_stored/$n -- python3 $R/bench.py --config5-variant stored --steps 1 --warmup 0 > $OUT/sq_stored_$n.log 2>&1 || echo "sq stored $n failed"
+done
+cd $R
+python3 tools/pmc_kernels.py --issue-json $OUT/issue_config5_stored.json 1000 $OUT/sq_stored > $OUT/pmc_stored_path_sq.txt
+grep "k_backward_wave\|k_derivs_wave" $OUT/pmc_stored_path_sq.txt | cut -c1-400
+echo "== kernel stats, config 5 with stored tensors"
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_stored -- python3 $R/bench.py --config5-variant stored --steps 2 --warmup 1 > $OUT/stats_stored.log 2>&1 || echo "rocprofv3 stats (stored) failed"
+cd $R
+find $OUT/stats_stored -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_bench_synth_config5_stored.csv
+head -5 $OUT/kernel_stats_bench_synth_config5_stored.csv
 echo "== full solves"
 timeout -k 10 600 python3 bench.py --solve > $OUT/bench_solve.json 2> $OUT/bench_solve.err || echo "solve bench failed"
 tail -c 400 $OUT/bench_solve.json; echo
