@@ -608,6 +608,11 @@ using namespace ilqg;
 
 constexpr int NX = N_X, NU = N_U;
 constexpr bool FULL = FULL_DDP != 0;
+// (a pair without the header's hint whose limitsU() stores nothing but zeros as the limits' gradients — read off the function
+// file at build time, tools/gen_record_dev.py limits_state_free — is a pair with state-independent limits)
+#if !defined(ILQG_STATE_DEPENDENT_LIMITS) && ILQG_DEV_LIMITS_STATE_FREE
+#define ILQG_STATE_DEPENDENT_LIMITS 0
+#endif
 #ifdef ILQG_STATE_DEPENDENT_LIMITS
 constexpr bool HX = ILQG_STATE_DEPENDENT_LIMITS != 0;
 #else

@@ -493,6 +493,68 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
             __builtin_amdgcn_sched_barrier(0);
             load_first_order();
         }
+    } else if constexpr(FULL) {
+        // STORED tensors (a pair without factored tables: the record carries fxx / fuu / fxu as the generated bp_derivsL
+        // wrote them, back_pass.c:95-131 reads them back): the same split of the entries over the row's 16 lanes — a lane
+        // takes the pairs e = 2 c + 32 q', e + 1 of every slice, one 16-byte load each — but the operand comes from HBM,
+        // so the loads run DEPTH slices ahead of the multiply-adds (4 trajectories x 11 loads of 256 bytes per slice).
+        // d += Vx[i] * t->f??[e] with the reference's one rounding per term in either build.
+        constexpr int NTX = (SXX + 31) / 32 * 2, NTU = (SUU + 31) / 32 * 2, NTC = (NXU + 31) / 32 * 2;
+        constexpr int PER = NTX + NTU + NTC;
+        typedef double dpair __attribute__((ext_vector_type(2)));
+        using gpair = const __attribute__((address_space(1))) dpair;
+        double dxx[NTX], duu[NTU], dxu[NTC];
+#pragma unroll
+        for(int q = 0; q < NTX; q++) dxx[q] = 0.0;
+#pragma unroll
+        for(int q = 0; q < NTU; q++) duu[q] = 0.0;
+#pragma unroll
+        for(int q = 0; q < NTC; q++) dxu[q] = 0.0;
+        auto fetch = [&](auto ic, double (&t)[PER]) {
+            constexpr int i = decltype(ic)::value;
+            // the lane's pair e = 2 c + 16 q, e + 1 of slice i of a tensor with `size` entries per slice (pairs beyond the slice —
+            // its length is not a multiple of 32 — read the slice's first pair and count as zeros)
+            auto pair_of = [&](unsigned member, int size, int q, double &a, double &b) {
+                const bool whole = 16 * q + 32 <= size;  // (every lane's pair is inside: known once q is unrolled)
+                const bool in = whole || 2 * c + 16 * q < size;
+                const int e = in ? 2 * c + 16 * q : 0;
+                const dpair v = *(gpair *)(rec + member + (unsigned)(i * size + e) * 8u);
+                a = in ? v.x : 0.0;
+                b = in ? v.y : 0.0;
+            };
+#pragma unroll
+            for(int q = 0; q < NTX; q += 2) pair_of(R::fxx, SXX, q, t[q], t[q + 1]);
+#pragma unroll
+            for(int q = 0; q < NTU; q += 2) pair_of(R::fuu, SUU, q, t[NTX + q], t[NTX + q + 1]);
+#pragma unroll
+            for(int q = 0; q < NTC; q += 2) pair_of(R::fxu, NXU, q, t[NTX + NTU + q], t[NTX + NTU + q + 1]);
+        };
+        static_assert(SXX % 2 == 0 && SUU % 2 == 0 && NXU % 2 == 0, "a pair of entries does not straddle two slices");
+#ifndef ILQG_QUAD_STORED_DEPTH
+#define ILQG_QUAD_STORED_DEPTH 4
+#endif
+        constexpr int DEPTH = ILQG_QUAD_STORED_DEPTH < NX ? ILQG_QUAD_STORED_DEPTH : NX;
+        double buf[DEPTH][PER];
+        static_for<0, DEPTH>([&](auto ic) { fetch(ic, buf[decltype(ic)::value]); });
+        static_for<0, NX>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            double m[PER];
+#pragma unroll
+            for(int q = 0; q < PER; q++) m[q] = buf[i % DEPTH][q];
+            if constexpr(i + DEPTH < NX) fetch(std::integral_constant<int, i + DEPTH>{}, buf[i % DEPTH]);
+            bc_vecs<i, NTC>(dxu, vx, m + NTX + NTU);
+            bc_vecs<i, NTU>(duu, vx, m + NTX);
+            bc_vecs<i, NTX>(dxx, vx, m);
+        });
+        using lds_pair_w = __attribute__((address_space(3))) dpair;
+        lds_pair_w *const pd2 = (lds_pair_w *)(uintptr_t)(rb + c * 16);
+#pragma unroll
+        for(int q = 0; q < NTC; q += 2) pd2[(Q::dxu + 16 * q) / 2] = dpair{dxu[q], dxu[q + 1]};
+#pragma unroll
+        for(int q = 0; q < NTU; q += 2) pd2[(Q::duu + 16 * q) / 2] = dpair{duu[q], duu[q + 1]};
+#pragma unroll
+        for(int q = 0; q < NTX; q += 2) pd2[(Q::dxx + 16 * q) / 2] = dpair{dxx[q], dxx[q + 1]};
+        wave_sync();
     }
 
     if(pf) pf->probe(1);
@@ -541,12 +603,12 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
 #pragma unroll
         for(int r = 0; r < NX; r++) {
             double v = cxx_c[r] + a[r] * HALF;
-            if(FULL && FACT) v += pd[r];
+            if(FULL) v += pd[r];
             here(v);
             qxx[r] = v;
         }
         qxx_d = cxx_d + dsum;
-        if(FULL && FACT) qxx_d += pd[cx_];
+        if(FULL) qxx_d += pd[cx_];
         here(qxx_d);
     }
     wave_sync();
@@ -577,7 +639,7 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
 #pragma unroll
         for(int j = 0; j < NU; j++) {
             double v = cxu_r[j] + a[j];
-            if(FULL && FACT) v += pd[j * NX];
+            if(FULL) v += pd[j * NX];
             here(v);
             qxu[j] = v;
         }
@@ -595,7 +657,7 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
         };
         if(!ILQG_LEAN_LATE) load_cuu();
         double duu_c[NU], duu_d = 0.0;
-        if(FULL && FACT) {
+        if(FULL) {
             const LdsBase pd = lds_base(rb + (Q::duu + buu) * 8);
 #pragma unroll
             for(int i = 0; i < NU; i++) duu_c[i] = pd[i];
@@ -639,12 +701,12 @@ __device__ __forceinline__ int back_step_quad(const unsigned rb, const unsigned 
 #pragma unroll
         for(int i = 0; i < NU; i++) {
             double v = cuu_c[i] + a[i] * HALF;
-            if(FULL && FACT) v += duu_c[i];
+            if(FULL) v += duu_c[i];
             here(v);
             col[i] = v;
         }
         double qd = cuu_d + dsum;
-        if(FULL && FACT) qd += duu_d;
+        if(FULL) qd += duu_d;
         here(qd);
         // every lane lays down its column (rows above the diagonal are good, the diagonal entry apart) and reads its row
         wave_sync();

@@ -1664,6 +1664,40 @@ def test_speculative_retries_under_other_lambda_schedules(ilqg, monkeypatch, opt
         assert calls.max() >= 4, calls.max()
 
 
+def test_stored_tensors_in_the_quad_mapping_equal_the_row_mapping(ilqg, monkeypatch):
+    """The hint-free n = 16 pair (stored tensors; its limitsU stores only zeros as the limits' gradients, which the build reads
+    off the function file: tools/gen_record_dev.py limits_state_free) through k_backward_quad with the tensors read from the
+    records (ILQG_QUAD_STORED=1, ilqg_quad.hpp: 16-byte pieces a few slices ahead) against the row-mapped default: the first
+    iteration's sweeps (lambda retries included) term by term to rounding — the product build's quad step leaves the
+    symmetric half sums out, DESIGN 2.2 — and three more iterations to the same accepted step sizes and costs."""
+    B, N, K = 23, 40, 4
+    x0, u0 = syn_inputs(B, N, first=5)
+
+    def run(quad):
+        monkeypatch.setenv("ILQG_QUAD_STORED", "1" if quad else "0")
+        s = ilqg.BatchSolver("synth16x8_plain", 1, batch=B, n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=K + 1, lambdaInit=1e-7))
+        s.init(x0, u0)
+        out = []
+        for it in range(K):
+            s.iterate(1)
+            l, L = s.gains()
+            out.append(dict(l=l.copy(), L=L.copy(), x=s.x().copy(), cost=s.scalar("cost").copy(), dV0=s.scalar("dV0").copy(),
+                            calls=s.ints("bp_calls").copy(), alpha=s.ints("alpha_idx").copy()))
+        s.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert np.concatenate([o["calls"] for o in a]).max() > 1
+    for k in a[0]:
+        if k in ("calls", "alpha"):
+            assert np.array_equal(a[0][k], b[0][k]), k
+        else:
+            assert np.allclose(a[0][k], b[0][k], rtol=1e-8, atol=1e-10), (k, float(np.abs(a[0][k] - b[0][k]).max()))
+    for it in range(1, K):
+        assert np.array_equal(a[it]["alpha"], b[it]["alpha"]), it
+        assert np.allclose(a[it]["cost"], b[it]["cost"], rtol=1e-7), it
+
+
 @pytest.mark.parametrize("strict", [True, False])
 def test_factored_records_with_state_dependent_limits(ilqg, oracle_built, strict):
     """n > 8, FULL_DDP = 1 from the factored tensor tables, AND input limits that depend on the state (problems/defs/

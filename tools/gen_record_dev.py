@@ -193,9 +193,49 @@ def scan(problem_dir, fd):
     return members, proxied, seqs, (len(es), runs)
 
 
+def limits_state_free(problem_dir):
+    """True if limitsU() provably stores nothing but zeros as the limits' gradients (lower_hx / upper_hx): every assignment
+    in its body to an indexed name that is not t->lower / t->upper, a sign or an index array has the literal 0 on its
+    right — and there is at least one (the reference's do_hx prints one per state, genenerator_main.mac:419-447).  The
+    backward kernels then leave signs and gradients alone (back_pass.c:186-199 multiplies by them: zero rows of K either
+    way) and the records written for them need not carry either."""
+    src = strip_comments(open(problem_dir + "/iLQG_func.c").read())
+    m = re.search(r"\bstatic\s+void\s+limitsU\s*\(\s*trajEl_t\s*\*\s*t\b[^)]*\)\s*\{", src)
+    if not m:
+        return False
+    depth, i = 1, m.end()
+    while depth and i < len(src):
+        depth += {"{": 1, "}": -1}.get(src[i], 0)
+        i += 1
+    body = src[m.end():i - 1]
+    if re.search(r"^\s*#", body, flags=re.M):
+        return False
+    grads = 0
+    for lhs, idx, op, rhs in re.findall(r"([A-Za-z_][\w>.-]*)\s*\[([^\]]*)\]\s*([-+*/]?=)(?!=)\s*([^;]*);", body):
+        name = lhs.split("->")[-1]
+        if name in ("lower", "upper") or "sign" in name or "idx" in name or name == "active":
+            continue
+        if "hx" in name or "grad" in name:
+            grads += 1
+            if op != "=" or not re.fullmatch(r"[-+]?0(\.0*)?", rhs.strip()):
+                return False
+        else:
+            return False  # an array this rule does not know
+    # (gradients reached without an index: `*hx_++ = ...`, memcpy: not the printers' form)
+    if re.search(r"\*\s*\w*hx\w*\s*(\+\+)?\s*=", body):
+        return False
+    return grads > 0
+
+
 def main():
     problem_dir, fd, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     lines = ["/* Written by tools/gen_record_dev.py from the generated pair in %s (FULL_DDP=%d); see there. */" % (problem_dir, fd)]
+    try:
+        free = limits_state_free(problem_dir)
+    except Exception:
+        free = False
+    lines.append("/* limitsU() stores zeros as the limits' gradients, and nothing else: %s */" % ("yes" if free else "not shown"))
+    lines.append("#define ILQG_DEV_LIMITS_STATE_FREE %d" % (1 if free else 0))
     try:
         members, proxied, seqs, (n, runs) = scan(problem_dir, fd)
         lines.append("#define ILQG_DEV_RECORDS 1")

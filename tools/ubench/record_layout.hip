@@ -39,6 +39,46 @@ __global__ __launch_bounds__(256) void k_write(char *buf, int T, int N, int B, i
     }
 }
 
+// the producer again, one wavefront per workgroup with `lds` bytes of dynamic LDS each: as many wavefronts per CU as that leaves
+// (33 KB: four, the product kernel's occupancy)
+// stagger: 0 none; 1: wavefront w begins with (w mod 4) quarters of a piece's arithmetic, so that the four wavefronts of a CU are a
+// quarter period apart; 2: a piece's 64 stores in four instalments between quarters of the NEXT piece's arithmetic (what a second
+// ring would allow)
+__global__ __launch_bounds__(64) void k_write_occ(char *buf, int T, int N, int B, int work, double seed, int stagger) {
+    extern __shared__ double pad[];
+    const int wave = blockIdx.x, lane = threadIdx.x & 63;
+    const int per = N / 64;
+    const int b = wave / per, k0 = (wave % per) * 64;
+    if(b >= B) return;
+    double acc = seed + lane;
+    pad[lane] = acc;
+    if(stagger == 1)
+        for(int j = 0; j < (wave & 3) * (work / 4); j++) acc = acc * 0.999999 + 1e-9;
+    for(int p = 0; p < PIECES; p++) {
+        if(stagger == 2) {
+            const double prev = acc;
+            for(int q = 0; q < 4; q++) {
+                for(int j = 0; j < work / 4; j++) acc = acc * 0.999999 + 1e-9;
+                if(p > 0)
+#pragma unroll 8
+                    for(int s = 16 * q; s < 16 * q + 16; s++) {
+                        double *dst = reinterpret_cast<double *>(buf + piece_at(T, N, b, k0 + s, p - 1)) + lane;
+                        *dst = prev + s;
+                    }
+            }
+            acc += pad[(lane + p) & 63];
+            continue;
+        }
+        for(int j = 0; j < work; j++) acc = acc * 0.999999 + 1e-9;
+        acc += pad[(lane + p) & 63];
+#pragma unroll 8
+        for(int s = 0; s < 64; s++) {
+            double *dst = reinterpret_cast<double *>(buf + piece_at(T, N, b, k0 + s, p)) + lane;
+            *dst = acc + s;
+        }
+    }
+}
+
 // consumer: one wavefront per trajectory (persistent over a queue), steps N-1 .. 0, 86 loads of 512 B each then `work` dependent FMAs
 template <int PF>
 __global__ __launch_bounds__(64, 2) void k_read(const char *buf, int T, int N, int B, int work, int *queue, double *out) {
@@ -99,6 +139,22 @@ int main(int argc, char **argv) {
                 float ms;
                 CHECK(hipEventElapsedTime(&ms, e0, e1));
                 if(rep) printf("write T=%2d work=%4d: %7.2f ms  %7.1f GB/s\n", T, work, ms, bytes / ms / 1e6);
+            }
+        }
+    }
+    for(int stagger = 0; stagger < 3; stagger++)
+    for(int lds : {0, 16 * 1024, 33 * 1024, 60 * 1024}) {
+        for(int work : {0, 400, 1200}) {
+            if(stagger && (work == 0 || lds < 30000)) continue;
+            const int waves = B * (N / 64);
+            for(int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_write_occ, dim3(waves), dim3(64), lds, 0, buf, 1, N, B, work, 1.0, stagger);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if(rep) printf("write T= 1 work=%4d stagger=%d, one wavefront per workgroup with %5d B of LDS: %7.2f ms  %7.1f GB/s\n", work, stagger, lds, ms, bytes / ms / 1e6);
             }
         }
     }
