@@ -447,75 +447,38 @@ struct RowLds {
 // written to HBM (k_derivs_wave), addressed as uniform base + 32-bit lane offset.  R: byte offsets of the members
 // (a struct of constexpr unsigned: cx, cxx, cu, cuu, cxu, fx, fu, lower, upper, lower_sign, upper_sign, lower_hx,
 // upper_hx and — FULL — fxx, fuu, fxu).
-// PF (k_backward_wave, stored tensors): the tensors travel ONE STEP AHEAD in registers.  A step is its 86 loads of 512
-// bytes and then 2 100 vector instructions that do not touch memory; requested at the start of the step, the loads were
-// exposed in front of the arithmetic (26 of a step's 35 us at config 5, profiles/r5_stored_path.txt).  Here the contraction
-// consumes what the previous step requested, and once the step's own first-order entries have arrived (back_step_row:
-// behind its first wave_sync — requested any earlier, the scheduler lets the step's own loads queue up behind them and
-// the first use of fx waits for all 44 KB) the tensors of the NEXT record of the sweep are requested into the same
-// registers: 96 doubles per lane (192 registers — one wavefront per SIMD instead of two), no second buffer, and the
-// step's arithmetic runs with the next step's 44 KB in flight.
-template <int NX, int NU, bool FULL, class R_, bool PF = false>
+// (Round 6: the tensors of step k-1 requested one step ahead into 192 registers, behind the first-order entries of step k,
+// were measured — one wavefront per SIMD instead of two, 590 against 530 ms per iteration of config 5 with stored tensors,
+// profiles/r6_stored_path.txt — and taken out again.)
+template <int NX, int NU, bool FULL, class R_>
 struct RecordSource {
     using R = R_;
     static constexpr int SXX = tri(NX), SUU = tri(NU), NXU = NX * NU;
     static constexpr int NTX = (SXX + 63) / 64, NTU = (SUU + 63) / 64, NTC = (NXU + 63) / 64;
-    static constexpr bool AHEAD = PF && FULL;
-    const char *rec;   // wave-uniform
-    const char *next;  // AHEAD: the record of the step the sweep visits after this one (its tensors are requested here)
-    mutable double txu[AHEAD ? NX : 1][NTC], tuu[AHEAD ? NX : 1][NTU], txx[AHEAD ? NX : 1][NTX];
+    const char *rec;  // wave-uniform
     template <unsigned OFF>
-    static ILQG_DEV double ld_of(const char *r, unsigned byte_off) {
+    ILQG_DEV double ld(unsigned byte_off) const {
         // the member's address in a scalar register pair of its own: the lane part stays a 32-bit offset
         using gchar = const __attribute__((address_space(1))) char;
-        gchar *member = (gchar *)(r + OFF);
+        gchar *member = (gchar *)(rec + OFF);
         asm("" : "+s"(member));
         return *(const __attribute__((address_space(1))) double *)(member + byte_off);
     }
-    template <unsigned OFF>
-    ILQG_DEV double ld(unsigned byte_off) const {
-        return ld_of<OFF>(rec, byte_off);
-    }
-    static ILQG_DEV unsigned off_xu(int lane, int q, int i) { return (unsigned)(((lane + 64 * q < NXU) ? lane + 64 * q : 0) + i * NXU) * 8u; }
-    static ILQG_DEV unsigned off_uu(int lane, int q, int i) { return (unsigned)(((lane + 64 * q < SUU) ? lane + 64 * q : 0) + i * SUU) * 8u; }
-    static ILQG_DEV unsigned off_xx(int lane, int q, int i) { return (unsigned)(((lane + 64 * q < SXX) ? lane + 64 * q : 0) + i * SXX) * 8u; }
-    // AHEAD: the tensors of record r into the registers (the first step of a sweep)
-    ILQG_DEV void request(const char *r, const int lane) const {
-        if constexpr(AHEAD) {
-#pragma unroll
-            for(int i = 0; i < NX; i++) {
-#pragma unroll
-                for(int q = 0; q < NTC; q++) txu[i][q] = ld_of<R::fxu>(r, off_xu(lane, q, i));
-#pragma unroll
-                for(int q = 0; q < NTU; q++) tuu[i][q] = ld_of<R::fuu>(r, off_uu(lane, q, i));
-#pragma unroll
-                for(int q = 0; q < NTX; q++) txx[i][q] = ld_of<R::fxx>(r, off_xx(lane, q, i));
-            }
-        }
-    }
     // d??[q] += sum_i Vx[i] * f??_i[lane + 64 q], i ascending (vxl: Vx[c] in lane c of every row)
     ILQG_DEV void contract(const double vxl, double (&dxx)[NTX], double (&duu)[NTU], double (&dxu)[NTC], const int lane) const {
-        if constexpr(AHEAD) {
-#pragma unroll
-            for(int i = 0; i < NX; i++) {
-                const double vxi = lane_bcast(vxl, i);  // Vx[i] (lane i holds it)
-#pragma unroll
-                for(int q = 0; q < NTC; q++) dxu[q] += vxi * txu[i][q];
-#pragma unroll
-                for(int q = 0; q < NTU; q++) duu[q] += vxi * tuu[i][q];
-#pragma unroll
-                for(int q = 0; q < NTX; q++) dxx[q] += vxi * txx[i][q];
-            }
-        } else if constexpr(FULL) {
+        if constexpr(FULL) {
 #pragma unroll 8
             for(int i = 0; i < NX; i++) {
                 const double vxi = lane_bcast(vxl, i);  // Vx[i] (lane i holds it)
 #pragma unroll
-                for(int q = 0; q < NTC; q++) dxu[q] += vxi * ld<R::fxu>(off_xu(lane, q, i));
+                for(int q = 0; q < NTC; q++)
+                    dxu[q] += vxi * ld<R::fxu>((unsigned)(((lane + 64 * q < NXU) ? lane + 64 * q : 0) + i * NXU) * 8u);
 #pragma unroll
-                for(int q = 0; q < NTU; q++) duu[q] += vxi * ld<R::fuu>(off_uu(lane, q, i));
+                for(int q = 0; q < NTU; q++)
+                    duu[q] += vxi * ld<R::fuu>((unsigned)(((lane + 64 * q < SUU) ? lane + 64 * q : 0) + i * SUU) * 8u);
 #pragma unroll
-                for(int q = 0; q < NTX; q++) dxx[q] += vxi * ld<R::fxx>(off_xx(lane, q, i));
+                for(int q = 0; q < NTX; q++)
+                    dxx[q] += vxi * ld<R::fxx>((unsigned)(((lane + 64 * q < SXX) ? lane + 64 * q : 0) + i * SXX) * 8u);
             }
         }
     }
@@ -656,11 +619,6 @@ __device__ __forceinline__ int back_step_row(RowLds<NX, NU> &S, const Source &D,
         }
     }
     wave_sync();
-    if constexpr(Source::AHEAD) {  // the next step's tensors: in flight from here to the end of the step
-        __builtin_amdgcn_sched_barrier(0);
-        D.request(D.next, lane);
-        __builtin_amdgcn_sched_barrier(0);
-    }
 
     // ---- T1 = Vxx fx, T2 = Vxx fu (the `ba` / `bc` temporaries of matMult.c); Qu = cu + fu'Vx, Qx = cx + fx'Vx
     double qxl = cxl, qul = cul;  // Qx[c], Qu[c]

@@ -13,7 +13,7 @@ from conftest import ROOT
 @pytest.fixture(scope="module")
 def built():
     import __graft_entry__ as g
-    g.build()
+    g.build_for_tests()
     from ddp_generator_amd import ilqg
     return ilqg
 

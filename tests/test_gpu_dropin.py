@@ -59,7 +59,7 @@ def case(problem):
 @pytest.fixture(scope="module")
 def built():
     import __graft_entry__ as g
-    g.build()
+    g.build_for_tests()
     from ddp_generator_amd import ilqg as m
     if m.Problem("carparking", 0).device_count() < 1:
         pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")

@@ -25,7 +25,7 @@ def close(a, b, tol=1e-10):
 @pytest.fixture(scope="module")
 def ilqg():
     import __graft_entry__ as g
-    g.build()
+    g.build_for_tests()
     from ddp_generator_amd import ilqg as m
     if m.Problem("brachi", 0).device_count() < 1:
         pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")

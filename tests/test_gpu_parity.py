@@ -33,8 +33,7 @@ def worst(a, b):
 @pytest.fixture(scope="module")
 def ilqg():
     import __graft_entry__ as g
-    g.build()
-    g.build_variants()  # (the `_exp`, `_lean`, `_elem` libraries some tests of this module load)
+    g.build_for_tests()  # (with the `_strict`, `_exp`, `_lean`, `_elem` libraries tests of this module load)
     from ddp_generator_amd import ilqg as m
     if m.Problem("carparking", 0).device_count() < 1:
         pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")
@@ -1273,13 +1272,15 @@ def test_failure_paths_are_per_trajectory(ilqg, synth):
     s.close(); clean.close()
 
 
+@pytest.mark.parametrize("problem", ["synth16x8", "synth16x8_plain"])
 @pytest.mark.parametrize("fd", [0, 1])
-def test_failure_paths_are_per_trajectory_with_uniform_guards(ilqg, fd):
+def test_failure_paths_are_per_trajectory_with_uniform_guards(ilqg, fd, problem):
     """the large generated file (n = 16) is compiled with wave-uniform NaN/Inf guards: when one lane's value is not
     finite every lane of the wavefront leaves the callback, and the kernel repeats the call lane by lane.  A NaN
     in one trajectory's inputs (initial roll-out) and an Inf planted in another one's state (derivatives) must fail
     exactly those two and leave every other trajectory's results bit-identical to a clean run (the repetition runs
-    the same machine code as the first attempt)."""
+    the same machine code as the first attempt).  `_plain`: the pair without hints, whose callbacks work on the private
+    element with proxies (ilqgdev) — the repetition then writes each lane's entries out by itself (mode ALONE)."""
     B, N, iters = 70, 32, 2
     x0, u0 = syn_inputs(B, N)
     runs = []
@@ -1287,7 +1288,7 @@ def test_failure_paths_are_per_trajectory_with_uniform_guards(ilqg, fd):
         u = u0.copy()
         if poison:
             u[5, 10, 3] = np.nan
-        s = ilqg.BatchSolver("synth16x8", fd, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters + 1))
+        s = ilqg.BatchSolver(problem, fd, batch=B, n_hor=N, params=SYN_PARAMS_TIGHT, opts=dict(max_iter=iters + 1))
         s.init(x0, u)
         if poison:
             st = s.ints("status")

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ilqg():
     import __graft_entry__ as g
-    g.build()
+    g.build_for_tests()
     from ddp_generator_amd import ilqg as m
     return m
 

@@ -17,7 +17,7 @@ OOT_LIBDIR = os.path.join(ROOT, "ddp-generator_amd", "lib_oot")
 @pytest.fixture(scope="module")
 def built():
     import __graft_entry__ as g
-    g.build()
+    g.build_for_tests()
     from ddp_generator_amd import ilqg
     ilqg.add_library_dir(OOT_LIBDIR)
     return ilqg
