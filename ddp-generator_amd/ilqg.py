@@ -52,8 +52,9 @@ def library_path(problem="carparking", full_ddp=0, strict=False):
     strict="elem": the n = 16 problem built with the one-output-element-per-lane backward step (FMA-free);
     strict="lean": the n = 16 problem's product build with the quad step laid out for two wavefronts per SIMD;
     strict="exp" / "exp_strict": the -DILQG_EXPERIMENTS builds (measured negative results kept tested: the backward pass
-    on two wavefronts, the derivative record in parts, the box QP's pattern tables), product / FMA-free"""
-    suffix = "_" + strict if strict in ("wave", "elem", "lean", "exp", "exp_strict") else ("_strict" if strict else "")
+    on two wavefronts, the derivative record in parts, the box QP's pattern tables), product / FMA-free;
+    strict="direct": the hint-free n = 16 pair with its callbacks on the record itself (-DILQG_DEV_ELEMENT=0: comparison)"""
+    suffix = "_" + strict if strict in ("wave", "elem", "lean", "exp", "exp_strict", "direct") else ("_strict" if strict else "")
     name = "libilqg_%s_fd%d_hip%s.so" % (problem, int(full_ddp), suffix)
     for d in [LIBDIR] + _extra_libdirs:
         if os.path.exists(os.path.join(d, name)):

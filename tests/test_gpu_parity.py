@@ -1665,6 +1665,35 @@ def test_speculative_retries_under_other_lambda_schedules(ilqg, monkeypatch, opt
         assert calls.max() >= 4, calls.max()
 
 
+def test_private_element_with_proxies_changes_nothing(ilqg):
+    """The hint-free n = 16 pair's callbacks work on a private element whose derivative arrays are proxies (an assignment goes
+    into a ring in LDS, runs of entries are written out by the wavefront: ilqg_kernels.hip ilqgdev, tools/gen_record_dev.py)
+    — against the same pair built with -DILQG_DEV_ELEMENT=0 (the callbacks store into the record in HBM entry by entry, as
+    every such pair did before round 6): the derivative records the host reads back, and four lock-step iterations with
+    lambda retries, bit for bit.  The generated arithmetic is the same text in both; this pins the plumbing — slot
+    addresses, run ends, write-outs, constants, limits, a ragged batch with lanes that copy."""
+    B, N, K = 37, 45, 4
+    x0, u0 = syn_inputs(B, N, first=9)
+    x0 = x0 * np.linspace(0.4, 2.2, B)[:, None]
+    out = []
+    for build in (False, "direct"):
+        s = ilqg.BatchSolver("synth16x8_plain", 1, batch=B, n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=K + 1, lambdaInit=1e-7), strict=build)
+        s.init(x0, u0)
+        s.calc_derivs()
+        rec, fin = s.derivs()
+        res = [rec.copy(), fin.copy()]
+        for it in range(K):
+            s.iterate(1)
+            l, L = s.gains()
+            res += [l.copy(), L.copy(), s.x().copy(), s.u().copy(), s.scalar("cost").copy(), s.scalar("lambda").copy(), s.ints("bp_calls").copy(),
+                    s.ints("alpha_idx").copy()]
+        s.close()
+        out.append(res)
+    assert np.concatenate([r for r in out[0][8::8]]).max() > 1  # lambda retries happen
+    for i, (a, b) in enumerate(zip(*out)):
+        assert np.array_equal(a, b), i
+
+
 def test_stored_tensors_in_the_quad_mapping_equal_the_row_mapping(ilqg, monkeypatch):
     """The hint-free n = 16 pair (stored tensors; its limitsU stores only zeros as the limits' gradients, which the build reads
     off the function file: tools/gen_record_dev.py limits_state_free) through k_backward_quad with the tensors read from the
