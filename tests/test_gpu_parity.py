@@ -1577,7 +1577,8 @@ def test_quad_lean_layout_equals_the_default(ilqg):
             assert np.array_equal(p[k], q[k]), (it, k)
 
 
-@pytest.mark.parametrize("problem,fd,strict", [("synth16x8", 1, False), ("synth16x8", 1, True), ("synth16x8", 0, False), ("synth16p", 0, False)])
+@pytest.mark.parametrize("problem,fd,strict", [("synth16x8", 1, False), ("synth16x8", 1, True), ("synth16x8", 0, False), ("synth16p", 0, False),
+                                               ("synth16x8", 1, "lean")])  # (round 6: the layout of two wavefronts per SIMD speculates as well)
 def test_speculative_retries_equal_the_sequential_sweeps(ilqg, monkeypatch, problem, fd, strict):
     """k_backward_quad with speculative retries (the default; k_wave_backward.inc SPEC): rows whose queue is used up run other
     trajectories' NEXT attempts (lambda_j replayed from the trajectory's lambda, iLQG.c:271-274) into buffers of their own,
