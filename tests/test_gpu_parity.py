@@ -1072,6 +1072,53 @@ def test_properties_at_full_benchmark_batch(ilqg, synth, oracle_built):
     d.close(); s.close(); small.close()
 
 
+def test_properties_at_config5_size_with_stored_tensors(ilqg, synth, oracle_built):
+    """BASELINE config 5 at full size from the pair WITHOUT hints (synth16x8_plain: stored tensors, 47.9 KB records): the
+    production path the fixture-sized tests (one piece of the record buffer) never reach — eight pieces per iteration on two
+    streams, the derivative kernel of one piece (private element with proxies, 512-byte records: ilqgdev) beside the
+    row-mapped backward kernel of the piece before it, constants written once per half of the buffer, the scalar
+    roll-outs with the 7-row second stage.  Accepted steps reduce the cost and rejected ones leave it untouched;
+    trajectories at piece boundaries and at the ends of the batch equal the same trajectories solved alone (one piece, no
+    neighbour kernel), bit for bit, over two iterations and again after a third (records of the buffer reused with their
+    constants in place); one of them equals the CPU oracle."""
+    B, N, iters = 16384, 1000, 2
+    x0, u0 = synth.synth16_batch(B, N)
+    s = ilqg.BatchSolver("synth16x8_plain", 1, batch=B, n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=50))
+    assert s.problem.wave_mapping
+    s.init(x0, u0)
+    prev = s.scalar("cost")
+    n_acc = 0
+    for _ in range(iters):
+        s.iterate(1)
+        c = s.scalar("cost")
+        acc = s.ints("accepted").astype(bool)
+        assert np.all(c[acc] < prev[acc]) and np.array_equal(c[~acc], prev[~acc])
+        n_acc += int(acc.sum())
+        prev = c
+    assert n_acc > B and np.all(s.ints("iterations") <= iters)
+    pick = [0, 1, 2047, 2048, 2049, 4095, 4096, 8191, 8192, 12345, 14335, 14336, 16383]
+    x2, u2, a2, c2 = s.x()[pick], s.u()[pick], s.ints("alpha_idx")[pick], prev[pick]
+    s.iterate(1)
+    x3, u3, c3, calls3 = s.x()[pick], s.u()[pick], s.scalar("cost")[pick], s.ints("bp_calls")[pick]
+    s.close()
+    small = ilqg.BatchSolver("synth16x8_plain", 1, batch=len(pick), n_hor=N, params=SYN_PARAMS, opts=dict(max_iter=50))
+    small.init(x0[pick], u0[pick])
+    small.iterate(iters)
+    assert np.array_equal(small.scalar("cost"), c2) and np.array_equal(small.ints("alpha_idx"), a2)
+    assert np.array_equal(small.x(), x2) and np.array_equal(small.u(), u2)
+    small.iterate(1)
+    assert np.array_equal(small.scalar("cost"), c3) and np.array_equal(small.ints("bp_calls"), calls3)
+    assert np.array_equal(small.x(), x3) and np.array_equal(small.u(), u3)
+    small.close()
+    b = 12345
+    d = Driver(lib_path("oracle", "synth16x8", 1), N, SYN_PARAMS, dict(max_iter=iters))
+    assert d.init(x0[b], u0[b]) == 1
+    d.solve()
+    assert close(c2[pick.index(b)], d.scalars()["cost"], 1e-9), (c2[pick.index(b)], d.scalars()["cost"])
+    assert np.abs(x2[pick.index(b)] - d.traj(0)[0]).max() < 1e-7
+    d.close()
+
+
 def test_properties_at_config5_size(ilqg, synth, oracle_built):
     """BASELINE config 5 at full size (synthetic n = 16, m = 8, N = 1000, FULL_DDP = 1, 16 384 trajectories): the
     production path of the wave mapping — two pieces of 8 192 trajectories on two streams, backward wavefronts taking
