@@ -288,7 +288,10 @@ def main(argv):
             return 1
     os.makedirs(argv[2], exist_ok=True)
     for w, name in (("problem", "iLQG_problem.h"), ("func", "iLQG_func.c")):
-        with open(os.path.join(argv[2], name), "w") as fh:
+        path = os.path.join(argv[2], name)
+        if os.path.exists(path) and open(path).read() == outs[w]:
+            continue  # (unchanged: keep the file's time, so that make rebuilds nothing that depends on it)
+        with open(path, "w") as fh:
             fh.write(outs[w])
     print("wrote %s/{iLQG_problem.h,iLQG_func.c} from the templates under %s" % (argv[2], ref))
     return 0
